@@ -1,0 +1,75 @@
+"""Pin the oracle (both restatements) to outputs of the real reference.
+
+The fixtures in tests/golden were produced by tools/make_golden.py from the
+unmodified reference in the build container."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_case
+from oracle import np_oracle, torch_oracle
+from oracle.schema import CONFIGS, num_params, state_dict_schema
+
+TINY = ["tiny_improved", "tiny_improved_d1", "tiny_improved_short", "tiny_groupcomm", "tiny_groupcomm_a2"]
+FULL = ["cfg1_improved_u8", "cfg1_improved_u8_pad", "cfg2_improved_u16", "cfg3_groupcomm_u8",
+        "cfg4_improved_u36_n2048"]
+
+
+def test_param_counts_match_readme():
+    # README.md:122-124,131-132 "#Params" column
+    assert num_params(CONFIGS["cfg2_improved_u16"]) == 5016353
+    assert num_params(CONFIGS["cfg3_groupcomm_u8"]) == 507177
+    assert num_params(CONFIGS["cfg4_improved_u36_n2048"]) == 23239241
+    assert num_params(CONFIGS["cfg5_improved_u36_n4096"]) == 26608201
+    assert len(state_dict_schema(CONFIGS["cfg2_improved_u16"])) == 489
+    assert len(state_dict_schema(CONFIGS["cfg3_groupcomm_u8"])) == 337
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_np_oracle_fp64_matches_reference(manifest, name):
+    cfg, sd, wav, gold = load_case(manifest, name)
+    out = np_oracle.forward(cfg, sd, wav, dtype=np.float64)
+    assert out.shape == gold["out"].shape
+    # reference ran in fp32: its own noise floor vs fp64 is ~1e-7..1e-6
+    assert np.abs(out - gold["out"]).max() < 5e-6
+    if "out_mixture_consistency" in gold:
+        mc = np_oracle.mixture_consistency(out, wav.astype(np.float64))
+        assert np.abs(mc - gold["out_mixture_consistency"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_np_oracle_fp32(manifest, name):
+    cfg, sd, wav, gold = load_case(manifest, name)
+    out = np_oracle.forward(cfg, sd, wav, dtype=np.float32)
+    assert out.dtype == np.float32
+    assert np.abs(out - gold["out"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("name", TINY + FULL)
+def test_torch_oracle_matches_reference(manifest, name):
+    cfg, sd, wav, gold = load_case(manifest, name)
+    with torch.no_grad():
+        out = torch_oracle.forward(cfg, torch_oracle.to_torch(sd), torch.from_numpy(wav))
+    assert tuple(out.shape) == gold["out"].shape
+    # same ATen op sequence as the reference -> agrees to rounding noise
+    assert np.abs(out.numpy() - gold["out"]).max() < 2e-6
+    if "out_mixture_consistency" in gold:
+        mc = torch_oracle.mixture_consistency(out, torch.from_numpy(wav))
+        assert np.abs(mc.numpy() - gold["out_mixture_consistency"]).max() < 2e-6
+
+
+def test_np_oracle_full_size_cfg1(manifest):
+    cfg, sd, wav, gold = load_case(manifest, "cfg1_improved_u8")
+    out = np_oracle.forward(cfg, sd, wav, dtype=np.float64)
+    assert np.abs(out - gold["out"]).max() < 5e-6
+
+
+def test_trace_keys(manifest):
+    cfg, sd, wav, _ = load_case(manifest, "tiny_groupcomm")
+    tr_np, tr_t = {}, {}
+    np_oracle.forward(cfg, sd, wav, trace=tr_np)
+    with torch.no_grad():
+        torch_oracle.forward(cfg, torch_oracle.to_torch(sd), torch.from_numpy(wav), trace=tr_t)
+    assert set(tr_np) == set(tr_t)
+    for k in tr_np:
+        assert np.abs(tr_np[k] - tr_t[k].numpy()).max() < 1e-4, k
