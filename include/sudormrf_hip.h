@@ -1,0 +1,163 @@
+/*
+ * sudormrf_hip.h -- C ABI of libsudormrf_hip.so, the MI355X (gfx950) hot path of
+ * SuDoRM-RF (Improved SuDORMRF and GroupComm SuDoRM-RF v2) inference forward.
+ *
+ * Boundary replaced (reference is pure PyTorch, paths relative to
+ * /root/reference/sudo_rm_rf/dnn/):
+ *   srf_forward            <- SuDORMRF.forward            models/improved_sudormrf.py:283-301
+ *                             GroupCommSudoRmRf.forward   models/groupcomm_sudormrf_v2.py:302-322
+ *   srf_encoder            <- self.encoder (nn.Conv1d)    models/improved_sudormrf.py:247-251,286
+ *                             + pad_to_appropriate_length :303-314 (folded into bounds checks)
+ *   srf_gln_stats/_apply   <- GlobLN.forward              models/improved_sudormrf.py:30-47
+ *   srf_pw_conv            <- nn.Conv1d(kernel_size=1) sites :256-259 (bottleneck), :174 (proj_1x1),
+ *                             :196,:220 (res_conv + residual), :268-269,:295-298 (mask_net + ReLU + *s)
+ *                             with the neighbouring GlobLN / PReLU folded into prologue / epilogue
+ *   srf_dwconv5            <- DilatedConvNorm.conv (depthwise k=5, stride 1|2) :152-153,:206-211
+ *   srf_merge              <- Upsample(x2 nearest) + add loop          :190-194,:214-216
+ *   srf_decoder            <- self.decoder (nn.ConvTranspose1d)        :272-279,:300 + crop :316-318
+ *   srf_tac                <- TAC.forward                 models/groupcomm_sudormrf_v2.py:356-377
+ *   srf_gln_apply_add      <- TAC_norm + residual add     models/groupcomm_sudormrf_v2.py:378-382
+ *   srf_mixture_consistency<- mixture_consistency.apply   experiments/utils/mixture_consistency.py:14-36
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (or fp64 for GlobLN sums) owned by the
+ *     caller; the library allocates nothing on the device and keeps no global state except a
+ *     thread-local error string;
+ *   - activations are [batch, channel, time] contiguous, exactly as the reference's tensors;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is asynchronous
+ *     on that stream, nothing synchronises;
+ *   - return value: 0 on success, a negative SRF_E* code otherwise (srf_last_error() has the text);
+ *     nothing throws across the ABI;
+ *   - GlobLN statistics travel as fp64 {sum, sum_of_squares} pairs ("sums", [groups][2]); producers
+ *     ACCUMULATE into them (atomics), so the caller zeroes them first (srf_forward does it itself).
+ */
+#ifndef SUDORMRF_HIP_H
+#define SUDORMRF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRF_ABI_VERSION 1
+
+#define SRF_OK 0
+#define SRF_EINVAL (-1)   /* bad argument / unsupported shape */
+#define SRF_EHIP (-2)     /* a HIP runtime call or kernel launch failed */
+#define SRF_EWORKSPACE (-3) /* workspace too small */
+
+#define SRF_VARIANT_IMPROVED 0
+#define SRF_VARIANT_GROUPCOMM 1
+
+/* Constructor arguments of the reference models, same meaning
+ * (improved_sudormrf.py:224-231, groupcomm_sudormrf_v2.py:232-241). */
+typedef struct srf_config {
+  int variant;           /* SRF_VARIANT_* */
+  int in_audio_channels; /* 1 for Improved */
+  int out_channels;      /* B */
+  int in_channels;       /* C */
+  int num_blocks;        /* U */
+  int upsampling_depth;  /* D */
+  int enc_kernel_size;   /* K (odd) */
+  int enc_num_basis;     /* N */
+  int num_sources;       /* S */
+  int group_size;        /* G (1 for Improved) */
+} srf_config;
+
+/* "Apply GlobLN (+ optional PReLU) to this tensor when it is loaded". */
+typedef struct srf_norm {
+  const double* sums;  /* [groups][2] {sum, sum of squares} over (channel,time); NULL = no normalisation */
+  const float* gamma;  /* [channels] */
+  const float* beta;   /* [channels] */
+  const float* prelu;  /* [1] shared slope, or NULL = no activation */
+} srf_norm;
+
+typedef struct srf_plan srf_plan;
+
+int srf_abi_version(void);
+const char* srf_last_error(void);
+
+/* Kernel-variant switch for A/B measurements: 0 = fast paths where the shape allows (default),
+ * 1 = force the generic (shape-agnostic, scalar-load) kernels everywhere. */
+void srf_set_kernel_mode(int mode);
+int srf_get_kernel_mode(void);
+
+/* ---- whole-model path ---------------------------------------------------------------------- */
+int srf_plan_create(const srf_config* cfg, int batch, int T, srf_plan** out);
+void srf_plan_destroy(srf_plan* plan);
+size_t srf_plan_workspace_bytes(const srf_plan* plan);
+int srf_plan_num_params(const srf_plan* plan);    /* tensors in state_dict() order */
+int srf_plan_frames(const srf_plan* plan);        /* L */
+int srf_plan_padded_length(const srf_plan* plan); /* T' */
+int srf_plan_num_launches(const srf_plan* plan);  /* kernel launches per forward (informational) */
+
+/* params: host array of num_params device pointers in the reference's state_dict() order
+ * (SURVEY.md Appendix A).  wav: [batch, in_audio_channels, T].  out: [batch, S*in_audio, T]. */
+int srf_forward(const srf_plan* plan, const float* const* params, int num_params,
+                const float* wav, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Copy an intermediate of the LAST srf_forward on this workspace into dst (for parity tests).
+ * what: 0 = encoder output [Bt,N,L], 1 = separation-module output [Bt,B,L], 2 = masked [Bt,S*A*N,L]. */
+int srf_debug_fetch(const srf_plan* plan, const void* workspace, int what, float* dst, size_t dst_floats,
+                    void* stream);
+
+/* ---- per-kernel entry points (unit parity + building blocks) -------------------------------- */
+
+/* out[b,n,l] = sum_{a,k} w[n,a,k] * xpad[b,a,h*l+k-h], h=K/2; samples outside [0,T) are zero, so the
+ * reference's right zero-padding is implicit in L.  sums (nullable): [Bt][2] += {sum, sumsq}. */
+int srf_encoder(const float* wav, const float* w, float* out, double* sums,
+                int Bt, int A, int T, int N, int K, int L, void* stream);
+
+/* sums[g][0..1] += {sum, sumsq} of x[g, :, :] (x: [groups, channels*length]). */
+int srf_gln_stats(const float* x, double* sums, int groups, long per_group, void* stream);
+/* y = gamma_c * (x - mu_g) / sqrt(var_g + 1e-8) + beta_c, then optional PReLU. */
+int srf_gln_apply(const float* x, float* y, const srf_norm* norm, int groups, int channels, int length,
+                  void* stream);
+/* y = x + GlobLN(q)  (TAC_norm + residual). */
+int srf_gln_apply_add(const float* x, const float* q, float* y, const srf_norm* norm, int groups,
+                      int channels, int length, void* stream);
+
+/* 1x1 convolution y[b,m,l] = bias[m] + sum_k w[m,k] * f(x[b,k,l])  (+ residual[b,m,l]),
+ * f = in_norm (GlobLN and/or PReLU on load; NULL = identity).
+ * epilogue_mask != 0:  y = relu(y) * mul[b, m % mul_channels, l]   (mask_nl_class + "* s.unsqueeze(1)").
+ * out_sums (nullable): [Bt][2] += {sum, sumsq} of the stored y. */
+int srf_pw_conv(const float* x, const float* w, const float* bias, float* y,
+                int Bt, int Cin, int Cout, int L, const srf_norm* in_norm, const float* residual,
+                double* out_sums, int epilogue_mask, const float* mul, int mul_channels, void* stream);
+
+/* Depthwise k=5, padding 2: y[r,j] = bias[c] + sum_k w[c,k] * f(x[r, stride*j+k-2]), r=(b,c), zero
+ * outside AFTER f (the reference pads the normalised tensor).  x: [Bt,C,Lin], y: [Bt,C,Lout],
+ * Lout = (Lin-1)/stride + 1. */
+int srf_dwconv5(const float* x, const float* w, const float* bias, float* y,
+                int Bt, int C, int Lin, int stride, const srf_norm* in_norm, double* out_sums,
+                void* stream);
+
+/* Bottom-up nearest-x2 upsample-and-add of D normalised levels:
+ * y[b,c,j] = n_0[j] + (n_1[j>>1] + (... + n_{D-1}[j>>(D-1)])),  n_k = GlobLN_k(levels[k]).
+ * levels[k]: [Bt,C,L>>k]; norms[k] describes level k (prelu ignored). */
+int srf_merge(const float* const* levels, const srf_norm* norms, int D, float* y,
+              int Bt, int C, int L, double* out_sums, void* stream);
+
+/* Transposed conv synthesis + crop: out[b,o,t] = sum_{ci,l,k: h*l+k-h=t} v[b,ci,l]*w[ci,o,k], t<T.
+ * v: [Bt,Ci,L], w: [Ci,Co,K] (ConvTranspose1d layout), out: [Bt,Co,T].
+ * scratch: device buffer of srf_decoder_scratch_floats() floats. */
+size_t srf_decoder_scratch_floats(int Bt, int Ci, int Co, int K, int L);
+int srf_decoder(const float* v, const float* w, float* out, int Bt, int Ci, int Co, int K, int L, int T,
+                float* scratch, void* stream);
+
+/* TAC up to (not including) TAC_norm: q[b,g,:,l] = PReLU(Wo [z_g ; PReLU(Wm mean_g z_g + bm)] + bo),
+ * z_g = PReLU(Wi x[b,g,:,l] + bi).  x,q: [Bt,G,n,L].  params: the 9 TAC tensors in state_dict order
+ * (TAC_input.0.weight/.bias, TAC_input.1.weight, TAC_mean.0.weight/.bias, TAC_mean.1.weight,
+ * TAC_output.0.weight/.bias, TAC_output.1.weight).  out_sums: [Bt*G][2]. */
+int srf_tac(const float* x, float* q, const float* const* params, int Bt, int G, int n, int H, int L,
+            double* out_sums, void* stream);
+
+/* pr + w * (mix - sum_s pr), uniform weights (w = 1/S).  pr,out: [Bt,S,T], mix: [Bt,1,T]. */
+int srf_mixture_consistency(const float* pr, const float* mix, float* out, int Bt, int S, int T,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUDORMRF_HIP_H */

@@ -1,0 +1,331 @@
+// Plan + whole-forward orchestration behind the C ABI (include/sudormrf_hip.h).
+//   srf_forward  <-  SuDORMRF.forward            improved_sudormrf.py:283-301
+//                    GroupCommSudoRmRf.forward   groupcomm_sudormrf_v2.py:302-322
+// One immutable plan per (config, batch, T): parameter indices in state_dict() order, workspace
+// carve-up, GlobLN statistic slots.  The library allocates nothing on the device: the caller hands
+// in one workspace buffer.  All launches go to the caller's stream; nothing synchronises.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "srf_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// error string / kernel mode
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int g_kernel_mode = 0;
+
+void srf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int srf_kernel_mode() { return g_kernel_mode; }
+
+extern "C" const char* srf_last_error(void) { return g_err; }
+extern "C" int srf_abi_version(void) { return SRF_ABI_VERSION; }
+extern "C" void srf_set_kernel_mode(int mode) { g_kernel_mode = mode ? 1 : 0; }
+extern "C" int srf_get_kernel_mode(void) { return g_kernel_mode; }
+
+int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
+int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T,
+                           hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// decoder = transpose(weight) -> frame GEMM (K2) -> overlap-add + crop
+// ---------------------------------------------------------------------------------------------
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" size_t srf_decoder_scratch_floats(int Bt, int Ci, int Co, int K, int L) {
+  const size_t M = (size_t)Co * K;
+  // wt [M][Ci] | zero bias [M] | z [Bt][M][L]   (each section 64-float aligned)
+  return align_up(M * Ci, 64) + align_up(M, 64) + align_up((size_t)Bt * M * L, 64);
+}
+
+extern "C" int srf_decoder(const float* v, const float* w, float* out, int Bt, int Ci, int Co, int K,
+                           int L, int T, float* scratch, void* stream) {
+  SRF_CHECK_ARG(v && w && out && scratch, "srf_decoder: null pointer");
+  SRF_CHECK_ARG(Bt > 0 && Ci > 0 && Co > 0 && L > 0 && T > 0, "srf_decoder: bad sizes");
+  SRF_CHECK_ARG(K >= 3 && (K & 1), "srf_decoder: kernel size must be odd (got %d)", K);
+  SRF_CHECK_ARG(T <= (K / 2) * L, "srf_decoder: T=%d exceeds hop*L=%d", T, (K / 2) * L);
+  SRF_CHECK_ARG(Co <= 65535 && Bt <= 65535, "srf_decoder: too many channels / batch");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = Co * K;
+  float* wt = scratch;
+  float* zb = wt + align_up((size_t)M * Ci, 64);
+  float* z = zb + align_up((size_t)M, 64);
+  int rc = srf_transpose_launch(w, wt, Ci, M, st);
+  if (rc) return rc;
+  SRF_CHECK_HIP(hipMemsetAsync(zb, 0, sizeof(float) * M, st));
+  rc = srf_pw_conv(v, wt, zb, z, Bt, Ci, M, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+  if (rc) return rc;
+  return srf_overlap_add_launch(z, out, Bt, Co, K, L, T, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------
+struct srf_plan {
+  srf_config cfg;
+  int Bt, T, Tp, L, A, SA;
+  int Bg, nB, nC;  // folded batch (Bt*G), channels outside / inside the U-block per group
+  int n_params, n_launches;
+  // parameter indices
+  int p_block0, p_block_stride, p_ublock_off, p_tail;
+  // workspace offsets (bytes)
+  size_t off_stats, stats_bytes, off_enc, off_xa, off_xb, off_xq, off_xu, off_y1, off_lv[SRF_MAX_DEPTH],
+      off_masked, off_dec, total_bytes;
+  int slots_per_block, n_slots;
+};
+
+static int plan_fail(srf_plan* p, int rc) {
+  delete p;
+  return rc;
+}
+
+extern "C" int srf_plan_create(const srf_config* c, int batch, int T, srf_plan** out) {
+  SRF_CHECK_ARG(c && out, "srf_plan_create: null pointer");
+  *out = nullptr;
+  SRF_CHECK_ARG(c->variant == SRF_VARIANT_IMPROVED || c->variant == SRF_VARIANT_GROUPCOMM,
+                "srf_plan_create: unknown variant %d", c->variant);
+  SRF_CHECK_ARG(batch > 0 && T > 0, "srf_plan_create: batch and T must be positive");
+  SRF_CHECK_ARG(c->out_channels > 0 && c->in_channels > 0 && c->num_blocks > 0 && c->enc_num_basis > 0 &&
+                    c->num_sources > 0,
+                "srf_plan_create: non-positive model dimension");
+  SRF_CHECK_ARG(c->upsampling_depth >= 1 && c->upsampling_depth <= SRF_MAX_DEPTH,
+                "srf_plan_create: upsampling_depth %d unsupported (1..%d)", c->upsampling_depth,
+                SRF_MAX_DEPTH);
+  SRF_CHECK_ARG(c->enc_kernel_size >= 3 && (c->enc_kernel_size & 1),
+                "srf_plan_create: enc_kernel_size must be odd (the reference's mask multiply breaks "
+                "for even sizes)");
+  srf_plan* p = new (std::nothrow) srf_plan;
+  SRF_CHECK_ARG(p != nullptr, "srf_plan_create: out of host memory");
+  memset(p, 0, sizeof(*p));
+  p->cfg = *c;
+  const bool gc = c->variant == SRF_VARIANT_GROUPCOMM;
+  const int G = gc ? c->group_size : 1;
+  p->A = gc ? c->in_audio_channels : 1;
+  if (G <= 0 || p->A <= 0) {
+    srf_set_error("srf_plan_create: group_size / in_audio_channels must be positive");
+    return plan_fail(p, SRF_EINVAL);
+  }
+  if (gc && (c->out_channels % G || c->in_channels % G)) {
+    srf_set_error("srf_plan_create: channels (%d,%d) not divisible by group_size %d", c->out_channels,
+                  c->in_channels, G);
+    return plan_fail(p, SRF_EINVAL);
+  }
+  if (gc) {
+    const int n = c->out_channels / G;
+    if (!(n == 2 || n == 4 || n == 8 || n == 16 || n == 32)) {
+      srf_set_error("srf_plan_create: out_channels/group_size = %d unsupported (2,4,8,16,32)", n);
+      return plan_fail(p, SRF_EINVAL);
+    }
+  }
+  const int D = c->upsampling_depth, U = c->num_blocks, K = c->enc_kernel_size;
+  const int h = K / 2;
+  const long nls = (long)h << D;  // n_least_samples_req, improved_sudormrf.py:244
+  long Tp = (T < nls) ? nls : ((T / nls) + (T % nls ? 1 : 0)) * nls;
+  p->Bt = batch;
+  p->T = T;
+  p->Tp = (int)Tp;
+  p->L = (int)((Tp + 2 * h - K) / h + 1);
+  p->SA = c->num_sources * p->A;
+  p->Bg = batch * G;
+  p->nB = c->out_channels / G;
+  p->nC = c->in_channels / G;
+  if (p->L % (1 << (D - 1)) != 0) {
+    srf_set_error("srf_plan_create: internal: L=%d not divisible by 2^(D-1)", p->L);
+    return plan_fail(p, SRF_EINVAL);
+  }
+  if ((long)p->Bg > 65535) {
+    srf_set_error("srf_plan_create: batch*group_size=%d too large (max 65535 per call)", p->Bg);
+    return plan_fail(p, SRF_EINVAL);
+  }
+  // ---- parameter indexing (state_dict order)
+  const int ublock_params = 10 + 4 * D;
+  p->p_block0 = 5;
+  p->p_ublock_off = gc ? 11 : 0;
+  p->p_block_stride = ublock_params + p->p_ublock_off;
+  p->p_tail = 5 + U * p->p_block_stride;
+  p->n_params = p->p_tail + 4;
+  // ---- statistic slots: ln | per block: [tac] proj d0..d{D-1} merged
+  p->slots_per_block = D + 2 + (gc ? 1 : 0);
+  p->n_slots = 1 + U * p->slots_per_block;
+  // ---- workspace
+  const size_t F = sizeof(float);
+  const size_t L = p->L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  p->stats_bytes = (size_t)p->n_slots * p->Bg * 2 * sizeof(double);
+  p->off_stats = take(p->stats_bytes);
+  p->off_enc = take(F * batch * c->enc_num_basis * L);
+  p->off_xa = take(F * batch * c->out_channels * L);
+  p->off_xb = take(F * batch * c->out_channels * L);
+  p->off_xq = gc ? take(F * batch * c->out_channels * L) : 0;
+  p->off_xu = gc ? take(F * batch * c->out_channels * L) : 0;
+  p->off_y1 = take(F * batch * c->in_channels * L);
+  for (int k = 0; k < D; ++k) p->off_lv[k] = take(F * batch * c->in_channels * (L >> k));
+  p->off_masked = take(F * batch * p->SA * c->enc_num_basis * L);
+  p->off_dec = take(F * srf_decoder_scratch_floats(batch, p->SA * c->enc_num_basis, p->SA, K, p->L));
+  p->total_bytes = off;
+  p->n_launches = 1 /*memset*/ + 2 + U * (D + 3 + (gc ? 2 : 0)) + 1 + 4;
+  *out = p;
+  return SRF_OK;
+}
+
+extern "C" void srf_plan_destroy(srf_plan* p) { delete p; }
+extern "C" size_t srf_plan_workspace_bytes(const srf_plan* p) { return p ? p->total_bytes : 0; }
+extern "C" int srf_plan_num_params(const srf_plan* p) { return p ? p->n_params : 0; }
+extern "C" int srf_plan_frames(const srf_plan* p) { return p ? p->L : 0; }
+extern "C" int srf_plan_padded_length(const srf_plan* p) { return p ? p->Tp : 0; }
+extern "C" int srf_plan_num_launches(const srf_plan* p) { return p ? p->n_launches : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_params, const float* wav,
+                           float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  SRF_CHECK_ARG(p && P && wav && out && workspace, "srf_forward: null pointer");
+  SRF_CHECK_ARG(num_params == p->n_params, "srf_forward: expected %d parameter tensors, got %d",
+                p->n_params, num_params);
+  if (workspace_bytes < p->total_bytes) {
+    srf_set_error("srf_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, p->total_bytes);
+    return SRF_EWORKSPACE;
+  }
+  SRF_CHECK_ARG((((size_t)workspace) & 255) == 0, "srf_forward: workspace must be 256-byte aligned");
+  for (int i = 0; i < num_params; ++i) SRF_CHECK_ARG(P[i] != nullptr, "srf_forward: parameter %d is null", i);
+
+  const srf_config& c = p->cfg;
+  const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;
+  const int G = gc ? c.group_size : 1;
+  const int D = c.upsampling_depth, U = c.num_blocks, N = c.enc_num_basis, K = c.enc_kernel_size;
+  const int Bt = p->Bt, L = p->L, Bg = p->Bg, nB = p->nB, nC = p->nC;
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  auto fptr = [&](size_t o) { return (float*)(ws + o); };
+  double* stats = (double*)(ws + p->off_stats);
+  auto slot = [&](int s) { return stats + (size_t)s * Bg * 2; };
+  int rc;
+
+  SRF_CHECK_HIP(hipMemsetAsync(stats, 0, p->stats_bytes, st));
+
+  // ---- front end: encoder (+ ln statistics), ln folded into the bottleneck GEMM's operand load
+  float* enc = fptr(p->off_enc);
+  rc = srf_encoder(wav, P[0], enc, slot(0), Bt, p->A, p->T, N, K, L, stream);
+  if (rc) return rc;
+  float* cur = fptr(p->off_xa);
+  float* nxt = fptr(p->off_xb);
+  {
+    srf_norm ln{slot(0), P[1], P[2], nullptr};
+    rc = srf_pw_conv(enc, P[3], P[4], cur, Bt, N, c.out_channels, L, &ln, nullptr, nullptr, 0, nullptr, 0,
+                     stream);
+    if (rc) return rc;
+  }
+
+  // ---- separation module
+  float* y1 = fptr(p->off_y1);
+  for (int i = 0; i < U; ++i) {
+    const float* const* Pb = P + p->p_block0 + (size_t)i * p->p_block_stride;
+    const float* const* Pu = Pb + p->p_ublock_off;
+    int s0 = 1 + i * p->slots_per_block;
+    const float* xin = cur;
+    if (gc) {
+      // TAC (groupcomm_sudormrf_v2.py:356-384): q = TAC MLPs, u = x + GlobLN_(b,g)(q)
+      float* xq = fptr(p->off_xq);
+      float* xu = fptr(p->off_xu);
+      rc = srf_tac(cur, xq, Pb, Bt, G, nB, 3 * nB, L, slot(s0), stream);
+      if (rc) return rc;
+      srf_norm tn{slot(s0), Pb[9], Pb[10], nullptr};
+      rc = srf_gln_apply_add(cur, xq, xu, &tn, Bg, nB, L, stream);
+      if (rc) return rc;
+      xin = xu;
+      s0 += 1;
+    }
+    // proj_1x1 conv (+ statistics for its GlobLN)            improved_sudormrf.py:205
+    rc = srf_pw_conv(xin, Pu[0], Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0), 0, nullptr, 0,
+                     stream);
+    if (rc) return rc;
+    // depthwise pyramid                                       :206-211
+    const float* levels[SRF_MAX_DEPTH];
+    srf_norm norms[SRF_MAX_DEPTH];
+    for (int k = 0; k < D; ++k) {
+      const float* const* Pk = Pu + 5 + 4 * k;
+      float* dk = fptr(p->off_lv[k]);
+      srf_norm in;
+      const float* src;
+      int Lin, stride;
+      if (k == 0) {
+        in = srf_norm{slot(s0), Pu[2], Pu[3], Pu[4]};  // proj_1x1.norm + act
+        src = y1;
+        Lin = L;
+        stride = 1;
+      } else {
+        const float* const* Pprev = Pu + 5 + 4 * (k - 1);
+        in = srf_norm{slot(s0 + k), Pprev[2], Pprev[3], nullptr};  // previous level's norm
+        src = fptr(p->off_lv[k - 1]);
+        Lin = L >> (k - 1);
+        stride = 2;
+      }
+      rc = srf_dwconv5(src, Pk[0], Pk[1], dk, Bg, nC, Lin, stride, &in, slot(s0 + 1 + k), stream);
+      if (rc) return rc;
+      levels[k] = dk;
+      norms[k] = srf_norm{slot(s0 + 1 + k), Pk[2], Pk[3], nullptr};
+    }
+    // upsample + add                                          :214-216   (output aliases y1: dead)
+    float* merged = y1;
+    rc = srf_merge(levels, norms, D, merged, Bg, nC, L, slot(s0 + 1 + D), stream);
+    if (rc) return rc;
+    // final_norm + PReLU folded into res_conv, + residual     :218-220
+    const float* const* Pf = Pu + 5 + 4 * D;
+    srf_norm fn{slot(s0 + 1 + D), Pf[0], Pf[1], Pf[2]};
+    rc = srf_pw_conv(merged, Pf[3], Pf[4], nxt, Bg, nC, nB, L, &fn, xin, nullptr, 0, nullptr, 0, stream);
+    if (rc) return rc;
+    float* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+
+  // ---- mask estimation + decoder                            :295-301
+  const float* const* Pt = P + p->p_tail;
+  float* masked = fptr(p->off_masked);
+  {
+    srf_norm pre{nullptr, nullptr, nullptr, Pt[0]};
+    rc = srf_pw_conv(cur, Pt[1], Pt[2], masked, Bt, c.out_channels, p->SA * N, L, &pre, nullptr, nullptr, 1,
+                     enc, N, stream);
+    if (rc) return rc;
+  }
+  rc = srf_decoder(masked, Pt[3], out, Bt, p->SA * N, p->SA, K, L, p->T, fptr(p->off_dec), stream);
+  return rc;
+}
+
+extern "C" int srf_debug_fetch(const srf_plan* p, const void* workspace, int what, float* dst,
+                               size_t dst_floats, void* stream) {
+  SRF_CHECK_ARG(p && workspace && dst, "srf_debug_fetch: null pointer");
+  const srf_config& c = p->cfg;
+  const char* ws = (const char*)workspace;
+  size_t off = 0, n = 0;
+  if (what == 0) {
+    off = p->off_enc;
+    n = (size_t)p->Bt * c.enc_num_basis * p->L;
+  } else if (what == 1) {
+    off = (c.num_blocks % 2 == 0) ? p->off_xa : p->off_xb;
+    n = (size_t)p->Bt * c.out_channels * p->L;
+  } else if (what == 2) {
+    off = p->off_masked;
+    n = (size_t)p->Bt * p->SA * c.enc_num_basis * p->L;
+  } else {
+    srf_set_error("srf_debug_fetch: unknown selector %d", what);
+    return SRF_EINVAL;
+  }
+  SRF_CHECK_ARG(dst_floats >= n, "srf_debug_fetch: destination too small (%zu < %zu)", dst_floats, n);
+  SRF_CHECK_HIP(hipMemcpyAsync(dst, ws + off, n * sizeof(float), hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream));
+  return SRF_OK;
+}

@@ -1,0 +1,108 @@
+// Shared device/host helpers for the gfx950 SuDoRM-RF kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/sudormrf_hip.h"
+
+#define SRF_WAVE 64
+#define SRF_MAX_DEPTH 8  // deepest upsampling_depth the merge kernel / plan support
+
+// ---------------------------------------------------------------------------------------------
+// host side: error reporting (thread-local string, never throws across the ABI)
+// ---------------------------------------------------------------------------------------------
+void srf_set_error(const char* fmt, ...);
+int srf_kernel_mode();  // 0 = fast paths allowed, 1 = generic kernels only
+
+#define SRF_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      srf_set_error(__VA_ARGS__);         \
+      return SRF_EINVAL;                  \
+    }                                     \
+  } while (0)
+
+#define SRF_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                \
+    hipError_t e__ = hipGetLastError();                                               \
+    if (e__ != hipSuccess) {                                                          \
+      srf_set_error("%s: kernel launch failed: %s", name, hipGetErrorString(e__));    \
+      return SRF_EHIP;                                                                \
+    }                                                                                 \
+  } while (0)
+
+#define SRF_CHECK_HIP(expr)                                                            \
+  do {                                                                                \
+    hipError_t e__ = (expr);                                                          \
+    if (e__ != hipSuccess) {                                                          \
+      srf_set_error("%s failed: %s", #expr, hipGetErrorString(e__));                  \
+      return SRF_EHIP;                                                                \
+    }                                                                                 \
+  } while (0)
+
+static inline bool srf_aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+struct SrfNormDev {  // by-value kernel argument mirror of srf_norm
+  const double* sums;
+  const float* gamma;
+  const float* beta;
+  const float* prelu;
+};
+
+static inline SrfNormDev srf_norm_dev(const srf_norm* n) {
+  SrfNormDev d{nullptr, nullptr, nullptr, nullptr};
+  if (n) {
+    d.sums = n->sums;
+    d.gamma = n->gamma;
+    d.beta = n->beta;
+    d.prelu = n->prelu;
+  }
+  return d;
+}
+
+// GlobLN statistics of one group from its fp64 {sum, sumsq}: mean and 1/sqrt(var_biased + 1e-8)
+// (reference: improved_sudormrf.py:44-47).  fp64 keeps E[x^2]-mu^2 free of cancellation trouble.
+__device__ __forceinline__ void srf_finalize_stats(const double* sums, long g, double inv_count,
+                                                   float& mean, float& rstd) {
+  const double s = sums[2 * g], q = sums[2 * g + 1];
+  const double m = s * inv_count;
+  double v = q * inv_count - m * m;
+  v = v < 0.0 ? 0.0 : v;
+  mean = (float)m;
+  rstd = (float)(1.0 / sqrt(v + 1e-8));
+}
+
+__device__ __forceinline__ double srf_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide {sum, sumsq} -> one fp64 atomic pair.  `sh` = 2*NWAVES doubles of LDS.
+// Must be reached by every thread of the block.
+template <int NWAVES>
+__device__ __forceinline__ void srf_block_stats_atomic(double s, double q, double* dst, double* sh) {
+  s = srf_wave_sum(s);
+  q = srf_wave_sum(q);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[w] = s;
+    sh[NWAVES + w] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int i = 0; i < NWAVES; ++i) {
+      a += sh[i];
+      b += sh[NWAVES + i];
+    }
+    atomicAdd(dst, a);
+    atomicAdd(dst + 1, b);
+  }
+}
+
+__device__ __forceinline__ float srf_prelu(float x, float a) { return x >= 0.f ? x : a * x; }

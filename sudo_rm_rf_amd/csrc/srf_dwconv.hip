@@ -1,0 +1,363 @@
+// K3 -- depthwise k=5 Conv1d (stride 1|2, padding 2, groups=C) with the PREVIOUS GlobLN (+PReLU)
+//       applied on load and the {sum,sumsq} of the output produced for the NEXT GlobLN
+//       (reference: DilatedConvNorm improved_sudormrf.py:138-159 as used in UConvBlock :178-189,
+//        :206-211; the conv zero-pads the *normalised* tensor, so out-of-range taps contribute 0).
+// K4 -- bottom-up nearest-x2 upsample + add over the D normalised levels (:190-194, :214-216), each
+//       level's GlobLN applied on load, {sum,sumsq} of the merged tensor produced for final_norm.
+//
+// Both are pure HBM streaming kernels (<= 5 MAC per 4-byte element).  Fast paths: one wavefront per
+// (batch,channel) row, 16-B loads/stores along time, halo exchange between neighbouring lanes with
+// wavefront shuffles (no LDS round trip), next chunk prefetched while the current one is computed,
+// per-channel scale/shift/taps wave-uniform.  Generic paths: one thread per output element.
+#include "srf_common.h"
+
+__device__ __forceinline__ void srf_wave_stats_atomic(double s, double q, double* dst) {
+  s = srf_wave_sum(s);
+  q = srf_wave_sum(q);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(dst, s);
+    atomicAdd(dst + 1, q);
+  }
+}
+
+struct RowCoef {
+  float sc, sh, slope;
+  bool act;
+};
+
+__device__ __forceinline__ RowCoef srf_row_coef(const SrfNormDev& nrm, long g, int c, double inv_count) {
+  RowCoef rc{1.f, 0.f, 1.f, false};
+  if (nrm.sums) {
+    float mean, rstd;
+    srf_finalize_stats(nrm.sums, g, inv_count, mean, rstd);
+    rc.sc = nrm.gamma[c] * rstd;
+    rc.sh = nrm.beta[c] - mean * rc.sc;
+  }
+  if (nrm.prelu) {
+    rc.act = true;
+    rc.slope = nrm.prelu[0];
+  }
+  return rc;
+}
+
+__device__ __forceinline__ float srf_tf(float v, const RowCoef& rc) {
+  v = fmaf(v, rc.sc, rc.sh);
+  if (rc.act) v = srf_prelu(v, rc.slope);
+  return v;
+}
+
+__device__ __forceinline__ float4 srf_tf4(float4 v, const RowCoef& rc) {
+  v.x = srf_tf(v.x, rc);
+  v.y = srf_tf(v.y, rc);
+  v.z = srf_tf(v.z, rc);
+  v.w = srf_tf(v.w, rc);
+  return v;
+}
+
+__device__ __forceinline__ float srf_tap5(float bs, float w0, float w1, float w2, float w3, float w4,
+                                          float x0, float x1, float x2, float x3, float x4) {
+  return fmaf(w4, x4, fmaf(w3, x3, fmaf(w2, x2, fmaf(w1, x1, fmaf(w0, x0, bs)))));
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise conv, generic: block = (row, chunk of 256 outputs), thread = one output
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_dwconv5_generic_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ y, SrfNormDev nrm, double inv_count, double* __restrict__ out_sums, int C,
+    int Lin, int Lout, int stride, int chunks) {
+  __shared__ double red[8];
+  const long row = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - row * chunks;
+  const int c = (int)(row % C);
+  const long b = row / C;
+  const RowCoef rc = srf_row_coef(nrm, b, c, inv_count);
+  const int j = chunk * 256 + threadIdx.x;
+  double ds = 0.0, dq = 0.0;
+  if (j < Lout) {
+    const float* xr = x + (size_t)row * Lin;
+    float acc = bias[c];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = stride * j + k - 2;
+      const float v = (i >= 0 && i < Lin) ? srf_tf(xr[i], rc) : 0.f;
+      acc = fmaf(w[c * 5 + k], v, acc);
+    }
+    y[(size_t)row * Lout + j] = acc;
+    ds = (double)acc;
+    dq = (double)acc * (double)acc;
+  }
+  if (out_sums) srf_block_stats_atomic<4>(ds, dq, out_sums + 2 * b, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise conv, fast: one wavefront per row; requires Lin % (4*STRIDE) == 0, 16-B aligned bases
+// ---------------------------------------------------------------------------------------------
+template <int STRIDE>
+__global__ __launch_bounds__(256) void srf_dwconv5_fast_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ y, SrfNormDev nrm, double inv_count, double* __restrict__ out_sums, int C,
+    int Lin, int Lout, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (row >= rows) return;  // wave-uniform; no block-level barrier below
+  const int c = (int)(row % C);
+  const long b = row / C;
+  const RowCoef rc = srf_row_coef(nrm, b, c, inv_count);
+  const float w0 = w[c * 5 + 0], w1 = w[c * 5 + 1], w2 = w[c * 5 + 2], w3 = w[c * 5 + 3],
+              w4 = w[c * 5 + 4];
+  const float bs = bias[c];
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * Lin);
+  float4* yr = reinterpret_cast<float4*>(y + (size_t)row * Lout);
+  const int nin4 = Lin >> 2, nout4 = Lout >> 2;
+  const int nchunks = (nout4 + 63) >> 6;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  double ds = 0.0, dq = 0.0;
+  float cz = 0.f, cw = 0.f;  // last two (transformed) inputs of the previous chunk = left halo of lane 0
+
+  if (STRIDE == 1) {
+    float4 nxt = (lane < nin4) ? srf_tf4(xr[lane], rc) : zero4;
+    for (int it = 0; it < nchunks; ++it) {
+      const float4 cur = nxt;
+      const int g = it * 64 + lane;
+      nxt = (g + 64 < nin4) ? srf_tf4(xr[g + 64], rc) : zero4;
+      float lz = __shfl_up(cur.z, 1, 64), lw = __shfl_up(cur.w, 1, 64);
+      float rx = __shfl_down(cur.x, 1, 64), ry = __shfl_down(cur.y, 1, 64);
+      const float nx0 = __shfl(nxt.x, 0, 64), ny0 = __shfl(nxt.y, 0, 64);
+      if (lane == 0) {
+        lz = cz;
+        lw = cw;
+      }
+      if (lane == 63) {
+        rx = nx0;
+        ry = ny0;
+      }
+      cz = __shfl(cur.z, 63, 64);
+      cw = __shfl(cur.w, 63, 64);
+      if (g < nout4) {
+        float4 o;
+        o.x = srf_tap5(bs, w0, w1, w2, w3, w4, lz, lw, cur.x, cur.y, cur.z);
+        o.y = srf_tap5(bs, w0, w1, w2, w3, w4, lw, cur.x, cur.y, cur.z, cur.w);
+        o.z = srf_tap5(bs, w0, w1, w2, w3, w4, cur.x, cur.y, cur.z, cur.w, rx);
+        o.w = srf_tap5(bs, w0, w1, w2, w3, w4, cur.y, cur.z, cur.w, rx, ry);
+        yr[g] = o;
+        const float s = (o.x + o.y) + (o.z + o.w);
+        const float q = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, o.w * o.w)));
+        ds += (double)s;
+        dq += (double)q;
+      }
+    }
+  } else {
+    // output group g (4 outputs j0..j0+3, j0 = 4g) needs inputs 2*j0-2 .. 2*j0+8:
+    // float4 A = in[2g], B = in[2g+1], left halo = left neighbour's (B.z,B.w), right = right's A.x
+    float4 nA = (2 * lane < nin4) ? srf_tf4(xr[2 * lane], rc) : zero4;
+    float4 nB = (2 * lane + 1 < nin4) ? srf_tf4(xr[2 * lane + 1], rc) : zero4;
+    for (int it = 0; it < nchunks; ++it) {
+      const float4 cA = nA, cB = nB;
+      const int g = it * 64 + lane;
+      const int gn = g + 64;
+      nA = (2 * gn < nin4) ? srf_tf4(xr[2 * gn], rc) : zero4;
+      nB = (2 * gn + 1 < nin4) ? srf_tf4(xr[2 * gn + 1], rc) : zero4;
+      float lz = __shfl_up(cB.z, 1, 64), lw = __shfl_up(cB.w, 1, 64);
+      float rx = __shfl_down(cA.x, 1, 64);
+      const float nx0 = __shfl(nA.x, 0, 64);
+      if (lane == 0) {
+        lz = cz;
+        lw = cw;
+      }
+      if (lane == 63) rx = nx0;
+      cz = __shfl(cB.z, 63, 64);
+      cw = __shfl(cB.w, 63, 64);
+      if (g < nout4) {
+        float4 o;
+        o.x = srf_tap5(bs, w0, w1, w2, w3, w4, lz, lw, cA.x, cA.y, cA.z);
+        o.y = srf_tap5(bs, w0, w1, w2, w3, w4, cA.x, cA.y, cA.z, cA.w, cB.x);
+        o.z = srf_tap5(bs, w0, w1, w2, w3, w4, cA.z, cA.w, cB.x, cB.y, cB.z);
+        o.w = srf_tap5(bs, w0, w1, w2, w3, w4, cB.x, cB.y, cB.z, cB.w, rx);
+        yr[g] = o;
+        const float s = (o.x + o.y) + (o.z + o.w);
+        const float q = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, o.w * o.w)));
+        ds += (double)s;
+        dq += (double)q;
+      }
+    }
+  }
+  if (out_sums) srf_wave_stats_atomic(ds, dq, out_sums + 2 * b);
+}
+
+extern "C" int srf_dwconv5(const float* x, const float* w, const float* bias, float* y, int Bt, int C,
+                           int Lin, int stride, const srf_norm* in_norm, double* out_sums,
+                           void* stream) {
+  SRF_CHECK_ARG(x && w && bias && y, "srf_dwconv5: null pointer");
+  SRF_CHECK_ARG(Bt > 0 && C > 0 && Lin > 0, "srf_dwconv5: bad sizes");
+  SRF_CHECK_ARG(stride == 1 || stride == 2, "srf_dwconv5: stride must be 1 or 2 (got %d)", stride);
+  const int Lout = (Lin - 1) / stride + 1;
+  const long rows = (long)Bt * C;
+  const double inv_count = 1.0 / ((double)C * (double)Lin);
+  SrfNormDev nd = srf_norm_dev(in_norm);
+  hipStream_t st = (hipStream_t)stream;
+  const bool fast = srf_kernel_mode() == 0 && (Lin % (4 * stride) == 0) && srf_aligned16(x) &&
+                    srf_aligned16(y) && rows < (1L << 32);
+  if (fast) {
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (stride == 1)
+      hipLaunchKernelGGL(srf_dwconv5_fast_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, nd,
+                         inv_count, out_sums, C, Lin, Lout, rows);
+    else
+      hipLaunchKernelGGL(srf_dwconv5_fast_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, nd,
+                         inv_count, out_sums, C, Lin, Lout, rows);
+  } else {
+    const int chunks = (Lout + 255) / 256;
+    const long blocks = rows * chunks;
+    SRF_CHECK_ARG(blocks < (1L << 31), "srf_dwconv5: tensor too large");
+    hipLaunchKernelGGL(srf_dwconv5_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias,
+                       y, nd, inv_count, out_sums, C, Lin, Lout, stride, chunks);
+  }
+  SRF_CHECK_LAUNCH("srf_dwconv5");
+  return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge (upsample-add over D levels)
+// ---------------------------------------------------------------------------------------------
+struct MergeArgs {
+  const float* lv[SRF_MAX_DEPTH];
+  SrfNormDev nrm[SRF_MAX_DEPTH];
+  double inv_count[SRF_MAX_DEPTH];
+  int D;
+};
+
+__global__ __launch_bounds__(256) void srf_merge_generic_kernel(MergeArgs a, float* __restrict__ y,
+                                                                double* __restrict__ out_sums, int C,
+                                                                int L, int chunks) {
+  __shared__ double red[8];
+  const long row = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - row * chunks;
+  const int c = (int)(row % C);
+  const long b = row / C;
+  const int j = chunk * 256 + threadIdx.x;
+  double ds = 0.0, dq = 0.0;
+  if (j < L) {
+    float t = 0.f;
+    for (int k = a.D - 1; k >= 0; --k) {
+      SrfNormDev nk = a.nrm[k];
+      nk.prelu = nullptr;
+      const RowCoef rc = srf_row_coef(nk, b, c, a.inv_count[k]);
+      const int Lk = L >> k;
+      const float v = srf_tf(a.lv[k][(size_t)row * Lk + (j >> k)], rc);
+      t = (k == a.D - 1) ? v : v + t;
+    }
+    y[(size_t)row * L + j] = t;
+    ds = (double)t;
+    dq = (double)t * (double)t;
+  }
+  if (out_sums) srf_block_stats_atomic<4>(ds, dq, out_sums + 2 * b, red);
+}
+
+// fast: one wavefront per row, lane = one float4 of level-0 output; level 1 as float2, deeper levels
+// as (lane-shared) dwords.  Requires L % 4 == 0 and L % 2^(D-1) == 0, aligned bases.
+__global__ __launch_bounds__(256) void srf_merge_fast_kernel(MergeArgs a, float* __restrict__ y,
+                                                             double* __restrict__ out_sums, int C, int L,
+                                                             long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c = (int)(row % C);
+  const long b = row / C;
+  const int D = a.D;
+  float sc[SRF_MAX_DEPTH], sh[SRF_MAX_DEPTH];
+#pragma unroll
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+    sc[k] = 1.f;
+    sh[k] = 0.f;
+    if (k < D) {
+      SrfNormDev nk = a.nrm[k];
+      nk.prelu = nullptr;
+      const RowCoef rc = srf_row_coef(nk, b, c, a.inv_count[k]);
+      sc[k] = rc.sc;
+      sh[k] = rc.sh;
+    }
+  }
+  const float4* l0 = reinterpret_cast<const float4*>(a.lv[0] + (size_t)row * L);
+  const float2* l1 = (D > 1) ? reinterpret_cast<const float2*>(a.lv[1] + (size_t)row * (L >> 1)) : nullptr;
+  float4* yr = reinterpret_cast<float4*>(y + (size_t)row * L);
+  const int n4 = L >> 2;
+  double ds = 0.0, dq = 0.0;
+  for (int g = lane; g < n4; g += 64) {
+    const float4 d0 = l0[g];
+    // levels >= 2 are constant over this lane's 4 outputs: bottom-up chain n_k + (n_{k+1} + ...)
+    float t = 0.f;
+    bool have = false;
+#pragma unroll
+    for (int k = SRF_MAX_DEPTH - 1; k >= 2; --k) {
+      if (k < D) {
+        const float v = a.lv[k][(size_t)row * (L >> k) + (g >> (k - 2))];
+        const float nk = fmaf(v, sc[k], sh[k]);
+        t = have ? nk + t : nk;
+        have = true;
+      }
+    }
+    float ta = t, tb = t;
+    if (D > 1) {
+      const float2 e = l1[g];
+      const float na = fmaf(e.x, sc[1], sh[1]), nb = fmaf(e.y, sc[1], sh[1]);
+      ta = have ? na + t : na;
+      tb = have ? nb + t : nb;
+    }
+    float4 o;
+    o.x = fmaf(d0.x, sc[0], sh[0]);
+    o.y = fmaf(d0.y, sc[0], sh[0]);
+    o.z = fmaf(d0.z, sc[0], sh[0]);
+    o.w = fmaf(d0.w, sc[0], sh[0]);
+    if (D > 1) {
+      o.x += ta;
+      o.y += ta;
+      o.z += tb;
+      o.w += tb;
+    }
+    yr[g] = o;
+    const float s = (o.x + o.y) + (o.z + o.w);
+    const float q = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, o.w * o.w)));
+    ds += (double)s;
+    dq += (double)q;
+  }
+  if (out_sums) srf_wave_stats_atomic(ds, dq, out_sums + 2 * b);
+}
+
+extern "C" int srf_merge(const float* const* levels, const srf_norm* norms, int D, float* y, int Bt,
+                         int C, int L, double* out_sums, void* stream) {
+  SRF_CHECK_ARG(levels && norms && y, "srf_merge: null pointer");
+  SRF_CHECK_ARG(D >= 1 && D <= SRF_MAX_DEPTH, "srf_merge: depth %d unsupported (1..%d)", D, SRF_MAX_DEPTH);
+  SRF_CHECK_ARG(Bt > 0 && C > 0 && L > 0, "srf_merge: bad sizes");
+  SRF_CHECK_ARG(L % (1 << (D - 1)) == 0, "srf_merge: L=%d not divisible by 2^(D-1)", L);
+  MergeArgs a;
+  bool aligned = srf_aligned16(y);
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+    a.lv[k] = nullptr;
+    a.nrm[k] = SrfNormDev{nullptr, nullptr, nullptr, nullptr};
+    a.inv_count[k] = 1.0;
+    if (k < D) {
+      SRF_CHECK_ARG(levels[k] != nullptr, "srf_merge: null level %d", k);
+      a.lv[k] = levels[k];
+      a.nrm[k] = srf_norm_dev(&norms[k]);
+      a.inv_count[k] = 1.0 / ((double)C * (double)(L >> k));
+      aligned = aligned && srf_aligned16(levels[k]);
+    }
+  }
+  a.D = D;
+  const long rows = (long)Bt * C;
+  hipStream_t st = (hipStream_t)stream;
+  const bool fast = srf_kernel_mode() == 0 && (L % 4 == 0) && aligned && rows < (1L << 32);
+  if (fast) {
+    hipLaunchKernelGGL(srf_merge_fast_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, y,
+                       out_sums, C, L, rows);
+  } else {
+    const int chunks = (L + 255) / 256;
+    const long blocks = rows * chunks;
+    SRF_CHECK_ARG(blocks < (1L << 31), "srf_merge: tensor too large");
+    hipLaunchKernelGGL(srf_merge_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, y, out_sums,
+                       C, L, chunks);
+  }
+  SRF_CHECK_LAUNCH("srf_merge");
+  return SRF_OK;
+}

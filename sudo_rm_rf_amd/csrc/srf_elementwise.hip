@@ -1,0 +1,181 @@
+// Stand-alone GlobLN pieces, TAC_norm + residual, mixture consistency, and the two small helpers of
+// the decoder (weight transpose, overlap-add).  All are pure HBM streaming kernels.
+//   GlobLN                      improved_sudormrf.py:30-47 (+ :24-27 gain/bias)
+//   TAC_norm + residual         groupcomm_sudormrf_v2.py:378-382
+//   mixture_consistency.apply   experiments/utils/mixture_consistency.py:14-36
+//   ConvTranspose1d overlap-add improved_sudormrf.py:272-279,300 and crop :316-318
+#include "srf_common.h"
+
+// ---- GlobLN statistics ------------------------------------------------------------------------
+// grid: (chunks, groups); each block reduces a contiguous slice of its group.
+__global__ __launch_bounds__(256) void srf_gln_stats_kernel(const float* __restrict__ x,
+                                                            double* __restrict__ sums, long per_group,
+                                                            long per_block) {
+  __shared__ double red[8];
+  const long g = blockIdx.y;
+  const long beg = (long)blockIdx.x * per_block;
+  long end = beg + per_block;
+  if (end > per_group) end = per_group;
+  const float* xg = x + g * per_group;
+  double ds = 0.0, dq = 0.0;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const float v = xg[i];
+    ds += (double)v;
+    dq += (double)v * (double)v;
+  }
+  srf_block_stats_atomic<4>(ds, dq, sums + 2 * g, red);
+}
+
+extern "C" int srf_gln_stats(const float* x, double* sums, int groups, long per_group, void* stream) {
+  SRF_CHECK_ARG(x && sums && groups > 0 && per_group > 0, "srf_gln_stats: bad arguments");
+  SRF_CHECK_ARG(groups <= 65535, "srf_gln_stats: too many groups");
+  const long per_block = 256 * 32;
+  const long chunks = (per_group + per_block - 1) / per_block;
+  dim3 grid((unsigned)chunks, (unsigned)groups);
+  hipLaunchKernelGGL(srf_gln_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, sums, per_group,
+                     per_block);
+  SRF_CHECK_LAUNCH("srf_gln_stats");
+  return SRF_OK;
+}
+
+// ---- GlobLN apply (optionally + residual input) ------------------------------------------------
+// One block per (row = (g,c), chunk of 1024 time steps).  ADD: y = xres + GlobLN(q).
+template <bool ADD>
+__global__ __launch_bounds__(256) void srf_gln_apply_kernel(const float* __restrict__ xres,
+                                                            const float* __restrict__ q,
+                                                            float* __restrict__ y, SrfNormDev nrm,
+                                                            double inv_count, int channels, int length,
+                                                            int chunks) {
+  const long row = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - row * chunks;
+  const int c = (int)(row % channels);
+  const long g = row / channels;
+  float sc = 1.f, sh = 0.f;
+  if (nrm.sums) {
+    float mean, rstd;
+    srf_finalize_stats(nrm.sums, g, inv_count, mean, rstd);
+    sc = nrm.gamma[c] * rstd;
+    sh = nrm.beta[c] - mean * sc;
+  }
+  const bool act = nrm.prelu != nullptr;
+  const float slope = act ? nrm.prelu[0] : 1.f;
+  const size_t base = (size_t)row * length;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int l = chunk * 1024 + u * 256 + threadIdx.x;
+    if (l < length) {
+      float v = fmaf(q[base + l], sc, sh);
+      if (act) v = srf_prelu(v, slope);
+      if (ADD) v = xres[base + l] + v;
+      y[base + l] = v;
+    }
+  }
+}
+
+static int gln_apply_launch(const float* xres, const float* q, float* y, const srf_norm* norm, int groups,
+                            int channels, int length, void* stream, bool add) {
+  SRF_CHECK_ARG(q && y && norm && groups > 0 && channels > 0 && length > 0, "srf_gln_apply: bad arguments");
+  const int chunks = (length + 1023) / 1024;
+  const long blocks = (long)groups * channels * chunks;
+  SRF_CHECK_ARG(blocks < (1L << 31), "srf_gln_apply: tensor too large");
+  const double inv_count = 1.0 / ((double)channels * (double)length);
+  SrfNormDev nd = srf_norm_dev(norm);
+  if (add)
+    hipLaunchKernelGGL(srf_gln_apply_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, xres, q, y, nd, inv_count, channels, length, chunks);
+  else
+    hipLaunchKernelGGL(srf_gln_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, xres, q, y, nd, inv_count, channels, length, chunks);
+  SRF_CHECK_LAUNCH("srf_gln_apply");
+  return SRF_OK;
+}
+
+extern "C" int srf_gln_apply(const float* x, float* y, const srf_norm* norm, int groups, int channels,
+                             int length, void* stream) {
+  return gln_apply_launch(nullptr, x, y, norm, groups, channels, length, stream, false);
+}
+
+extern "C" int srf_gln_apply_add(const float* x, const float* q, float* y, const srf_norm* norm,
+                                 int groups, int channels, int length, void* stream) {
+  SRF_CHECK_ARG(x != nullptr, "srf_gln_apply_add: null x");
+  return gln_apply_launch(x, q, y, norm, groups, channels, length, stream, true);
+}
+
+// ---- mixture consistency (uniform weights) -----------------------------------------------------
+__global__ __launch_bounds__(256) void srf_mixcons_kernel(const float* __restrict__ pr,
+                                                          const float* __restrict__ mix,
+                                                          float* __restrict__ out, int S, int T,
+                                                          long total /* Bt*T */) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / T;
+  const int t = (int)(i - b * T);
+  const float* p = pr + (size_t)b * S * T + t;
+  float sum = 0.f;
+  for (int s = 0; s < S; ++s) sum += p[(size_t)s * T];
+  const float corr = (1.0f / (float)S) * (mix[i] - sum);
+  float* o = out + (size_t)b * S * T + t;
+  for (int s = 0; s < S; ++s) o[(size_t)s * T] = p[(size_t)s * T] + corr;
+}
+
+extern "C" int srf_mixture_consistency(const float* pr, const float* mix, float* out, int Bt, int S,
+                                       int T, void* stream) {
+  SRF_CHECK_ARG(pr && mix && out && Bt > 0 && S > 0 && T > 0, "srf_mixture_consistency: bad arguments");
+  const long total = (long)Bt * T;
+  hipLaunchKernelGGL(srf_mixcons_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, pr, mix, out, S, T, total);
+  SRF_CHECK_LAUNCH("srf_mixture_consistency");
+  return SRF_OK;
+}
+
+// ---- decoder helpers ---------------------------------------------------------------------------
+// wt[m][ci] = w[ci][m]   (w: [Ci][M] = ConvTranspose1d weight with (o,k) flattened to m)
+__global__ __launch_bounds__(256) void srf_transpose_kernel(const float* __restrict__ w,
+                                                            float* __restrict__ wt, int Ci, int M) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = c0 + r, m = m0 + tx;
+    tile[r][tx] = (ci < Ci && m < M) ? w[(size_t)ci * M + m] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int m = m0 + r, ci = c0 + tx;
+    if (m < M && ci < Ci) wt[(size_t)m * Ci + ci] = tile[tx][r];
+  }
+}
+
+int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st) {
+  dim3 grid((M + 31) / 32, (Ci + 31) / 32);
+  hipLaunchKernelGGL(srf_transpose_kernel, grid, dim3(256), 0, st, w, wt, Ci, M);
+  SRF_CHECK_LAUNCH("srf_transpose");
+  return SRF_OK;
+}
+
+// out[b,o,t] = sum over the <=3 (frame l, tap k) pairs with h*l + k - h = t of z[b, o*K + k, l]
+// q = t / h, r = t % h:  (l=q+1,k=r), (l=q,k=r+h), and (l=q-1,k=2h) when r == 0.
+__global__ __launch_bounds__(256) void srf_overlap_add_kernel(const float* __restrict__ z,
+                                                              float* __restrict__ out, int Co, int K,
+                                                              int L, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int o = blockIdx.y;
+  const long b = blockIdx.z;
+  const int h = K / 2;
+  const int q = t / h, r = t - q * h;
+  const float* zb = z + ((size_t)b * Co * K + (size_t)o * K) * L;
+  float acc = 0.f;
+  if (r == 0 && q >= 1 && q - 1 < L) acc += zb[(size_t)(2 * h) * L + (q - 1)];
+  if (q < L) acc += zb[(size_t)(r + h) * L + q];
+  if (q + 1 < L) acc += zb[(size_t)r * L + (q + 1)];
+  out[((size_t)b * Co + o) * T + t] = acc;
+}
+
+int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T,
+                           hipStream_t st) {
+  dim3 grid((T + 255) / 256, Co, Bt);
+  hipLaunchKernelGGL(srf_overlap_add_kernel, grid, dim3(256), 0, st, z, out, Co, K, L, T);
+  SRF_CHECK_LAUNCH("srf_overlap_add");
+  return SRF_OK;
+}

@@ -1,0 +1,273 @@
+// K2 -- pointwise (kernel_size=1) Conv1d as a GEMM over [channel, time], with the neighbouring
+// GlobLN / PReLU folded into the operand load and bias / residual / ReLU-mask / GlobLN statistics
+// folded into the epilogue.  Sites (improved_sudormrf.py): bottleneck :256-259,:292 (prologue = ln),
+// proj_1x1 :174,:205 (epilogue statistics for its GlobLN), res_conv :196,:220 (prologue =
+// final_norm + PReLU, epilogue = + residual), mask_net :268-269,:295-298 (prologue = PReLU,
+// epilogue = ReLU * encoder output), and the decoder's frame GEMM (srf_api.hip).
+//
+//   y[b, m, l] = bias[m] + sum_k w[m, k] * f(x[b, k, l])        W: [Cout, Cin] row-major (Conv1d
+//   weight [Cout, Cin, 1]), X_b: [Cin, L] row-major -> time is the contiguous GEMM-N dimension.
+//
+// MFMA path: exact-fp32 v_mfma_f32_32x32x2_f32 (gfx950 has no xf32/TF32; bf16 operands break the
+// 1e-4 parity bar), 128x128 block tile, BK=16, 4 wavefronts each owning a 64x64 quadrant (2x2 MFMA
+// tiles, 64 accumulator VGPRs), operands staged global -> registers (transform) -> LDS in [k][m] /
+// [k][n] layout so every MFMA operand fetch is a conflict-free ds_read_b32, register prefetch of the
+// next k-tile under the current tile's MFMAs, one barrier per k-tile (double-buffered LDS).
+// Blocks are numbered so that the M-tiles sharing one X tile run back-to-back on one XCD (L2 reuse).
+// Generic path (any shape, small channel counts): one thread per time step, MT outputs in registers,
+// weights as scalar operands.
+#include "srf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PwArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  const float* residual;
+  double* out_sums;
+  const float* mul;
+  SrfNormDev nrm;
+  double inv_count;
+  int Cin, Cout, L, Bt;
+  int mul_channels;
+  int epi_mask;
+};
+
+// ---------------------------------------------------------------------------------------------
+// generic VALU kernel
+// ---------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void srf_pw_generic_kernel(PwArgs a) {
+  __shared__ double red[8];
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  const int m0 = blockIdx.y * MT;
+  const long b = blockIdx.z;
+  const bool valid = l < a.L;
+  float mean = 0.f, rstd = 1.f;
+  const bool has_norm = a.nrm.sums != nullptr;
+  if (has_norm) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
+  const bool act = a.nrm.prelu != nullptr;
+  const float slope = act ? a.nrm.prelu[0] : 1.f;
+  float acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = 0.f;
+  const float* xb = a.x + (size_t)b * a.Cin * a.L;
+  for (int k = 0; k < a.Cin; ++k) {
+    float xv = valid ? xb[(size_t)k * a.L + l] : 0.f;
+    if (has_norm) {
+      const float sc = a.nrm.gamma[k] * rstd;
+      xv = fmaf(xv, sc, a.nrm.beta[k] - mean * sc);
+    }
+    if (act) xv = srf_prelu(xv, slope);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + i;
+      const float wv = (m < a.Cout) ? a.w[(size_t)m * a.Cin + k] : 0.f;
+      acc[i] = fmaf(wv, xv, acc[i]);
+    }
+  }
+  double ds = 0.0, dq = 0.0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + i;
+    if (m < a.Cout && valid) {
+      const size_t idx = ((size_t)b * a.Cout + m) * a.L + l;
+      float v = acc[i] + a.bias[m];
+      if (a.residual) v += a.residual[idx];
+      if (a.epi_mask)
+        v = fmaxf(v, 0.f) * a.mul[((size_t)b * a.mul_channels + (m % a.mul_channels)) * a.L + l];
+      a.y[idx] = v;
+      ds += (double)v;
+      dq += (double)v * (double)v;
+    }
+  }
+  if (a.out_sums) srf_block_stats_atomic<4>(ds, dq, a.out_sums + 2 * b, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA kernel
+// ---------------------------------------------------------------------------------------------
+constexpr int PW_BM = 128, PW_BN = 128, PW_BK = 16;
+constexpr int PW_LDA = PW_BM + 4;  // padded row pitch (floats) of the [k][m] / [k][n] LDS tiles
+constexpr int PW_LDB = PW_BN + 4;
+
+// PRO: 0 = identity, 1 = GlobLN, 2 = GlobLN + PReLU, 3 = PReLU only
+template <int PRO>
+__global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int nLt, int total) {
+  __shared__ __attribute__((aligned(16))) float As[2][PW_BK][PW_LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][PW_BK][PW_LDB];
+  __shared__ double red[8];
+
+  // ---- XCD-aware tile numbering: hardware places block id on XCD id%8; give each XCD a contiguous
+  // run of virtual ids so the nMt blocks that share one X tile hit the same L2 (bijective remap).
+  const int id = blockIdx.x;
+  const int xcd = id & 7, slot = id >> 3;
+  const int qn = total >> 3, rn = total & 7;
+  const int v = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  const int mt = v % nMt;
+  const int lt = (v / nMt) % nLt;
+  const long b = v / (nMt * nLt);
+  const int m0 = mt * PW_BM, l0 = lt * PW_BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  float mean = 0.f, rstd = 1.f, slope = 1.f;
+  if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
+  if (PRO == 2 || PRO == 3) slope = a.nrm.prelu[0];
+
+  const float* xb = a.x + (size_t)b * a.Cin * a.L;
+  const int Cin = a.Cin, L = a.L, Cout = a.Cout;
+
+  // staging assignment
+  const int a_m = tid >> 2;        // 0..63 (+64 second pass)
+  const int a_kq = (tid & 3) * 4;  // k offset of this thread's float4 inside the k-tile
+  const int b_r = tid >> 5;        // 0..7 (+8 second pass)
+  const int b_c = (tid & 31) * 4;  // column offset of this thread's float4
+
+  float4 ra[2], rb[2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = m0 + a_m + 64 * p;
+      ra[p] = (m < Cout) ? *reinterpret_cast<const float4*>(a.w + (size_t)m * Cin + k0 + a_kq)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int k = k0 + b_r + 8 * p;
+      const int l = l0 + b_c;
+      float4 xv = (l < L) ? *reinterpret_cast<const float4*>(xb + (size_t)k * L + l)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRO == 1 || PRO == 2) {
+        const float sc = a.nrm.gamma[k] * rstd;
+        const float sh = a.nrm.beta[k] - mean * sc;
+        xv.x = fmaf(xv.x, sc, sh);
+        xv.y = fmaf(xv.y, sc, sh);
+        xv.z = fmaf(xv.z, sc, sh);
+        xv.w = fmaf(xv.w, sc, sh);
+      }
+      if (PRO == 2 || PRO == 3) {
+        xv.x = srf_prelu(xv.x, slope);
+        xv.y = srf_prelu(xv.y, slope);
+        xv.z = srf_prelu(xv.z, slope);
+        xv.w = srf_prelu(xv.w, slope);
+      }
+      rb[p] = xv;
+    }
+  };
+  auto lds_store = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = a_m + 64 * p;
+      As[buf][a_kq + 0][m] = ra[p].x;
+      As[buf][a_kq + 1][m] = ra[p].y;
+      As[buf][a_kq + 2][m] = ra[p].z;
+      As[buf][a_kq + 3][m] = ra[p].w;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      *reinterpret_cast<float4*>(&Bs[buf][b_r + 8 * p][b_c]) = rb[p];
+  };
+
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+  const int nk = Cin / PW_BK;
+  gload(0);
+  lds_store(0);
+  __syncthreads();
+  const int kh = lane >> 5, col = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * PW_BK);
+#pragma unroll
+    for (int kk = 0; kk < PW_BK / 2; ++kk) {
+      const float a0 = As[buf][2 * kk + kh][wm * 64 + col];
+      const float a1 = As[buf][2 * kk + kh][wm * 64 + 32 + col];
+      const float b0 = Bs[buf][2 * kk + kh][wn * 64 + col];
+      const float b1 = Bs[buf][2 * kk + kh][wn * 64 + 32 + col];
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+    }
+    if (kt + 1 < nk) lds_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float s = 0.f, q = 0.f;
+  auto epi = [&](const f32x16& acc, int i2, int j2) {
+    const int l = l0 + wn * 64 + j2 * 32 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (m < Cout && l < L) {
+        const size_t idx = ((size_t)b * Cout + m) * L + l;
+        float v = acc[r] + a.bias[m];
+        if (a.residual) v += a.residual[idx];
+        if (a.epi_mask)
+          v = fmaxf(v, 0.f) * a.mul[((size_t)b * a.mul_channels + (m % a.mul_channels)) * L + l];
+        a.y[idx] = v;
+        s += v;
+        q = fmaf(v, v, q);
+      }
+    }
+  };
+  epi(acc00, 0, 0);
+  epi(acc01, 0, 1);
+  epi(acc10, 1, 0);
+  epi(acc11, 1, 1);
+  if (a.out_sums) srf_block_stats_atomic<4>((double)s, (double)q, a.out_sums + 2 * b, red);
+}
+
+extern "C" int srf_pw_conv(const float* x, const float* w, const float* bias, float* y, int Bt, int Cin,
+                           int Cout, int L, const srf_norm* in_norm, const float* residual,
+                           double* out_sums, int epilogue_mask, const float* mul, int mul_channels,
+                           void* stream) {
+  SRF_CHECK_ARG(x && w && bias && y, "srf_pw_conv: null pointer");
+  SRF_CHECK_ARG(Bt > 0 && Cin > 0 && Cout > 0 && L > 0, "srf_pw_conv: bad sizes");
+  SRF_CHECK_ARG(!epilogue_mask || (mul && mul_channels > 0), "srf_pw_conv: mask epilogue needs mul");
+  PwArgs a;
+  a.x = x;
+  a.w = w;
+  a.bias = bias;
+  a.y = y;
+  a.residual = residual;
+  a.out_sums = out_sums;
+  a.mul = mul;
+  a.nrm = srf_norm_dev(in_norm);
+  a.inv_count = 1.0 / ((double)Cin * (double)L);
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.L = L;
+  a.Bt = Bt;
+  a.mul_channels = mul_channels > 0 ? mul_channels : 1;
+  a.epi_mask = epilogue_mask ? 1 : 0;
+  if (a.nrm.sums) SRF_CHECK_ARG(a.nrm.gamma && a.nrm.beta, "srf_pw_conv: norm without gamma/beta");
+  hipStream_t st = (hipStream_t)stream;
+
+  const bool mfma_ok = srf_kernel_mode() == 0 && (Cin % PW_BK == 0) && (L % 4 == 0) && Cout >= 32 &&
+                       Cin >= 32 && srf_aligned16(x) && srf_aligned16(w);
+  if (mfma_ok) {
+    const int nMt = (Cout + PW_BM - 1) / PW_BM, nLt = (L + PW_BN - 1) / PW_BN;
+    const long total = (long)Bt * nMt * nLt;
+    SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
+    const int pro = a.nrm.sums ? (a.nrm.prelu ? 2 : 1) : (a.nrm.prelu ? 3 : 0);
+    dim3 grid((unsigned)total), block(256);
+    switch (pro) {
+      case 0: hipLaunchKernelGGL(srf_pw_mfma_kernel<0>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
+      case 1: hipLaunchKernelGGL(srf_pw_mfma_kernel<1>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
+      case 2: hipLaunchKernelGGL(srf_pw_mfma_kernel<2>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
+      default: hipLaunchKernelGGL(srf_pw_mfma_kernel<3>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
+    }
+  } else {
+    SRF_CHECK_ARG(Bt <= 65535, "srf_pw_conv: batch too large for the generic kernel");
+    constexpr int MT = 16;
+    dim3 grid((L + 255) / 256, (Cout + MT - 1) / MT, Bt);
+    hipLaunchKernelGGL(srf_pw_generic_kernel<MT>, grid, dim3(256), 0, st, a);
+  }
+  SRF_CHECK_LAUNCH("srf_pw_conv");
+  return SRF_OK;
+}

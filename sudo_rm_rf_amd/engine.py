@@ -1,0 +1,138 @@
+"""Host-side engine: plan / workspace cache and the single srf_forward call per model forward.
+
+Python owns tensors and module structure only; all arithmetic happens in libsudormrf_hip.so.
+"""
+import ctypes as C
+import threading
+import warnings
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+_MAX_PLANS = 4
+
+
+def _config_struct(variant, in_audio_channels, out_channels, in_channels, num_blocks, upsampling_depth,
+                   enc_kernel_size, enc_num_basis, num_sources, group_size):
+    return _lib.srf_config(
+        variant=_lib.VARIANT_GROUPCOMM if variant == "groupcomm" else _lib.VARIANT_IMPROVED,
+        in_audio_channels=in_audio_channels, out_channels=out_channels, in_channels=in_channels,
+        num_blocks=num_blocks, upsampling_depth=upsampling_depth, enc_kernel_size=enc_kernel_size,
+        enc_num_basis=enc_num_basis, num_sources=num_sources, group_size=group_size)
+
+
+class Plan:
+    """An immutable srf_plan plus the workspace it needs (owned by torch's allocator)."""
+
+    def __init__(self, cfg_tuple, batch, T, device):
+        lib = _lib.load()
+        self.cfg_tuple, self.batch, self.T, self.device = cfg_tuple, batch, T, device
+        cfg = _config_struct(*cfg_tuple)
+        handle = C.c_void_p()
+        _lib.check(lib.srf_plan_create(C.byref(cfg), batch, T, C.byref(handle)), "srf_plan_create")
+        self.handle = handle
+        self.workspace_bytes = lib.srf_plan_workspace_bytes(handle)
+        self.num_params = lib.srf_plan_num_params(handle)
+        self.frames = lib.srf_plan_frames(handle)
+        self.padded_length = lib.srf_plan_padded_length(handle)
+        self.num_launches = lib.srf_plan_num_launches(handle)
+        self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=device)
+        if self.workspace.data_ptr() % 256:
+            raise _lib.SrfError("torch returned a workspace that is not 256-byte aligned")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().srf_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def forward(self, param_ptrs, wav, out):
+        lib = _lib.load()
+        rc = lib.srf_forward(self.handle, param_ptrs, self.num_params, _lib.ptr(wav), _lib.ptr(out),
+                             _lib.ptr(self.workspace), self.workspace_bytes,
+                             _lib.current_stream(wav.device))
+        _lib.check(rc, "srf_forward")
+
+    def debug_fetch(self, what, shape):
+        dst = torch.empty(shape, dtype=torch.float32, device=self.device)
+        rc = _lib.load().srf_debug_fetch(self.handle, _lib.ptr(self.workspace), what, _lib.ptr(dst),
+                                         dst.numel(), _lib.current_stream(self.device))
+        _lib.check(rc, "srf_debug_fetch")
+        return dst
+
+
+class ModelEngine:
+    """Per-model state: plan cache (per device / batch / length) and the parameter pointer table."""
+
+    def __init__(self, cfg_tuple):
+        self.cfg_tuple = cfg_tuple
+        self._plans = OrderedDict()
+        self._ptr_cache = {}
+        self._lock = threading.Lock()
+        self._warned_grad = False
+        self.last_plan = None
+
+    def plan_for(self, batch, T, device):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), batch, T)
+        with self._lock:
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = Plan(self.cfg_tuple, batch, T, device)
+                self._plans[key] = plan
+                while len(self._plans) > _MAX_PLANS:
+                    self._plans.popitem(last=False)
+            else:
+                self._plans.move_to_end(key)
+        return plan
+
+    def _param_table(self, params, device):
+        key = tuple(p.data_ptr() for p in params)
+        dkey = device.index
+        cached = self._ptr_cache.get(dkey)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        arr = (C.c_void_p * len(key))(*key)
+        self._ptr_cache[dkey] = (key, arr)
+        return arr
+
+    def run(self, module, wav, expected_channels):
+        if not isinstance(wav, torch.Tensor):
+            raise TypeError("input must be a torch.Tensor")
+        if wav.dim() != 3:
+            # the reference fails on non-3D input too (Conv1d on the padded tensor)
+            raise RuntimeError("expected input of shape [batch, %d, time], got %s" %
+                               (expected_channels, tuple(wav.shape)))
+        if wav.shape[1] != expected_channels:
+            raise RuntimeError("expected %d input channel(s), got %d" % (expected_channels, wav.shape[1]))
+        if wav.device.type != "cuda":
+            raise _lib.SrfError(
+                "sudo_rm_rf_amd runs on an MI355X only: input is on %s.  There is deliberately no CPU "
+                "fallback (use the reference implementation for CPU inference)." % wav.device)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()) and \
+                not self._warned_grad:
+            self._warned_grad = True
+            warnings.warn("sudo_rm_rf_amd: forward is inference-only in this build; the output does "
+                          "not carry autograd history.", stacklevel=3)
+        params = [p.detach() for p in module.state_dict(keep_vars=True).values()]
+        for p in params:
+            if p.device != wav.device or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.SrfError("all parameters must be contiguous float32 on %s" % wav.device)
+        # the reference's pad buffer is float32 whatever the input dtype (improved_sudormrf.py:312)
+        x = wav.detach().to(torch.float32).contiguous()
+        batch, _, T = x.shape
+        if batch == 0 or T == 0:
+            raise RuntimeError("empty input %s" % (tuple(wav.shape),))
+        with torch.cuda.device(x.device):
+            plan = self.plan_for(batch, T, x.device)
+            if plan.num_params != len(params):
+                raise _lib.SrfError("state_dict has %d tensors, plan expects %d" %
+                                    (len(params), plan.num_params))
+            out_ch = module.num_sources * expected_channels
+            out = torch.empty((batch, out_ch, T), dtype=torch.float32, device=x.device)
+            plan.forward(self._param_table(params, x.device), x, out)
+            self.last_plan = plan
+        return out

@@ -1,0 +1,167 @@
+"""Per-kernel Python wrappers over the C ABI (unit parity tests and sub-module forwards).
+
+Every function takes CUDA float32 tensors, launches on torch's current stream and returns new
+tensors.  GlobLN statistics travel as float64 ``sums`` tensors of shape [groups, 2]
+({sum, sum of squares}); producers accumulate into them, so pass zero-initialised tensors.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _chk(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise _lib.SrfError("sudo_rm_rf_amd ops need CUDA (ROCm) tensors; got %s" % t.device)
+        if not t.is_contiguous():
+            raise _lib.SrfError("tensor must be contiguous")
+        dev = t.device
+    return dev
+
+
+def new_sums(groups, device):
+    return torch.zeros((groups, 2), dtype=torch.float64, device=device)
+
+
+def _norm(sums, gamma, beta, prelu):
+    if sums is None and gamma is None and beta is None and prelu is None:
+        return None
+    return C.byref(_lib.make_norm(sums, gamma, beta, prelu))
+
+
+def encoder(wav, weight, L, sums=None):
+    """wav [Bt,A,T], weight [N,A,K] -> [Bt,N,L]  (reference: improved_sudormrf.py:247-251,286)."""
+    dev = _chk(wav, weight, sums)
+    Bt, A, T = wav.shape
+    N, A2, K = weight.shape
+    assert A == A2
+    out = torch.empty((Bt, N, L), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().srf_encoder(_lib.ptr(wav), _lib.ptr(weight), _lib.ptr(out), _lib.ptr(sums),
+                                       Bt, A, T, N, K, L, _lib.current_stream(dev)), "srf_encoder")
+    return out
+
+
+def gln_stats(x, groups):
+    dev = _chk(x)
+    sums = new_sums(groups, dev)
+    per_group = x.numel() // groups
+    _lib.check(_lib.load().srf_gln_stats(_lib.ptr(x), _lib.ptr(sums), groups, per_group,
+                                         _lib.current_stream(dev)), "srf_gln_stats")
+    return sums
+
+
+def gln_apply(x, sums, gamma, beta, prelu=None, residual=None):
+    """x [groups, channels, length]; y = GlobLN(x) (+PReLU), or residual + GlobLN(x)."""
+    dev = _chk(x, sums, gamma, beta, prelu, residual)
+    groups, channels = x.shape[0], x.shape[1]
+    length = x.numel() // (groups * channels)
+    y = torch.empty_like(x)
+    n = _lib.make_norm(sums, gamma, beta, prelu)
+    lib = _lib.load()
+    if residual is None:
+        rc = lib.srf_gln_apply(_lib.ptr(x), _lib.ptr(y), C.byref(n), groups, channels, length,
+                               _lib.current_stream(dev))
+    else:
+        rc = lib.srf_gln_apply_add(_lib.ptr(residual), _lib.ptr(x), _lib.ptr(y), C.byref(n), groups,
+                                   channels, length, _lib.current_stream(dev))
+    _lib.check(rc, "srf_gln_apply")
+    return y
+
+
+def glob_ln(x, gamma, beta):
+    """GlobLN.forward (improved_sudormrf.py:30-47) on [batch, channels, *]."""
+    x = x.contiguous()
+    return gln_apply(x, gln_stats(x, x.shape[0]), gamma, beta)
+
+
+def pw_conv(x, weight, bias, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None, residual=None,
+            out_sums=None, mask_mul=None):
+    """1x1 conv with fused prologue / epilogue.  x [Bt,Cin,L], weight [Cout,Cin(,1)] -> [Bt,Cout,L]."""
+    dev = _chk(x, weight, bias, in_sums, in_gamma, in_beta, in_prelu, residual, out_sums, mask_mul)
+    Bt, Cin, L = x.shape
+    Cout = weight.shape[0]
+    assert weight.numel() == Cout * Cin
+    y = torch.empty((Bt, Cout, L), dtype=torch.float32, device=dev)
+    rc = _lib.load().srf_pw_conv(
+        _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), Bt, Cin, Cout, L,
+        _norm(in_sums, in_gamma, in_beta, in_prelu), _lib.ptr(residual), _lib.ptr(out_sums),
+        1 if mask_mul is not None else 0, _lib.ptr(mask_mul),
+        mask_mul.shape[1] if mask_mul is not None else 0, _lib.current_stream(dev))
+    _lib.check(rc, "srf_pw_conv")
+    return y
+
+
+def dwconv5(x, weight, bias, stride, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None,
+            out_sums=None):
+    """depthwise k=5 conv.  x [Bt,C,Lin], weight [C,1,5] -> [Bt,C,Lout]."""
+    dev = _chk(x, weight, bias, in_sums, in_gamma, in_beta, in_prelu, out_sums)
+    Bt, Cc, Lin = x.shape
+    Lout = (Lin - 1) // stride + 1
+    y = torch.empty((Bt, Cc, Lout), dtype=torch.float32, device=dev)
+    rc = _lib.load().srf_dwconv5(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), Bt, Cc, Lin,
+                                 stride, _norm(in_sums, in_gamma, in_beta, in_prelu), _lib.ptr(out_sums),
+                                 _lib.current_stream(dev))
+    _lib.check(rc, "srf_dwconv5")
+    return y
+
+
+def merge(levels, sums, gammas, betas, out_sums=None):
+    """levels[k] [Bt,C,L>>k] (pre-norm) -> merged [Bt,C,L] (improved_sudormrf.py:214-216)."""
+    dev = _chk(*levels, *sums, *gammas, *betas, out_sums)
+    D = len(levels)
+    Bt, Cc, L = levels[0].shape
+    y = torch.empty((Bt, Cc, L), dtype=torch.float32, device=dev)
+    lv = (C.c_void_p * D)(*[t.data_ptr() for t in levels])
+    norms = (_lib.srf_norm * D)(*[_lib.make_norm(s, g, b, None) for s, g, b in zip(sums, gammas, betas)])
+    rc = _lib.load().srf_merge(lv, norms, D, _lib.ptr(y), Bt, Cc, L, _lib.ptr(out_sums),
+                               _lib.current_stream(dev))
+    _lib.check(rc, "srf_merge")
+    return y
+
+
+def decoder(v, weight, T):
+    """v [Bt,Ci,L], weight [Ci,Co,K] -> [Bt,Co,T]  (improved_sudormrf.py:272-279,300,316-318)."""
+    dev = _chk(v, weight)
+    Bt, Ci, L = v.shape
+    Ci2, Co, K = weight.shape
+    assert Ci == Ci2
+    lib = _lib.load()
+    scratch = torch.empty(lib.srf_decoder_scratch_floats(Bt, Ci, Co, K, L), dtype=torch.float32, device=dev)
+    out = torch.empty((Bt, Co, T), dtype=torch.float32, device=dev)
+    rc = lib.srf_decoder(_lib.ptr(v), _lib.ptr(weight), _lib.ptr(out), Bt, Ci, Co, K, L, T,
+                         _lib.ptr(scratch), _lib.current_stream(dev))
+    _lib.check(rc, "srf_decoder")
+    return out
+
+
+def tac(x4, params, out_sums=None):
+    """x4 [Bt,G,n,L]; params = the 9 TAC tensors in state_dict order -> pre-norm q [Bt,G,n,L]."""
+    dev = _chk(x4, *params, out_sums)
+    Bt, G, n, L = x4.shape
+    H = params[0].shape[0]
+    q = torch.empty_like(x4)
+    pp = (C.c_void_p * 9)(*[p.data_ptr() for p in params])
+    rc = _lib.load().srf_tac(_lib.ptr(x4), _lib.ptr(q), pp, Bt, G, n, H, L, _lib.ptr(out_sums),
+                             _lib.current_stream(dev))
+    _lib.check(rc, "srf_tac")
+    return q
+
+
+def mixture_consistency(pr_batch, input_mixture):
+    dev = _chk(pr_batch, input_mixture)
+    Bt, S, T = pr_batch.shape
+    out = torch.empty_like(pr_batch)
+    rc = _lib.load().srf_mixture_consistency(_lib.ptr(pr_batch), _lib.ptr(input_mixture), _lib.ptr(out),
+                                             Bt, S, T, _lib.current_stream(dev))
+    _lib.check(rc, "srf_mixture_consistency")
+    return out
+
+
+def set_kernel_mode(mode):
+    """0 = fast paths (default), 1 = generic kernels only (A/B measurements)."""
+    _lib.load().srf_set_kernel_mode(int(mode))
