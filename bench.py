@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- separated-seconds/sec of the SuDoRM-RF forward hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one forward of Improved SuDoRM-RF U16/512 (BASELINE.json configs[1]) over one batch of 32
+synthetic 4 s @ 8 kHz mixtures already resident in HBM, through the C ABI (srf_forward).  With N GPUs
+every rank runs its own batch of 32 (batch sharding = weak scaling, no data-path collective); the
+timed region is bracketed by barrier + synchronize and the max over ranks is reported.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (variant, ctor kwargs, T, fs, default per-GPU batch)
+    "cfg2_improved_u16": ("improved", dict(out_channels=256, in_channels=512, num_blocks=16,
+                                           upsampling_depth=5, enc_kernel_size=21, enc_num_basis=512,
+                                           num_sources=2), 32000, 8000, 32),
+    "cfg1_improved_u8": ("improved", dict(out_channels=256, in_channels=512, num_blocks=8,
+                                          upsampling_depth=5, enc_kernel_size=21, enc_num_basis=512,
+                                          num_sources=2), 32000, 8000, 1),
+    "cfg3_groupcomm_u8": ("groupcomm", dict(in_audio_channels=1, out_channels=256, in_channels=512,
+                                            num_blocks=8, upsampling_depth=5, enc_kernel_size=21,
+                                            enc_num_basis=512, num_sources=2, group_size=16), 32000, 8000, 32),
+    "cfg4_improved_u36_n2048": ("improved", dict(out_channels=512, in_channels=512, num_blocks=36,
+                                                 upsampling_depth=6, enc_kernel_size=21,
+                                                 enc_num_basis=2048, num_sources=2), 32000, 8000, 32),
+    "cfg5_improved_u36_n4096": ("improved", dict(out_channels=512, in_channels=512, num_blocks=36,
+                                                 upsampling_depth=6, enc_kernel_size=21,
+                                                 enc_num_basis=4096, num_sources=2), 128000, 16000, 16),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2_improved_u16", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--kernel-mode", type=int, default=0, help="1 = generic kernels only (A/B)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-repeats", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(variant, kw, T, fs, batch, repeats):
+    """The oracle's torch-CPU restatement (same ATen op sequence as the reference's nn.Modules; the
+    reference tree itself is not present on the GPU box) timed on the host cores: kind = "port"."""
+    import torch
+    from oracle import torch_oracle
+    from oracle.schema import ModelConfig
+    from oracle.weights import make_mixture, make_state_dict
+    cfg = ModelConfig(variant=variant, **kw)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = torch_oracle.to_torch(make_state_dict(cfg, seed=0))
+    wav = torch.from_numpy(make_mixture(batch, T, seed=0))
+    with torch.no_grad():
+        torch_oracle.forward(cfg, sd, wav)                       # warm-up
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            torch_oracle.forward(cfg, sd, wav)
+        dt = (time.perf_counter() - t0) / repeats
+    return {"value": batch * (T / fs) / dt, "unit": "separated-seconds/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "seconds_per_forward": dt,
+            "sample": "oracle/torch_oracle.forward on %d of the workload's mixtures (batch %d), 1 warm-up + "
+                      "%d timed forwards, %d host threads" % (batch, batch, repeats, torch.get_num_threads())}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_gpus = world
+    if args.gpus != n_gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d (launch through torch.distributed.run for N>1)" %
+              (args.gpus, world), file=sys.stderr)
+
+    from sudo_rm_rf_amd import _lib, ops, roofline
+    import sudo_rm_rf.dnn.models.improved_sudormrf as improved_sudormrf
+    import sudo_rm_rf.dnn.models.groupcomm_sudormrf_v2 as sudormrf_gc_v2
+    _lib.load()
+    ops.set_kernel_mode(args.kernel_mode)
+
+    variant, kw, T, fs, def_batch = WORKLOADS[args.workload]
+    batch = args.batch or def_batch
+    torch.manual_seed(0)
+    cls = improved_sudormrf.SuDORMRF if variant == "improved" else sudormrf_gc_v2.GroupCommSudoRmRf
+    model = cls(**kw).to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)           # a different shard per rank
+    wav = torch.randn(batch, 1, T, generator=g)
+    wav = ((wav - wav.mean(-1, keepdim=True)) / (wav.std(-1, keepdim=True) + 1e-9)).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(wav)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(wav)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.shape == (batch, kw["num_sources"], T) and bool(torch.isfinite(out).all())
+    ms_per_step = 1e3 * dt / args.steps
+    value = n_gpus * batch * (T / fs) * args.steps / dt
+
+    G = kw.get("group_size", 1) if variant == "groupcomm" else 1
+    dims = dict(variant=variant, B=kw["out_channels"], C=kw["in_channels"], U=kw["num_blocks"],
+                D=kw["upsampling_depth"], K=kw["enc_kernel_size"], N=kw["enc_num_basis"],
+                S=kw["num_sources"], T=T, G=G)
+    alg_bytes = roofline.bytes_per_example(**dims) * batch
+    alg_flops = roofline.flops_per_example(**dims) * batch
+    fwd_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
+    result = {
+        "metric": "separated-seconds/sec (4s@8kHz mixtures), Improved-U16/512, 1->8 MI355X"
+        if args.workload == "cfg2_improved_u16" else "separated-seconds/sec, " + args.workload,
+        "value": value, "unit": "separated-seconds/sec", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s forward, batch %d per GPU, T=%d (%.0f s @ %d Hz), inference" %
+                               (args.workload, batch, T, T / fs, fs),
+                   "global_batch": batch * n_gpus, "parallelism": "batch-sharded replicas x%d" % n_gpus,
+                   "kernel_mode": args.kernel_mode},
+        "forward_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": fwd_gbs / roofline.HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_forward": alg_bytes,
+                             "algorithmic_tflops": alg_flops / (ms_per_step * 1e-3) / 1e12},
+    }
+
+    # ---- per-kernel durations with HIP events on the launch stream (separate instrumented pass) ----
+    if rank == 0 and not args.no_kernel_profile:
+        import ctypes as C
+        lib = _lib.load()
+        stream = _lib.current_stream(dev)
+        psteps = min(args.steps, 10)
+        with torch.no_grad():
+            lib.srf_profile_begin(stream)
+            for _ in range(psteps):
+                model(wav)
+            cnt = C.c_int(0)
+            _lib.check(lib.srf_profile_end(stream, C.byref(cnt)), "srf_profile_end")
+        launches = roofline.launch_model(Bt=batch, **dims)
+        per = {}
+        name, ms = C.c_char_p(), C.c_float()
+        assert cnt.value == psteps * len(launches), (cnt.value, psteps, len(launches))
+        for i in range(cnt.value):
+            lib.srf_profile_get(i, C.byref(name), C.byref(ms))
+            fam, nbytes, flops = launches[i % len(launches)]
+            k = name.value.decode()
+            e = per.setdefault(k, {"ms": 0.0, "launches": 0, "bytes": 0.0, "flops": 0.0})
+            e["ms"] += ms.value
+            e["launches"] += 1
+            e["bytes"] += nbytes
+            e["flops"] += flops
+        kernels = {}
+        for k, e in per.items():
+            sec = e["ms"] * 1e-3
+            kernels[k] = {"ms_per_forward": e["ms"] / psteps, "launches_per_forward": e["launches"] // psteps,
+                          "avg_launch_us": 1e3 * e["ms"] / e["launches"],
+                          "algorithmic_GBps": e["bytes"] / sec / 1e9, "TFLOPs": e["flops"] / sec / 1e12}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_forward"])
+        kd = kernels[dom]
+        if dom.startswith("pw_conv"):
+            rl = {"kernel": dom, "bound": "mfma", "achieved": kd["TFLOPs"], "peak": roofline.MFMA_F32_PEAK_TFLOPS,
+                  "unit": "TFLOP/s", "frac": kd["TFLOPs"] / roofline.MFMA_F32_PEAK_TFLOPS, "traffic": None}
+        else:
+            rl = {"kernel": dom, "bound": "hbm", "achieved": kd["algorithmic_GBps"], "peak": roofline.HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": kd["algorithmic_GBps"] / roofline.HBM_PEAK_GBS, "traffic": None}
+        rl["avg_launch_us"] = kd["avg_launch_us"]
+        rl["share_of_forward"] = kd["ms_per_forward"] / sum(v["ms_per_forward"] for v in kernels.values())
+        result["roofline"] = rl
+        result["kernels"] = kernels
+    elif rank == 0:
+        result["roofline"] = dict(result["forward_roofline"], traffic=None)
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(variant, kw, T, fs, args.cpu_batch, args.cpu_repeats)
+        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,14 @@ const char* srf_last_error(void);
 void srf_set_kernel_mode(int mode);
 int srf_get_kernel_mode(void);
 
+/* In-library profiler (bench.py): between begin/end every kernel launched through this library is
+ * followed by a HIP event on the caller's stream; end() synchronises the stream and get(i) returns
+ * the kernel family name and the elapsed ms between the previous event and launch i's event
+ * (i.e. that launch's duration including its launch gap).  Not thread-safe; off by default. */
+int srf_profile_begin(void* stream);
+int srf_profile_end(void* stream, int* count);
+int srf_profile_get(int i, const char** name, float* ms);
+
 /* ---- whole-model path ---------------------------------------------------------------------- */
 int srf_plan_create(const srf_config* cfg, int batch, int T, srf_plan** out);
 void srf_plan_destroy(srf_plan* plan);

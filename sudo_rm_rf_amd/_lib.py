@@ -37,6 +37,9 @@ _PROTOS = {
     "srf_last_error": (C.c_char_p, []),
     "srf_set_kernel_mode": (None, [_i]),
     "srf_get_kernel_mode": (_i, []),
+    "srf_profile_begin": (_i, [_vp]),
+    "srf_profile_end": (_i, [_vp, C.POINTER(_i)]),
+    "srf_profile_get": (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     "srf_plan_create": (_i, [C.POINTER(srf_config), _i, _i, C.POINTER(_vp)]),
     "srf_plan_destroy": (None, [_vp]),
     "srf_plan_workspace_bytes": (_sz, [_vp]),

@@ -25,6 +25,58 @@ void srf_set_error(const char* fmt, ...) {
 }
 int srf_kernel_mode() { return g_kernel_mode; }
 
+// ---- in-library HIP-event profiler: one event after every kernel launch on the caller's stream ------
+struct ProfMark {
+  const char* name;
+  hipEvent_t ev;
+};
+static bool g_prof = false;
+static std::vector<ProfMark> g_marks;
+static std::vector<hipEvent_t> g_pool;
+static std::vector<float> g_ms;
+
+bool srf_profiling() { return g_prof; }
+void srf_prof_mark(const char* name, hipStream_t st) {
+  hipEvent_t ev;
+  if (!g_pool.empty()) {
+    ev = g_pool.back();
+    g_pool.pop_back();
+  } else if (hipEventCreate(&ev) != hipSuccess) {
+    return;
+  }
+  (void)hipEventRecord(ev, st);
+  g_marks.push_back(ProfMark{name, ev});
+}
+
+extern "C" int srf_profile_begin(void* stream) {
+  for (auto& m : g_marks) g_pool.push_back(m.ev);
+  g_marks.clear();
+  g_ms.clear();
+  g_prof = true;
+  srf_prof_mark("begin", (hipStream_t)stream);
+  return SRF_OK;
+}
+
+extern "C" int srf_profile_end(void* stream, int* count) {
+  g_prof = false;
+  SRF_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  g_ms.assign(g_marks.size(), 0.f);
+  for (size_t i = 1; i < g_marks.size(); ++i) {
+    float ms = 0.f;
+    SRF_CHECK_HIP(hipEventElapsedTime(&ms, g_marks[i - 1].ev, g_marks[i].ev));
+    g_ms[i] = ms;
+  }
+  if (count) *count = g_marks.empty() ? 0 : (int)g_marks.size() - 1;
+  return SRF_OK;
+}
+
+extern "C" int srf_profile_get(int i, const char** name, float* ms) {
+  SRF_CHECK_ARG(i >= 0 && (size_t)(i + 1) < g_marks.size() && name && ms, "srf_profile_get: bad index %d", i);
+  *name = g_marks[i + 1].name;
+  *ms = g_ms[i + 1];
+  return SRF_OK;
+}
+
 extern "C" const char* srf_last_error(void) { return g_err; }
 extern "C" int srf_abi_version(void) { return SRF_ABI_VERSION; }
 extern "C" void srf_set_kernel_mode(int mode) { g_kernel_mode = mode ? 1 : 0; }

@@ -13,6 +13,8 @@
 // ---------------------------------------------------------------------------------------------
 void srf_set_error(const char* fmt, ...);
 int srf_kernel_mode();  // 0 = fast paths allowed, 1 = generic kernels only
+bool srf_profiling();
+void srf_prof_mark(const char* name, hipStream_t st);
 
 #define SRF_CHECK_ARG(cond, ...)          \
   do {                                    \
@@ -22,13 +24,15 @@ int srf_kernel_mode();  // 0 = fast paths allowed, 1 = generic kernels only
     }                                     \
   } while (0)
 
-#define SRF_CHECK_LAUNCH(name)                                                        \
+// after every kernel launch: surface launch errors; in profiling mode drop a HIP event on the stream
+#define SRF_CHECK_LAUNCH(name, st)                                                    \
   do {                                                                                \
     hipError_t e__ = hipGetLastError();                                               \
     if (e__ != hipSuccess) {                                                          \
       srf_set_error("%s: kernel launch failed: %s", name, hipGetErrorString(e__));    \
       return SRF_EHIP;                                                                \
     }                                                                                 \
+    if (srf_profiling()) srf_prof_mark(name, (hipStream_t)(st));                      \
   } while (0)
 
 #define SRF_CHECK_HIP(expr)                                                            \

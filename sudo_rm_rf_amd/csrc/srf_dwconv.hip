@@ -213,7 +213,7 @@ extern "C" int srf_dwconv5(const float* x, const float* w, const float* bias, fl
     hipLaunchKernelGGL(srf_dwconv5_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias,
                        y, nd, inv_count, out_sums, C, Lin, Lout, stride, chunks);
   }
-  SRF_CHECK_LAUNCH("srf_dwconv5");
+  SRF_CHECK_LAUNCH(fast ? (stride == 1 ? "dwconv5_s1_fast" : "dwconv5_s2_fast") : "dwconv5_generic", st);
   return SRF_OK;
 }
 
@@ -358,6 +358,6 @@ extern "C" int srf_merge(const float* const* levels, const srf_norm* norms, int 
     hipLaunchKernelGGL(srf_merge_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, y, out_sums,
                        C, L, chunks);
   }
-  SRF_CHECK_LAUNCH("srf_merge");
+  SRF_CHECK_LAUNCH(fast ? "merge_fast" : "merge_generic", st);
   return SRF_OK;
 }

@@ -34,7 +34,7 @@ extern "C" int srf_gln_stats(const float* x, double* sums, int groups, long per_
   dim3 grid((unsigned)chunks, (unsigned)groups);
   hipLaunchKernelGGL(srf_gln_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, sums, per_group,
                      per_block);
-  SRF_CHECK_LAUNCH("srf_gln_stats");
+  SRF_CHECK_LAUNCH("gln_stats", stream);
   return SRF_OK;
 }
 
@@ -86,7 +86,7 @@ static int gln_apply_launch(const float* xres, const float* q, float* y, const s
   else
     hipLaunchKernelGGL(srf_gln_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
                        (hipStream_t)stream, xres, q, y, nd, inv_count, channels, length, chunks);
-  SRF_CHECK_LAUNCH("srf_gln_apply");
+  SRF_CHECK_LAUNCH(add ? "gln_apply_add" : "gln_apply", stream);
   return SRF_OK;
 }
 
@@ -124,7 +124,7 @@ extern "C" int srf_mixture_consistency(const float* pr, const float* mix, float*
   const long total = (long)Bt * T;
   hipLaunchKernelGGL(srf_mixcons_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, pr, mix, out, S, T, total);
-  SRF_CHECK_LAUNCH("srf_mixture_consistency");
+  SRF_CHECK_LAUNCH("mixture_consistency", stream);
   return SRF_OK;
 }
 
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void srf_transpose_kernel(const float* __restr
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st) {
   dim3 grid((M + 31) / 32, (Ci + 31) / 32);
   hipLaunchKernelGGL(srf_transpose_kernel, grid, dim3(256), 0, st, w, wt, Ci, M);
-  SRF_CHECK_LAUNCH("srf_transpose");
+  SRF_CHECK_LAUNCH("transpose", st);
   return SRF_OK;
 }
 
@@ -176,6 +176,6 @@ int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, in
                            hipStream_t st) {
   dim3 grid((T + 255) / 256, Co, Bt);
   hipLaunchKernelGGL(srf_overlap_add_kernel, grid, dim3(256), 0, st, z, out, Co, K, L, T);
-  SRF_CHECK_LAUNCH("srf_overlap_add");
+  SRF_CHECK_LAUNCH("overlap_add", st);
   return SRF_OK;
 }

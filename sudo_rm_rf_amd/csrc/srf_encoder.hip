@@ -126,6 +126,6 @@ extern "C" int srf_encoder(const float* wav, const float* w, float* out, double*
     hipLaunchKernelGGL(srf_encoder_generic_kernel, grid, dim3(256), lds, st, wav, w, out, sums, A, T, N,
                        K, L);
   }
-  SRF_CHECK_LAUNCH("srf_encoder");
+  SRF_CHECK_LAUNCH("encoder", st);
   return SRF_OK;
 }

@@ -268,6 +268,6 @@ extern "C" int srf_pw_conv(const float* x, const float* w, const float* bias, fl
     dim3 grid((L + 255) / 256, (Cout + MT - 1) / MT, Bt);
     hipLaunchKernelGGL(srf_pw_generic_kernel<MT>, grid, dim3(256), 0, st, a);
   }
-  SRF_CHECK_LAUNCH("srf_pw_conv");
+  SRF_CHECK_LAUNCH(mfma_ok ? "pw_conv_mfma" : "pw_conv_generic", st);
   return SRF_OK;
 }

@@ -132,6 +132,6 @@ extern "C" int srf_tac(const float* x, float* q, const float* const* params, int
       srf_set_error("srf_tac: channels per group n=%d unsupported (2,4,8,16,32)", n);
       return SRF_EINVAL;
   }
-  SRF_CHECK_LAUNCH("srf_tac");
+  SRF_CHECK_LAUNCH("tac", st);
   return SRF_OK;
 }

@@ -1,0 +1,63 @@
+"""Algorithmic (fusion-minimal) HBM bytes and FLOPs of the SuDoRM-RF forward, per example and per
+kernel launch (derivation in DESIGN.md).  Pure arithmetic, used by bench.py."""
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (exact fp32)
+
+
+def frames(T, K, D):
+    h = K // 2
+    n = h * 2 ** D
+    Tp = n if T < n else (T // n + (1 if T % n else 0)) * n
+    return (Tp + 2 * h - K) // h + 1
+
+
+def bytes_per_example(variant, B, C, U, D, K, N, S, T, G=1):
+    """materialise only at GlobLN barriers, fp32, weights ignored."""
+    L = frames(T, K, D)
+    xfac = 7 if variant == "groupcomm" else 3
+    return 4.0 * ((1 + S) * T + 3 * N * L + 2 * B * L + U * (xfac * B * L + (10 - 2.0 ** (3 - D)) * C * L))
+
+
+def flops_per_example(variant, B, C, U, D, K, N, S, T, G=1):
+    L = frames(T, K, D)
+    dw = 5 * C * L * (2 - 2.0 ** (1 - D))
+    if variant == "groupcomm":
+        n, h, c = B // G, 3 * B // G, C // G
+        blk = L * (G * 3 * n * h + h * h) + G * (2 * n * c * L) + dw
+    else:
+        blk = 2 * B * C * L + dw
+    mac = N * K * L + N * B * L + U * blk + B * S * N * L + S * N * S * K * L
+    return 2.0 * mac
+
+
+def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
+    """(family, algorithmic_bytes, flops) for every kernel launch of one srf_forward, in launch order
+    (mirrors srf_api.hip).  Bytes = tensors each kernel must read + write once, fp32."""
+    L = frames(T, K, D)
+    SA = S * A
+    Bg, nB, nC = Bt * G, B // G, C // G
+    f = 4.0
+    out = [("encoder", f * Bt * (A * T + N * L), 2.0 * Bt * N * A * K * L)]
+
+    def pw(cin, cout, bt, extra_in=0):
+        return ("pw_conv", f * bt * L * (cin + cout + extra_in), 2.0 * bt * cin * cout * L)
+
+    out.append(pw(N, B, Bt))
+    for _ in range(U):
+        if variant == "groupcomm":
+            n, h = nB, 3 * nB
+            out.append(("tac", f * Bt * B * L * 2, 2.0 * Bt * L * (2 * G * n * h + h * h + n * h + G * n * h)))
+            out.append(("gln_apply_add", f * Bt * B * L * 3, 3.0 * Bt * B * L))
+        out.append(pw(nB, nC, Bg))
+        for k in range(D):
+            lin = L if k == 0 else L >> (k - 1)
+            lout = L >> k
+            out.append(("dwconv5", f * Bg * nC * (lin + lout), 2.0 * 5 * Bg * nC * lout))
+        out.append(("merge", f * Bg * nC * (sum(L >> k for k in range(D)) + L), 2.0 * D * Bg * nC * L))
+        out.append(pw(nC, nB, Bg, extra_in=nB))
+    out.append(pw(B, SA * N, Bt, extra_in=N))
+    out.append(("transpose", f * 2 * SA * N * SA * K, 0.0))
+    out.append(pw(SA * N, SA * K, Bt))
+    out.append(("overlap_add", f * Bt * (SA * K * L + SA * T), 3.0 * Bt * SA * T))
+    return out

@@ -1,0 +1,143 @@
+"""Whole-model parity through the C ABI (srf_forward) on the GPU.
+
+Bar (BASELINE.json north_star): separated waveforms within 1e-4 max-abs of the reference CPU forward
+on the same inputs.  The golden outputs were produced by the unmodified reference (tools/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_case
+from oracle import np_oracle, torch_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4   # north_star tolerance, max-abs
+
+ALL_CASES = ["tiny_improved", "tiny_improved_d1", "tiny_improved_short", "tiny_groupcomm", "tiny_groupcomm_a2",
+             "cfg1_improved_u8", "cfg1_improved_u8_pad", "cfg2_improved_u16", "cfg3_groupcomm_u8",
+             "cfg4_improved_u36_n2048", "cfg5_improved_u36_n4096"]
+
+
+def build(cfg, sd):
+    import sudo_rm_rf.dnn.models.improved_sudormrf as improved_sudormrf       # reference import paths
+    import sudo_rm_rf.dnn.models.groupcomm_sudormrf_v2 as sudormrf_gc_v2
+    cls = improved_sudormrf.SuDORMRF if cfg.variant == "improved" else sudormrf_gc_v2.GroupCommSudoRmRf
+    m = cls(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(DEV).eval()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_forward_matches_reference_golden(manifest, name):
+    cfg, sd, wav, gold = load_case(manifest, name)
+    model = build(cfg, sd)
+    with torch.no_grad():
+        out = model(torch.from_numpy(wav).to(DEV))
+    assert out.dtype == torch.float32 and out.device.type == "cuda"
+    got = out.cpu().numpy()
+    assert got.shape == gold["out"].shape
+    err = np.abs(got - gold["out"]).max()
+    print(f"{name}: max abs err vs reference = {err:.3e} (out abs max {np.abs(gold['out']).max():.3f})")
+    assert err <= TOL
+    if "out_mixture_consistency" in gold:
+        import sudo_rm_rf.dnn.experiments.utils.mixture_consistency as mixture_consistency
+        mc = mixture_consistency.apply(out, torch.from_numpy(wav).to(DEV)).cpu().numpy()
+        assert np.abs(mc - gold["out_mixture_consistency"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["tiny_improved", "tiny_groupcomm", "cfg1_improved_u8_pad"])
+def test_generic_kernels_agree_with_fast(manifest, name):
+    from sudo_rm_rf_amd import ops
+    cfg, sd, wav, gold = load_case(manifest, name)
+    model = build(cfg, sd)
+    x = torch.from_numpy(wav).to(DEV)
+    try:
+        ops.set_kernel_mode(1)
+        with torch.no_grad():
+            gen = model(x).cpu().numpy()
+    finally:
+        ops.set_kernel_mode(0)
+    assert np.abs(gen - gold["out"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["tiny_improved", "tiny_groupcomm"])
+def test_intermediates_match_oracle(manifest, name):
+    cfg, sd, wav, _ = load_case(manifest, name)
+    model = build(cfg, sd)
+    tr = {}
+    np_oracle.forward(cfg, sd, wav, dtype=np.float64, trace=tr)
+    with torch.no_grad():
+        model(torch.from_numpy(wav).to(DEV))
+    plan = model._engine().last_plan
+    Bt, L = wav.shape[0], plan.frames
+    enc = plan.debug_fetch(0, (Bt, cfg.enc_num_basis, L)).cpu().numpy()
+    assert np.abs(enc - tr["enc"]).max() < 1e-5
+    last = f"sm.{cfg.num_blocks - 1}.out" if cfg.variant == "improved" else f"sm.{cfg.num_blocks - 1}.UBlock.out"
+    smo = plan.debug_fetch(1, (Bt, cfg.out_channels, L)).cpu().numpy()
+    assert np.abs(smo - tr[last].reshape(smo.shape)).max() < 2e-4
+    masked = plan.debug_fetch(2, tr["masked"].shape).cpu().numpy()
+    assert np.abs(masked - tr["masked"]).max() < 1e-4
+
+
+def test_batch32_examples_are_independent_at_full_size(manifest):
+    """BASELINE cfg 2 at its full size (batch 32): every example must reproduce the golden output of
+    the same waveform run on its own -- nothing on the path mixes examples."""
+    cfg, sd, wav, gold = load_case(manifest, "cfg2_improved_u16")
+    model = build(cfg, sd)
+    reps = np.concatenate([wav] * 16, axis=0)            # 32 examples: golden inputs interleaved
+    assert reps.shape[0] == 32
+    with torch.no_grad():
+        out = model(torch.from_numpy(reps).to(DEV)).cpu().numpy()
+    for i in range(32):
+        assert np.abs(out[i] - gold["out"][i % 2]).max() <= TOL, i
+
+
+def test_run_to_run_determinism(manifest):
+    cfg, sd, wav, _ = load_case(manifest, "cfg1_improved_u8")
+    model = build(cfg, sd)
+    x = torch.from_numpy(wav).to(DEV)
+    with torch.no_grad():
+        a = model(x).clone()
+        b = model(x).clone()
+    # fp64 atomics may reorder, which can move a statistic by one fp32 ulp at most
+    assert (a - b).abs().max().item() < 1e-6
+
+
+def test_arbitrary_lengths_and_dtypes(manifest):
+    cfg, sd, _, _ = load_case(manifest, "tiny_improved")
+    model = build(cfg, sd)
+    sdt = torch_oracle.to_torch(sd)
+    for T in (1, 7, 50, 160, 161, 1001):
+        g = torch.Generator().manual_seed(T)
+        wav = torch.randn(2, 1, T, generator=g)
+        with torch.no_grad():
+            want = torch_oracle.forward(cfg, sdt, wav)
+            got = model(wav.to(DEV))
+            got64 = model(wav.double().to(DEV))          # reference casts to fp32 in its pad buffer
+        assert got.shape == (2, cfg.num_sources, T)
+        assert (got.cpu() - want).abs().max().item() <= TOL, T
+        assert torch.equal(got, got64)
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(2, 100, device=DEV))           # 2-D input: error, like the reference
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(2, 2, 100, device=DEV))        # wrong channel count
+
+
+def test_submodule_forwards(manifest):
+    """UConvBlock / TAC / GlobLN called stand-alone (as pickled sub-modules may be) match the oracle."""
+    cfg, sd, wav, _ = load_case(manifest, "tiny_groupcomm")
+    model = build(cfg, sd)
+    tr = {}
+    np_oracle.forward(cfg, sd, wav, dtype=np.float64, trace=tr)
+    x = torch.from_numpy(tr["bottleneck"].astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        y = model.sm[0](x).cpu().numpy()
+    assert np.abs(y - tr["sm.0.UBlock.out"].reshape(y.shape)).max() < 1e-4

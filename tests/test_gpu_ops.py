@@ -1,0 +1,253 @@
+"""Per-kernel parity: every C-ABI entry point vs an fp64 torch/numpy reference of the same op.
+
+Tolerances are for fp32 arithmetic with re-association (no reduced-precision operands anywhere)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    from sudo_rm_rf_amd import _lib
+    _lib.load()
+    yield
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+
+
+@pytest.fixture(params=[0, 1], ids=["fast", "generic"])
+def mode(request):
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(request.param)
+    yield request.param
+    ops.set_kernel_mode(0)
+
+
+def rnd(*shape, seed=0, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale + shift)
+
+
+def dev32(t):
+    return t.to(torch.float32).to(DEV).contiguous()
+
+
+def gln64(x, gamma, beta):
+    dims = list(range(1, x.dim()))
+    mu = x.mean(dim=dims, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=dims, keepdim=True)
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    return gamma.view(shape) * (x - mu) / (var + 1e-8).sqrt() + beta.view(shape)
+
+
+def sums64(x):
+    xf = x.reshape(x.shape[0], -1)
+    return torch.stack([xf.sum(1), (xf * xf).sum(1)], 1)
+
+
+def check(got, want, atol, what=""):
+    got = got.detach().cpu().to(torch.float64)
+    err = (got - want).abs().max().item()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.1e}"
+
+
+def check_sums(got, x64, what=""):
+    want = sums64(x64)
+    got = got.cpu()
+    rel = ((got - want).abs() / (want.abs() + 1e-3 * x64[0].numel() ** 0.5)).max().item()
+    assert rel < 2e-6, f"{what}: stats rel err {rel:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("A,K,T,N,Bt", [(1, 21, 32000, 96, 2), (1, 21, 1237, 33, 3), (2, 11, 700, 16, 2),
+                                        (1, 5, 64, 8, 1)])
+def test_encoder(mode, A, K, T, N, Bt):
+    from sudo_rm_rf_amd import ops
+    h = K // 2
+    D = 3
+    nls = h * 2 ** D
+    Tp = nls if T < nls else (T // nls + (1 if T % nls else 0)) * nls
+    L = (Tp + 2 * h - K) // h + 1
+    x, w = rnd(Bt, A, T, seed=1), rnd(N, A, K, seed=2, scale=0.3)
+    xp = torch.zeros(Bt, A, Tp, dtype=torch.float64)
+    xp[..., :T] = x
+    want = F.conv1d(xp, w, None, stride=h, padding=h)
+    sums = ops.new_sums(Bt, DEV)
+    got = ops.encoder(dev32(x), dev32(w), L, sums)
+    check(got, want, 2e-5, "encoder")
+    check_sums(sums, want, "encoder sums")
+
+
+def test_gln_standalone():
+    from sudo_rm_rf_amd import ops
+    x, g, b = rnd(3, 40, 333, seed=3, scale=2.0, shift=0.7), rnd(40, seed=4), rnd(40, seed=5)
+    got = ops.glob_ln(dev32(x), dev32(g), dev32(b))
+    check(got, gln64(x, g, b), 2e-5, "glob_ln")
+
+
+# ---------------------------------------------------------------------------------------------
+PW_SHAPES = [  # Bt, Cin, Cout, L
+    (2, 256, 512, 3200),   # proj_1x1 of cfg2
+    (2, 512, 256, 800),    # res_conv-like
+    (1, 64, 42, 200),      # partial M tile (decoder frame GEMM shape), partial N tile
+    (3, 48, 160, 132),     # nothing a multiple of the tile
+    (4, 16, 32, 404),      # GroupComm per-group shape (generic kernel)
+    (2, 24, 20, 50),       # generic: Cin not multiple of 16, L not multiple of 4
+]
+
+
+@pytest.mark.parametrize("Bt,Cin,Cout,L", PW_SHAPES)
+@pytest.mark.parametrize("pro", [0, 1, 2, 3])
+def test_pw_conv(mode, Bt, Cin, Cout, L, pro):
+    from sudo_rm_rf_amd import ops
+    x = rnd(Bt, Cin, L, seed=10, scale=1.5, shift=0.3)
+    w = rnd(Cout, Cin, 1, seed=11, scale=Cin ** -0.5)
+    bias = rnd(Cout, seed=12, scale=0.2)
+    gamma, beta = rnd(Cin, seed=13, scale=0.3, shift=1.0), rnd(Cin, seed=14, scale=0.3)
+    slope = torch.tensor([0.17], dtype=torch.float64)
+    res = rnd(Bt, Cout, L, seed=15)
+    xin = x
+    kw = {}
+    if pro in (1, 2):
+        xin = gln64(x, gamma, beta)
+        kw.update(in_sums=sums64(x).to(DEV), in_gamma=dev32(gamma), in_beta=dev32(beta))
+    if pro in (2, 3):
+        xin = torch.where(xin >= 0, xin, slope * xin)
+        kw.update(in_prelu=dev32(slope))
+    want = F.conv1d(xin, w, bias) + res
+    osums = ops.new_sums(Bt, DEV)
+    got = ops.pw_conv(dev32(x), dev32(w), dev32(bias), residual=dev32(res), out_sums=osums, **kw)
+    # the sums handed in are exact fp64 sums of the fp64 tensor -> only fp32 arithmetic error remains
+    check(got, want, 5e-5, f"pw_conv pro={pro}")
+    check_sums(osums, want, "pw_conv sums")
+
+
+def test_pw_conv_mask_epilogue(mode):
+    from sudo_rm_rf_amd import ops
+    Bt, Cin, N, S, L = 2, 64, 48, 2, 260
+    x, w, bias = rnd(Bt, Cin, L, seed=20), rnd(S * N, Cin, 1, seed=21, scale=0.2), rnd(S * N, seed=22)
+    enc = rnd(Bt, N, L, seed=23)
+    slope = torch.tensor([0.3], dtype=torch.float64)
+    m = F.conv1d(torch.where(x >= 0, x, slope * x), w, bias)
+    want = (torch.relu(m.view(Bt, S, N, L)) * enc.unsqueeze(1)).view(Bt, S * N, L)
+    got = ops.pw_conv(dev32(x), dev32(w), dev32(bias), in_prelu=dev32(slope), mask_mul=dev32(enc))
+    check(got, want, 2e-5, "mask epilogue")
+
+
+def test_pw_conv_transpose_detecting(mode):
+    """A = I-like weights with an ASYMMETRIC operand catch row/col swaps in the MFMA C layout."""
+    from sudo_rm_rf_amd import ops
+    Bt, C, L = 1, 128, 256
+    x = (torch.arange(C, dtype=torch.float64)[:, None] * 1000 + torch.arange(L, dtype=torch.float64)[None, :])
+    x = (x / 1000).unsqueeze(0)
+    w = torch.zeros(C, C, 1, dtype=torch.float64)
+    w[torch.arange(C), (torch.arange(C) * 7 + 3) % C, 0] = 1.0     # permutation matrix
+    got = ops.pw_conv(dev32(x), dev32(w), dev32(torch.zeros(C, dtype=torch.float64)))
+    check(got, F.conv1d(x, w), 1e-4, "permutation GEMM")
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Bt,C,Lin,stride", [(2, 64, 3200, 1), (2, 64, 3200, 2), (3, 20, 200, 2),
+                                             (2, 7, 404, 2), (2, 7, 202, 1), (1, 5, 50, 2),
+                                             (2, 32, 256, 1), (2, 32, 512, 2), (1, 3, 4, 1), (1, 3, 8, 2),
+                                             (1, 3, 6, 2)])
+@pytest.mark.parametrize("pro", [0, 1, 2])
+def test_dwconv5(mode, Bt, C, Lin, stride, pro):
+    from sudo_rm_rf_amd import ops
+    x = rnd(Bt, C, Lin, seed=30, scale=1.3, shift=-0.4)
+    w, bias = rnd(C, 1, 5, seed=31, scale=0.5), rnd(C, seed=32, scale=0.2)
+    gamma, beta = rnd(C, seed=33, scale=0.3, shift=1.0), rnd(C, seed=34, scale=0.3)
+    slope = torch.tensor([0.21], dtype=torch.float64)
+    xin, kw = x, {}
+    if pro >= 1:
+        xin = gln64(x, gamma, beta)
+        kw.update(in_sums=sums64(x).to(DEV), in_gamma=dev32(gamma), in_beta=dev32(beta))
+    if pro == 2:
+        xin = torch.where(xin >= 0, xin, slope * xin)
+        kw.update(in_prelu=dev32(slope))
+    want = F.conv1d(xin, w, bias, stride=stride, padding=2, groups=C)
+    osums = ops.new_sums(Bt, DEV)
+    got = ops.dwconv5(dev32(x), dev32(w), dev32(bias), stride, out_sums=osums, **kw)
+    check(got, want, 2e-5, "dwconv5")
+    check_sums(osums, want, "dwconv5 sums")
+
+
+@pytest.mark.parametrize("Bt,C,L,D", [(2, 64, 3200, 5), (2, 16, 6400, 6), (2, 5, 808, 3), (1, 3, 36, 3),
+                                      (2, 4, 64, 1), (1, 3, 6, 2), (1, 2, 256, 8)])
+def test_merge(mode, Bt, C, L, D):
+    from sudo_rm_rf_amd import ops
+    levels = [rnd(Bt, C, L >> k, seed=40 + k, scale=1.0 + 0.2 * k, shift=0.1 * k) for k in range(D)]
+    gam = [rnd(C, seed=50 + k, scale=0.3, shift=1.0) for k in range(D)]
+    bet = [rnd(C, seed=60 + k, scale=0.3) for k in range(D)]
+    normed = [gln64(levels[k], gam[k], bet[k]) for k in range(D)]
+    u = normed[-1]
+    for k in range(D - 2, -1, -1):
+        u = normed[k] + u.repeat_interleave(2, dim=-1)
+    osums = ops.new_sums(Bt, DEV)
+    got = ops.merge([dev32(t) for t in levels], [sums64(t).to(DEV) for t in levels],
+                    [dev32(t) for t in gam], [dev32(t) for t in bet], out_sums=osums)
+    check(got, u, 3e-5, "merge")
+    check_sums(osums, u, "merge sums")
+
+
+@pytest.mark.parametrize("Bt,Ci,Co,K,L,T", [(2, 64, 2, 21, 100, 1000), (1, 96, 2, 21, 64, 633),
+                                            (2, 32, 4, 11, 40, 200), (1, 1024, 2, 21, 320, 3200)])
+def test_decoder(mode, Bt, Ci, Co, K, L, T):
+    from sudo_rm_rf_amd import ops
+    h = K // 2
+    v, w = rnd(Bt, Ci, L, seed=70), rnd(Ci, Co, K, seed=71, scale=Ci ** -0.5)
+    want = F.conv_transpose1d(v, w, None, stride=h, padding=h, output_padding=h - 1)[..., :T]
+    got = ops.decoder(dev32(v), dev32(w), T)
+    check(got, want, 3e-5, "decoder")
+
+
+@pytest.mark.parametrize("Bt,G,n,L", [(2, 16, 16, 300), (1, 4, 8, 77), (2, 8, 4, 130), (1, 2, 32, 64)])
+def test_tac(Bt, G, n, L):
+    from sudo_rm_rf_amd import ops
+    H = 3 * n
+    x = rnd(Bt, G, n, L, seed=80)
+    P = [rnd(H, n, seed=81, scale=n ** -0.5), rnd(H, seed=82, scale=0.2), torch.tensor([0.2], dtype=torch.float64),
+         rnd(H, H, seed=83, scale=H ** -0.5), rnd(H, seed=84, scale=0.2), torch.tensor([0.3], dtype=torch.float64),
+         rnd(n, 2 * H, seed=85, scale=(2 * H) ** -0.5), rnd(n, seed=86, scale=0.2),
+         torch.tensor([0.15], dtype=torch.float64)]
+    pr = lambda t, a: torch.where(t >= 0, t, a * t)
+    rows = x.permute(0, 3, 1, 2).reshape(-1, n)
+    z = pr(rows @ P[0].T + P[1], P[2]).view(Bt, L, G, H)
+    q = pr(z.mean(2).view(Bt * L, H) @ P[3].T + P[4], P[5])
+    cat = torch.cat([z.view(Bt * L, G, H), q.unsqueeze(1).expand(Bt * L, G, H)], 2).reshape(-1, 2 * H)
+    o = pr(cat @ P[6].T + P[7], P[8]).view(Bt, L, G, n).permute(0, 2, 3, 1).contiguous()
+    osums = ops.new_sums(Bt * G, DEV)
+    got = ops.tac(dev32(x), [dev32(p) for p in P], out_sums=osums)
+    check(got, o, 2e-5, "tac")
+    check_sums(osums, o.view(Bt * G, n, L), "tac sums")
+    # TAC_norm + residual
+    gam, bet = rnd(n, seed=87, shift=1.0, scale=0.2), rnd(n, seed=88, scale=0.2)
+    want = x + gln64(o.view(Bt * G, n, L), gam, bet).view(x.shape)
+    y = ops.gln_apply(got.view(Bt * G, n, L), osums, dev32(gam), dev32(bet),
+                      residual=dev32(x).view(Bt * G, n, L))
+    check(y.view(x.shape), want, 3e-5, "tac norm + residual")
+
+
+def test_mixture_consistency():
+    from sudo_rm_rf_amd import ops
+    pr, mix = rnd(3, 4, 1001, seed=90), rnd(3, 1, 1001, seed=91)
+    want = pr + (mix - pr.sum(1, keepdim=True)) / 4
+    check(ops.mixture_consistency(dev32(pr), dev32(mix)), want, 1e-6, "mixture consistency")
+
+
+def test_stats_robust_to_large_mean():
+    """E[x^2]-mu^2 in fp64 must survive mean >> std (fp32 accumulation would not)."""
+    from sudo_rm_rf_amd import ops
+    x = rnd(2, 16, 4096, seed=95, scale=0.05, shift=30.0)
+    g, b = torch.ones(16, dtype=torch.float64), torch.zeros(16, dtype=torch.float64)
+    x32 = x.to(torch.float32).to(torch.float64)           # what the kernel actually sees
+    got = ops.glob_ln(dev32(x), dev32(g), dev32(b))
+    check(got, gln64(x32, g, b), 2e-3, "large-mean GlobLN")   # (x-mu) itself loses bits in fp32

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Runs ON the GPU box (via gpurun): smoke -> GPU tests -> bench -> rocprofv3 kernel trace.
+# Everything of interest is written under gpurun_out/ (merged back into the repo's gpurun_out/).
+set -u
+OUT=gpurun_out/${1:-r01}
+mkdir -p "$OUT"
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+STEPS=${STEPS:-30}
+{
+  echo "== env"; rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | head -4; nproc; 
+  python -c "import torch;print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))"
+} > "$OUT/env.log" 2>&1
+echo "== smoke"; timeout 300 python __graft_entry__.py smoke > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?" | tee -a "$OUT/smoke.log"
+tail -5 "$OUT/smoke.log"
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+  echo "== pytest -m gpu"
+  timeout ${TEST_TIMEOUT:-900} python -m pytest tests -q -m gpu -p no:cacheprovider --tb=short -rA ${PYTEST_ARGS:-} > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"
+  grep -E "passed|failed|error" "$OUT/pytest_gpu.log" | tail -3
+  grep -E "^(FAILED|ERROR)" "$OUT/pytest_gpu.log" | head -40
+fi
+echo "== bench"
+timeout 600 python bench.py --steps $STEPS --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
+cat "$OUT/bench.json"; tail -3 "$OUT/bench.err"
+if [ "${SKIP_GENERIC:-0}" != "1" ]; then
+  timeout 600 python bench.py --steps 5 --warmup 2 --kernel-mode 1 --no-cpu-baseline > "$OUT/bench_generic.json" 2> "$OUT/bench_generic.err"
+  cat "$OUT/bench_generic.json"
+fi
+for w in ${EXTRA_WORKLOADS:-}; do
+  timeout 600 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
+  cat "$OUT/bench_$w.json"; tail -2 "$OUT/bench_$w.err"
+done
+if [ "${SKIP_PROF:-0}" != "1" ]; then
+  echo "== rocprofv3 kernel trace"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- \
+      python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile ) > "$OUT/rocprof.log" 2>&1
+  echo "rocprof rc=$?"
+  find "$OUT/prof" -name "*kernel_stats*" | head -3
+  f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
+  # keep the merged-back payload small: the raw kernel trace can be large
+  find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
+fi
+if [ -n "${PMC:-}" ]; then
+  echo "== rocprofv3 pmc"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $PMC -d "$GRAFT_REPO_ROOT/$OUT/pmc" -o bench -- \
+      python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile ) > "$OUT/pmc.log" 2>&1
+  echo "pmc rc=$?"; ls "$OUT/pmc" | head
+fi
+echo "== done"
