@@ -48,40 +48,85 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2_improved_u16", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
-    ap.add_argument("--kernel-mode", type=int, default=0, help="1 = generic kernels only (A/B)")
+    ap.add_argument("--kernel-mode", type=int, default=0,
+                    help="0 fast (split-bf16x3 MFMA GEMMs), 1 generic kernels only, 2 fast with exact-fp32 MFMA GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-repeats", type=int, default=3)
+    ap.add_argument("--cpu-timeout", type=float, default=150.0)
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(variant, kw, T, fs, batch, repeats):
+def cpu_baseline(variant, kw, T, fs, batch, repeats, budget_s=45.0):
     """The oracle's torch-CPU restatement (same ATen op sequence as the reference's nn.Modules; the
-    reference tree itself is not present on the GPU box) timed on the host cores: kind = "port"."""
+    reference tree itself is not present on the GPU box) timed on the host cores: kind = "port".
+    A short sweep over intra-op thread counts picks the fastest setting (all 256 hardware threads of
+    the GPU box's host are far slower than 32-64 for these small ops); `cores` = threads of the
+    reported run."""
     import torch
     from oracle import torch_oracle
     from oracle.schema import ModelConfig
     from oracle.weights import make_mixture, make_state_dict
     cfg = ModelConfig(variant=variant, **kw)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    hw = os.cpu_count() or 1
     sd = torch_oracle.to_torch(make_state_dict(cfg, seed=0))
     wav = torch.from_numpy(make_mixture(batch, T, seed=0))
+    cands = sorted({min(hw, c) for c in (8, 16, 32, 64)})
+    best, tried, t_start = None, {}, time.perf_counter()
     with torch.no_grad():
-        torch_oracle.forward(cfg, sd, wav)                       # warm-up
-        t0 = time.perf_counter()
-        for _ in range(repeats):
-            torch_oracle.forward(cfg, sd, wav)
-        dt = (time.perf_counter() - t0) / repeats
-    return {"value": batch * (T / fs) / dt, "unit": "separated-seconds/sec", "cores": torch.get_num_threads(),
-            "kind": "port", "seconds_per_forward": dt,
-            "sample": "oracle/torch_oracle.forward on %d of the workload's mixtures (batch %d), 1 warm-up + "
-                      "%d timed forwards, %d host threads" % (batch, batch, repeats, torch.get_num_threads())}
+        for nt in cands:
+            if time.perf_counter() - t_start > budget_s:
+                break
+            torch.set_num_threads(nt)
+            t0 = time.perf_counter()
+            torch_oracle.forward(cfg, sd, wav)                   # warm-up
+            warm = time.perf_counter() - t0
+            if warm > budget_s / 3:
+                tried[nt] = warm
+                if best is None or warm < best[1]:
+                    best = (nt, warm)
+                continue
+            t0 = time.perf_counter()
+            for _ in range(repeats):
+                torch_oracle.forward(cfg, sd, wav)
+            dt = (time.perf_counter() - t0) / repeats
+            tried[nt] = dt
+            if best is None or dt < best[1]:
+                best = (nt, dt)
+    nt, dt = best
+    return {"value": batch * (T / fs) / dt, "unit": "separated-seconds/sec", "cores": nt,
+            "host_hw_threads": hw, "kind": "port", "seconds_per_forward": dt,
+            "thread_sweep_s_per_forward": {str(k): v for k, v in tried.items()},
+            "sample": "oracle/torch_oracle.forward (the reference's ATen op sequence) on %d of the workload's "
+                      "mixtures (batch %d), 1 warm-up + %d timed forwards per thread count, best of %s threads"
+                      % (batch, batch, repeats, sorted(tried))}
+
+
+def cpu_baseline_subprocess(args):
+    """Run the CPU leg in a child process under a hard wall-clock limit so that a slow host can never
+    take the GPU result down with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", args.workload,
+           "--cpu-batch", str(args.cpu_batch), "--cpu-repeats", str(args.cpu_repeats)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"value": None, "kind": "port", "error": (r.stderr or r.stdout)[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "kind": "port", "error": "cpu baseline exceeded %.0f s" % args.cpu_timeout}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        variant, kw, T, fs, _ = WORKLOADS[args.workload]
+        print(json.dumps(cpu_baseline(variant, kw, T, fs, args.cpu_batch, args.cpu_repeats)))
+        return
     import torch
     import torch.distributed as dist
 
@@ -152,7 +197,10 @@ def main():
         if args.workload == "cfg2_improved_u16" else "separated-seconds/sec, " + args.workload,
         "value": value, "unit": "separated-seconds/sec", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32" if args.kernel_mode else
+        "f32 (1x1 convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "%s forward, batch %d per GPU, T=%d (%.0f s @ %d Hz), inference" %
                                (args.workload, batch, T, T / fs, fs),
                    "global_batch": batch * n_gpus, "parallelism": "batch-sharded replicas x%d" % n_gpus,
@@ -197,8 +245,11 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_forward"])
         kd = kernels[dom]
         if dom.startswith("pw_conv"):
-            rl = {"kernel": dom, "bound": "mfma", "achieved": kd["TFLOPs"], "peak": roofline.MFMA_F32_PEAK_TFLOPS,
-                  "unit": "TFLOP/s", "frac": kd["TFLOPs"] / roofline.MFMA_F32_PEAK_TFLOPS, "traffic": None}
+            # fp32-equivalent FLOPs; the split-precision kernel issues 3 bf16 MFMAs per product block, so
+            # its matrix-pipe peak is (bf16 dense peak)/3 in fp32-equivalent terms
+            peak = roofline.MFMA_BF16_PEAK_TFLOPS / 3 if dom == "pw_conv_bf16x3" else roofline.MFMA_F32_PEAK_TFLOPS
+            rl = {"kernel": dom, "bound": "mfma", "achieved": kd["TFLOPs"], "peak": peak,
+                  "unit": "TFLOP/s", "frac": kd["TFLOPs"] / peak, "traffic": None}
         else:
             rl = {"kernel": dom, "bound": "hbm", "achieved": kd["algorithmic_GBps"], "peak": roofline.HBM_PEAK_GBS,
                   "unit": "GB/s", "frac": kd["algorithmic_GBps"] / roofline.HBM_PEAK_GBS, "traffic": None}
@@ -210,8 +261,9 @@ def main():
         result["roofline"] = dict(result["forward_roofline"], traffic=None)
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(variant, kw, T, fs, args.cpu_batch, args.cpu_repeats)
-        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        result["cpu_baseline"] = cpu_baseline_subprocess(args)
+        if result["cpu_baseline"].get("value"):
+            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -21,15 +21,16 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 (or fp64 for GlobLN sums) owned by the
- *     caller; the library allocates nothing on the device and keeps no global state except a
- *     thread-local error string;
+ *     caller; the library allocates nothing on the device; global state = a thread-local error string,
+ *     the kernel-mode switch and the (off by default) profiler;
  *   - activations are [batch, channel, time] contiguous, exactly as the reference's tensors;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is asynchronous
  *     on that stream, nothing synchronises;
  *   - return value: 0 on success, a negative SRF_E* code otherwise (srf_last_error() has the text);
  *     nothing throws across the ABI;
- *   - GlobLN statistics travel as fp64 {sum, sum_of_squares} pairs ("sums", [groups][2]); producers
- *     ACCUMULATE into them (atomics), so the caller zeroes them first (srf_forward does it itself).
+ *   - GlobLN statistics travel as fp64 {sum, sum_of_squares} pairs ("sums",
+ *     [groups][SRF_STAT_BUCKETS][2]); producers ACCUMULATE into them (atomics), so the caller zeroes
+ *     them first (srf_forward does it itself).
  */
 #ifndef SUDORMRF_HIP_H
 #define SUDORMRF_HIP_H
@@ -40,7 +41,11 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 1
+#define SRF_ABI_VERSION 2
+
+/* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
+ * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
+#define SRF_STAT_BUCKETS 64
 
 #define SRF_OK 0
 #define SRF_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -67,7 +72,7 @@ typedef struct srf_config {
 
 /* "Apply GlobLN (+ optional PReLU) to this tensor when it is loaded". */
 typedef struct srf_norm {
-  const double* sums;  /* [groups][2] {sum, sum of squares} over (channel,time); NULL = no normalisation */
+  const double* sums;  /* [groups][SRF_STAT_BUCKETS][2] over (channel,time); NULL = no normalisation */
   const float* gamma;  /* [channels] */
   const float* beta;   /* [channels] */
   const float* prelu;  /* [1] shared slope, or NULL = no activation */
@@ -78,8 +83,11 @@ typedef struct srf_plan srf_plan;
 int srf_abi_version(void);
 const char* srf_last_error(void);
 
-/* Kernel-variant switch for A/B measurements: 0 = fast paths where the shape allows (default),
- * 1 = force the generic (shape-agnostic, scalar-load) kernels everywhere. */
+/* Kernel-variant switch for A/B measurements:
+ *   0 = fast paths where the shape allows (default); 1x1 convs run as split-precision MFMA GEMMs
+ *       (each fp32 operand = bf16 hi + bf16 lo, three bf16 MFMAs per product block, fp32 accumulate);
+ *   1 = force the generic (shape-agnostic, scalar-load, fp32 FMA) kernels everywhere;
+ *   2 = fast paths, but 1x1 convs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32). */
 void srf_set_kernel_mode(int mode);
 int srf_get_kernel_mode(void);
 
@@ -113,11 +121,11 @@ int srf_debug_fetch(const srf_plan* plan, const void* workspace, int what, float
 /* ---- per-kernel entry points (unit parity + building blocks) -------------------------------- */
 
 /* out[b,n,l] = sum_{a,k} w[n,a,k] * xpad[b,a,h*l+k-h], h=K/2; samples outside [0,T) are zero, so the
- * reference's right zero-padding is implicit in L.  sums (nullable): [Bt][2] += {sum, sumsq}. */
+ * reference's right zero-padding is implicit in L.  sums (nullable): [Bt][SRF_STAT_BUCKETS][2] += {sum, sumsq}. */
 int srf_encoder(const float* wav, const float* w, float* out, double* sums,
                 int Bt, int A, int T, int N, int K, int L, void* stream);
 
-/* sums[g][0..1] += {sum, sumsq} of x[g, :, :] (x: [groups, channels*length]). */
+/* sums[g][bucket][0..1] += {sum, sumsq} of x[g, :, :] (x: [groups, channels*length]). */
 int srf_gln_stats(const float* x, double* sums, int groups, long per_group, void* stream);
 /* y = gamma_c * (x - mu_g) / sqrt(var_g + 1e-8) + beta_c, then optional PReLU. */
 int srf_gln_apply(const float* x, float* y, const srf_norm* norm, int groups, int channels, int length,
@@ -129,7 +137,7 @@ int srf_gln_apply_add(const float* x, const float* q, float* y, const srf_norm* 
 /* 1x1 convolution y[b,m,l] = bias[m] + sum_k w[m,k] * f(x[b,k,l])  (+ residual[b,m,l]),
  * f = in_norm (GlobLN and/or PReLU on load; NULL = identity).
  * epilogue_mask != 0:  y = relu(y) * mul[b, m % mul_channels, l]   (mask_nl_class + "* s.unsqueeze(1)").
- * out_sums (nullable): [Bt][2] += {sum, sumsq} of the stored y. */
+ * out_sums (nullable): [Bt][SRF_STAT_BUCKETS][2] += {sum, sumsq} of the stored y. */
 int srf_pw_conv(const float* x, const float* w, const float* bias, float* y,
                 int Bt, int Cin, int Cout, int L, const srf_norm* in_norm, const float* residual,
                 double* out_sums, int epilogue_mask, const float* mul, int mul_channels, void* stream);
@@ -157,7 +165,7 @@ int srf_decoder(const float* v, const float* w, float* out, int Bt, int Ci, int 
 /* TAC up to (not including) TAC_norm: q[b,g,:,l] = PReLU(Wo [z_g ; PReLU(Wm mean_g z_g + bm)] + bo),
  * z_g = PReLU(Wi x[b,g,:,l] + bi).  x,q: [Bt,G,n,L].  params: the 9 TAC tensors in state_dict order
  * (TAC_input.0.weight/.bias, TAC_input.1.weight, TAC_mean.0.weight/.bias, TAC_mean.1.weight,
- * TAC_output.0.weight/.bias, TAC_output.1.weight).  out_sums: [Bt*G][2]. */
+ * TAC_output.0.weight/.bias, TAC_output.1.weight).  out_sums: [Bt*G][SRF_STAT_BUCKETS][2]. */
 int srf_tac(const float* x, float* q, const float* const* params, int Bt, int G, int n, int H, int L,
             double* out_sums, void* stream);
 

@@ -11,7 +11,8 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
+STAT_BUCKETS = 64
 
 SRF_OK = 0
 VARIANT_IMPROVED, VARIANT_GROUPCOMM = 0, 1

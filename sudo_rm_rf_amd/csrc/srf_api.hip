@@ -79,7 +79,7 @@ extern "C" int srf_profile_get(int i, const char** name, float* ms) {
 
 extern "C" const char* srf_last_error(void) { return g_err; }
 extern "C" int srf_abi_version(void) { return SRF_ABI_VERSION; }
-extern "C" void srf_set_kernel_mode(int mode) { g_kernel_mode = mode ? 1 : 0; }
+extern "C" void srf_set_kernel_mode(int mode) { g_kernel_mode = (mode == 1 || mode == 2) ? mode : 0; }
 extern "C" int srf_get_kernel_mode(void) { return g_kernel_mode; }
 
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
@@ -215,7 +215,7 @@ extern "C" int srf_plan_create(const srf_config* c, int batch, int T, srf_plan**
     off = align_up(off + bytes, 256);
     return o;
   };
-  p->stats_bytes = (size_t)p->n_slots * p->Bg * 2 * sizeof(double);
+  p->stats_bytes = (size_t)p->n_slots * p->Bg * SRF_STAT_BUCKETS * 2 * sizeof(double);
   p->off_stats = take(p->stats_bytes);
   p->off_enc = take(F * batch * c->enc_num_basis * L);
   p->off_xa = take(F * batch * c->out_channels * L);
@@ -263,7 +263,7 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
   hipStream_t st = (hipStream_t)stream;
   auto fptr = [&](size_t o) { return (float*)(ws + o); };
   double* stats = (double*)(ws + p->off_stats);
-  auto slot = [&](int s) { return stats + (size_t)s * Bg * 2; };
+  auto slot = [&](int s) { return stats + (size_t)s * Bg * SRF_STAT_BUCKETS * 2; };
   int rc;
 
   SRF_CHECK_HIP(hipMemsetAsync(stats, 0, p->stats_bytes, st));

@@ -12,7 +12,7 @@
 // host side: error reporting (thread-local string, never throws across the ABI)
 // ---------------------------------------------------------------------------------------------
 void srf_set_error(const char* fmt, ...);
-int srf_kernel_mode();  // 0 = fast paths allowed, 1 = generic kernels only
+int srf_kernel_mode();  // 0 = fast paths, 1 = generic kernels only, 2 = fast paths with exact-fp32 MFMA GEMMs
 bool srf_profiling();
 void srf_prof_mark(const char* name, hipStream_t st);
 
@@ -69,9 +69,17 @@ static inline SrfNormDev srf_norm_dev(const srf_norm* n) {
 
 // GlobLN statistics of one group from its fp64 {sum, sumsq}: mean and 1/sqrt(var_biased + 1e-8)
 // (reference: improved_sudormrf.py:44-47).  fp64 keeps E[x^2]-mu^2 free of cancellation trouble.
+//
+// Statistics are spread over SRF_STAT_BUCKETS {sum,sumsq} pairs per group so that concurrent producers
+// do not serialise on one address (measured: 512 same-address fp64 atomics cost ~150 us per launch on
+// MI355X, a fixed floor under every streaming kernel).  Each lane of the calling wavefront loads one
+// bucket and a shuffle reduction adds them: MUST be called by a full, converged 64-lane wavefront.
+__device__ __forceinline__ double srf_wave_sum(double v);
 __device__ __forceinline__ void srf_finalize_stats(const double* sums, long g, double inv_count,
                                                    float& mean, float& rstd) {
-  const double s = sums[2 * g], q = sums[2 * g + 1];
+  const double2 bk =
+      reinterpret_cast<const double2*>(sums)[g * SRF_STAT_BUCKETS + (threadIdx.x & (SRF_STAT_BUCKETS - 1))];
+  const double s = srf_wave_sum(bk.x), q = srf_wave_sum(bk.y);
   const double m = s * inv_count;
   double v = q * inv_count - m * m;
   v = v < 0.0 ? 0.0 : v;
@@ -83,6 +91,11 @@ __device__ __forceinline__ double srf_wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// Address of bucket `bucket` (any non-negative number, reduced mod SRF_STAT_BUCKETS) of group g.
+__device__ __forceinline__ double* srf_stat_slot(double* sums, long g, long bucket) {
+  return sums + 2 * (g * SRF_STAT_BUCKETS + (bucket & (SRF_STAT_BUCKETS - 1)));
 }
 
 // Block-wide {sum, sumsq} -> one fp64 atomic pair.  `sh` = 2*NWAVES doubles of LDS.

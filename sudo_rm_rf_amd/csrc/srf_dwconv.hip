@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void srf_dwconv5_generic_kernel(
     ds = (double)acc;
     dq = (double)acc * (double)acc;
   }
-  if (out_sums) srf_block_stats_atomic<4>(ds, dq, out_sums + 2 * b, red);
+  if (out_sums) srf_block_stats_atomic<4>(ds, dq, srf_stat_slot(out_sums, b, blockIdx.x), red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void srf_dwconv5_fast_kernel(
       }
     }
   }
-  if (out_sums) srf_wave_stats_atomic(ds, dq, out_sums + 2 * b);
+  if (out_sums) srf_wave_stats_atomic(ds, dq, srf_stat_slot(out_sums, b, row));
 }
 
 extern "C" int srf_dwconv5(const float* x, const float* w, const float* bias, float* y, int Bt, int C,
@@ -237,21 +237,29 @@ __global__ __launch_bounds__(256) void srf_merge_generic_kernel(MergeArgs a, flo
   const long b = row / C;
   const int j = chunk * 256 + threadIdx.x;
   double ds = 0.0, dq = 0.0;
+  RowCoef rcs[SRF_MAX_DEPTH];  // statistics are finalised by the whole (converged) wavefront
+#pragma unroll
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+    SrfNormDev nk = a.nrm[k];
+    nk.prelu = nullptr;
+    if (k >= a.D) nk.sums = nullptr;
+    rcs[k] = srf_row_coef(nk, b, c, a.inv_count[k]);
+  }
   if (j < L) {
     float t = 0.f;
-    for (int k = a.D - 1; k >= 0; --k) {
-      SrfNormDev nk = a.nrm[k];
-      nk.prelu = nullptr;
-      const RowCoef rc = srf_row_coef(nk, b, c, a.inv_count[k]);
-      const int Lk = L >> k;
-      const float v = srf_tf(a.lv[k][(size_t)row * Lk + (j >> k)], rc);
-      t = (k == a.D - 1) ? v : v + t;
+#pragma unroll
+    for (int k = SRF_MAX_DEPTH - 1; k >= 0; --k) {
+      if (k < a.D) {
+        const int Lk = L >> k;
+        const float v = srf_tf(a.lv[k][(size_t)row * Lk + (j >> k)], rcs[k]);
+        t = (k == a.D - 1) ? v : v + t;
+      }
     }
     y[(size_t)row * L + j] = t;
     ds = (double)t;
     dq = (double)t * (double)t;
   }
-  if (out_sums) srf_block_stats_atomic<4>(ds, dq, out_sums + 2 * b, red);
+  if (out_sums) srf_block_stats_atomic<4>(ds, dq, srf_stat_slot(out_sums, b, blockIdx.x), red);
 }
 
 // fast: one wavefront per row, lane = one float4 of level-0 output; level 1 as float2, deeper levels
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256) void srf_merge_fast_kernel(MergeArgs a, float*
     ds += (double)s;
     dq += (double)q;
   }
-  if (out_sums) srf_wave_stats_atomic(ds, dq, out_sums + 2 * b);
+  if (out_sums) srf_wave_stats_atomic(ds, dq, srf_stat_slot(out_sums, b, row));
 }
 
 extern "C" int srf_merge(const float* const* levels, const srf_norm* norms, int D, float* y, int Bt,

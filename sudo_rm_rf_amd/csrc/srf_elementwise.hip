@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void srf_gln_stats_kernel(const float* __restr
     ds += (double)v;
     dq += (double)v * (double)v;
   }
-  srf_block_stats_atomic<4>(ds, dq, sums + 2 * g, red);
+  srf_block_stats_atomic<4>(ds, dq, srf_stat_slot(sums, g, blockIdx.x), red);
 }
 
 extern "C" int srf_gln_stats(const float* x, double* sums, int groups, long per_group, void* stream) {

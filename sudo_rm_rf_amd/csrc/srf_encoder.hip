@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void srf_encoder_fast_kernel(const float* __re
     ds += (double)s;
     dq += (double)q;
   }
-  if (sums) srf_block_stats_atomic<4>(ds, dq, sums + 2 * (size_t)b, red);
+  if (sums) srf_block_stats_atomic<4>(ds, dq, srf_stat_slot(sums, b, blockIdx.x), red);
 }
 
 // Generic path: any A, any odd K.  64 frames per block, window in dynamic LDS, taps read from LDS in
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void srf_encoder_generic_kernel(const float* _
       dq += (double)acc * (double)acc;
     }
   }
-  if (sums) srf_block_stats_atomic<4>(ds, dq, sums + 2 * (size_t)b, red);
+  if (sums) srf_block_stats_atomic<4>(ds, dq, srf_stat_slot(sums, b, blockIdx.x), red);
 }
 
 extern "C" int srf_encoder(const float* wav, const float* w, float* out, double* sums, int Bt, int A,

@@ -18,22 +18,7 @@
 // weights as scalar operands.
 #include "srf_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct PwArgs {
-  const float* x;
-  const float* w;
-  const float* bias;
-  float* y;
-  const float* residual;
-  double* out_sums;
-  const float* mul;
-  SrfNormDev nrm;
-  double inv_count;
-  int Cin, Cout, L, Bt;
-  int mul_channels;
-  int epi_mask;
-};
+#include "srf_pw.h"
 
 // ---------------------------------------------------------------------------------------------
 // generic VALU kernel
@@ -83,7 +68,8 @@ __global__ __launch_bounds__(256) void srf_pw_generic_kernel(PwArgs a) {
       dq += (double)v * (double)v;
     }
   }
-  if (a.out_sums) srf_block_stats_atomic<4>(ds, dq, a.out_sums + 2 * b, red);
+  if (a.out_sums)
+    srf_block_stats_atomic<4>(ds, dq, srf_stat_slot(a.out_sums, b, blockIdx.x + blockIdx.y * gridDim.x), red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -196,31 +182,17 @@ __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue (shared with the bf16x3 kernel): bias / residual / ReLU*enc / statistics
   float s = 0.f, q = 0.f;
-  auto epi = [&](const f32x16& acc, int i2, int j2) {
-    const int l = l0 + wn * 64 + j2 * 32 + col;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (m < Cout && l < L) {
-        const size_t idx = ((size_t)b * Cout + m) * L + l;
-        float v = acc[r] + a.bias[m];
-        if (a.residual) v += a.residual[idx];
-        if (a.epi_mask)
-          v = fmaxf(v, 0.f) * a.mul[((size_t)b * a.mul_channels + (m % a.mul_channels)) * L + l];
-        a.y[idx] = v;
-        s += v;
-        q = fmaf(v, v, q);
-      }
-    }
-  };
-  epi(acc00, 0, 0);
-  epi(acc01, 0, 1);
-  epi(acc10, 1, 0);
-  epi(acc11, 1, 1);
-  if (a.out_sums) srf_block_stats_atomic<4>((double)s, (double)q, a.out_sums + 2 * b, red);
+  const int mb = m0 + wm * 64, lb = l0 + wn * 64;
+  srf_pw_epilogue_tile(a, acc00, b, mb, lb, lane, s, q);
+  srf_pw_epilogue_tile(a, acc01, b, mb, lb + 32, lane, s, q);
+  srf_pw_epilogue_tile(a, acc10, b, mb + 32, lb, lane, s, q);
+  srf_pw_epilogue_tile(a, acc11, b, mb + 32, lb + 32, lane, s, q);
+  if (a.out_sums) srf_block_stats_atomic<4>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v), red);
 }
+
+int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st);
 
 extern "C" int srf_pw_conv(const float* x, const float* w, const float* bias, float* y, int Bt, int Cin,
                            int Cout, int L, const srf_norm* in_norm, const float* residual,
@@ -248,8 +220,11 @@ extern "C" int srf_pw_conv(const float* x, const float* w, const float* bias, fl
   if (a.nrm.sums) SRF_CHECK_ARG(a.nrm.gamma && a.nrm.beta, "srf_pw_conv: norm without gamma/beta");
   hipStream_t st = (hipStream_t)stream;
 
-  const bool mfma_ok = srf_kernel_mode() == 0 && (Cin % PW_BK == 0) && (L % 4 == 0) && Cout >= 32 &&
-                       Cin >= 32 && srf_aligned16(x) && srf_aligned16(w);
+  const int mode = srf_kernel_mode();
+  const bool mfma_ok = mode != 1 && (Cin % PW_BK == 0) && (L % 4 == 0) && Cout >= 32 && Cin >= 32 &&
+                       srf_aligned16(x) && srf_aligned16(w);
+  const int pro_sel = a.nrm.sums ? (a.nrm.prelu ? 2 : 1) : (a.nrm.prelu ? 3 : 0);
+  if (mfma_ok && mode == 0 && (Cin % 32 == 0)) return srf_pw_bf16x3_launch(a, pro_sel, st);
   if (mfma_ok) {
     const int nMt = (Cout + PW_BM - 1) / PW_BM, nLt = (L + PW_BN - 1) / PW_BN;
     const long total = (long)Bt * nMt * nLt;

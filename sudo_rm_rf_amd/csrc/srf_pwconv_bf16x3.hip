@@ -1,0 +1,187 @@
+// K2 (fast path) -- pointwise conv as a split-precision MFMA GEMM: every fp32 operand is split into
+// two bf16 terms  x = hi + lo  (hi = bf16_rne(x), lo = bf16_rne(x - hi), |x - hi - lo| <= 2^-18 |x|)
+// and each 32x32x16 product block is accumulated in fp32 from THREE bf16 MFMAs
+//     acc += a_lo*b_hi;  acc += a_hi*b_lo;  acc += a_hi*b_hi          (a_lo*b_lo ~ 2^-18 dropped)
+// The bf16 matrix pipe runs 16x the exact-fp32 MFMA rate, so three passes are still ~5x faster than
+// v_mfma_f32_32x32x2_f32 while the result stays in the fp32 round-off class: the whole forward stays
+// <= 1e-6 max-abs from the reference (bar: 1e-4); plain bf16 operands measured 3-4e-4 and fail it.
+// Same sites / prologue / epilogue as srf_pwconv.hip (reference: improved_sudormrf.py:256-259, :174,
+// :196,:220, :268-269,:295-298).
+//
+// Tiling: block 128(M) x 128(N=time) x 32(K), 4 wavefronts x (2x2 MFMA tiles of 32x32), 64 fp32
+// accumulators per lane.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive-k bf16 per lane for BOTH
+// operands (A: row l&31, B: column l&31, k = 8*(l>>5)+j), but X_b is [k][time] with time contiguous:
+// the transposition happens in registers while staging -- each thread loads 8 k-rows x 2 time steps
+// (coalesced 512-B row segments per wavefront), applies the GlobLN/PReLU prologue, splits, and writes
+// the 8-k packets as 16-B ds_write_b128 into [time][k] LDS images (row pitch 80 B: conflict-free
+// ds_read_b128 fragment fetches).  W is [m][k] row-major already.  LDS: 4 images x 2 stages = 80 KB
+// -> 2 blocks per CU; next k-tile's global loads are issued before the current tile's MFMAs.
+#include "srf_pw.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 32;
+constexpr int X3_PITCH = 80;                    // bytes per LDS row (32 bf16 = 64 B + 16 B pad)
+constexpr int X3_IMG = X3_BM * X3_PITCH;        // one [128][32] bf16 image
+constexpr int X3_STAGE = 4 * X3_IMG;            // A_hi, A_lo, B_hi, B_lo
+
+__device__ __forceinline__ void srf_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+
+// PRO: 0 = identity, 1 = GlobLN, 2 = GlobLN + PReLU, 3 = PReLU only
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt, int nLt, int total) {
+  // exactly 80 KB so that two blocks share a CU's 160 KB; the statistics scratch reuses it at the end
+  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];
+
+  const int v = srf_xcd_remap(blockIdx.x, total);
+  const int mt = v % nMt;
+  const int lt = (v / nMt) % nLt;
+  const long b = v / (nMt * nLt);
+  const int m0 = mt * X3_BM, l0 = lt * X3_BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  float mean = 0.f, rstd = 1.f, slope = 1.f;
+  if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
+  if (PRO == 2 || PRO == 3) slope = a.nrm.prelu[0];
+
+  const int Cin = a.Cin, L = a.L, Cout = a.Cout;
+  const float* xb = a.x + (size_t)b * Cin * L;
+
+  // ---- staging assignment
+  // A (weights [m][k]): thread -> row m = tid>>1, k-half kh = tid&1 (16 consecutive k = 4 float4)
+  const int a_m = tid >> 1, a_kh = (tid & 1) * 16;
+  const bool a_ok = (m0 + a_m) < Cout;
+  const float* a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_kh;
+  // B (X_b [k][time]): thread -> time pair n = 2*(tid&63), k-group kg = tid>>6 (8 consecutive k rows)
+  const int b_n = 2 * (tid & 63), b_kg = (tid >> 6) * 8;
+  const bool b_ok = (l0 + b_n) < L;   // L % 4 == 0 and n even -> both elements in range
+  const float* b_src = xb + (size_t)b_kg * L + (l0 + b_n);
+
+  float4 ra[4];
+  float2 rb[8];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ra[i] = a_ok ? *reinterpret_cast<const float4*>(a_src + k0 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      rb[j] = b_ok ? *reinterpret_cast<const float2*>(b_src + (size_t)(k0 + j) * L) : make_float2(0.f, 0.f);
+  };
+  auto lds_store = [&](int stage, int k0) {
+    char* base = smem + stage * X3_STAGE;
+    // A: two 8-k packets per thread
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float va[8] = {ra[2 * p].x, ra[2 * p].y, ra[2 * p].z, ra[2 * p].w,
+                           ra[2 * p + 1].x, ra[2 * p + 1].y, ra[2 * p + 1].z, ra[2 * p + 1].w};
+      bf16x8 hi, lo;
+      srf_split8(va, hi, lo);
+      const int off = a_m * X3_PITCH + (a_kh + 8 * p) * 2;
+      *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + off) = hi;
+      *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + off) = lo;
+    }
+    // B: prologue, then one 8-k packet for each of the two time steps
+    float v0[8], v1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x0 = rb[j].x, x1 = rb[j].y;
+      if (PRO == 1 || PRO == 2) {
+        const int k = k0 + b_kg + j;
+        const float sc = a.nrm.gamma[k] * rstd;
+        const float sh = a.nrm.beta[k] - mean * sc;
+        x0 = fmaf(x0, sc, sh);
+        x1 = fmaf(x1, sc, sh);
+      }
+      if (PRO == 2 || PRO == 3) {
+        x0 = srf_prelu(x0, slope);
+        x1 = srf_prelu(x1, slope);
+      }
+      v0[j] = x0;
+      v1[j] = x1;
+    }
+    bf16x8 hi, lo;
+    srf_split8(v0, hi, lo);
+    int off = b_n * X3_PITCH + b_kg * 2;
+    *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + off) = hi;
+    *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + off) = lo;
+    srf_split8(v1, hi, lo);
+    off += X3_PITCH;
+    *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + off) = hi;
+    *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + off) = lo;
+  };
+
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+  const int nk = Cin / X3_BK;
+  gload(0);
+  lds_store(0, 0);
+  __syncthreads();
+  // fragment addresses: row (lane&31) of the wave's 64-row slab, 16-B k-packet (lane>>5)
+  const int frag = (lane & 31) * X3_PITCH + (lane >> 5) * 16;
+  const int a_row0 = (wm * 64) * X3_PITCH + frag, a_row1 = a_row0 + 32 * X3_PITCH;
+  const int b_row0 = (wn * 64) * X3_PITCH + frag, b_row1 = b_row0 + 32 * X3_PITCH;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * X3_BK);
+    const char* base = smem + stage * X3_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {   // two K=16 MFMA steps per 32-deep tile
+      const int ko = ks * 32;          // 16 bf16 = 32 bytes
+      const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row0 + ko);
+      const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row1 + ko);
+      const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row0 + ko);
+      const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row1 + ko);
+      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row0 + ko);
+      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
+      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
+      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
+    }
+    if (kt + 1 < nk) lds_store(stage ^ 1, (kt + 1) * X3_BK);
+    __syncthreads();
+  }
+
+  float s = 0.f, q = 0.f;
+  const int mb = m0 + wm * 64, lb = l0 + wn * 64;
+  srf_pw_epilogue_tile(a, acc00, b, mb, lb, lane, s, q);
+  srf_pw_epilogue_tile(a, acc01, b, mb, lb + 32, lane, s, q);
+  srf_pw_epilogue_tile(a, acc10, b, mb + 32, lb, lane, s, q);
+  srf_pw_epilogue_tile(a, acc11, b, mb + 32, lb + 32, lane, s, q);
+  // all LDS reads finished at the loop's last barrier: reuse the first bytes as reduction scratch
+  if (a.out_sums)
+    srf_block_stats_atomic<4>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
+                              reinterpret_cast<double*>(smem));
+}
+
+int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
+  const int nMt = (a.Cout + X3_BM - 1) / X3_BM, nLt = (a.L + X3_BN - 1) / X3_BN;
+  const long total = (long)a.Bt * nMt * nLt;
+  SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
+  dim3 grid((unsigned)total), block(256);
+  switch (pro) {
+    case 0: hipLaunchKernelGGL(srf_pw_bf16x3_kernel<0>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
+    case 1: hipLaunchKernelGGL(srf_pw_bf16x3_kernel<1>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
+    case 2: hipLaunchKernelGGL(srf_pw_bf16x3_kernel<2>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
+    default: hipLaunchKernelGGL(srf_pw_bf16x3_kernel<3>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
+  }
+  SRF_CHECK_LAUNCH("pw_conv_bf16x3", st);
+  return SRF_OK;
+}

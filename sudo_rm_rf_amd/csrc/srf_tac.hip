@@ -92,8 +92,9 @@ __global__ __launch_bounds__(128) void srf_tac_kernel(TacArgs a) {
     if (a.out_sums) {
       const double ds = srf_wave_sum((double)s), dq = srf_wave_sum((double)qq);
       if ((threadIdx.x & 63) == 0) {
-        atomicAdd(a.out_sums + 2 * (b * G + g), ds);
-        atomicAdd(a.out_sums + 2 * (b * G + g) + 1, dq);
+        double* dst = srf_stat_slot(a.out_sums, b * G + g, blockIdx.x * 2 + (threadIdx.x >> 6));
+        atomicAdd(dst, ds);
+        atomicAdd(dst + 1, dq);
       }
     }
   }

@@ -25,7 +25,7 @@ def _chk(*ts):
 
 
 def new_sums(groups, device):
-    return torch.zeros((groups, 2), dtype=torch.float64, device=device)
+    return torch.zeros((groups, _lib.STAT_BUCKETS, 2), dtype=torch.float64, device=device)
 
 
 def _norm(sums, gamma, beta, prelu):
@@ -163,5 +163,6 @@ def mixture_consistency(pr_batch, input_mixture):
 
 
 def set_kernel_mode(mode):
-    """0 = fast paths (default), 1 = generic kernels only (A/B measurements)."""
+    """0 = fast paths, split-bf16x3 MFMA GEMMs (default); 1 = generic kernels only; 2 = fast paths with
+    exact-fp32 MFMA GEMMs."""
     _lib.load().srf_set_kernel_mode(int(mode))

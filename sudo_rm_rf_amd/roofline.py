@@ -3,6 +3,7 @@ kernel launch (derivation in DESIGN.md).  Pure arithmetic, use
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (exact fp32)
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
 
 
 def frames(T, K, D):

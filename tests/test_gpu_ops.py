@@ -48,8 +48,12 @@ def gln64(x, gamma, beta):
 
 
 def sums64(x):
+    """exact fp64 {sum, sumsq} per group in the library's bucketed layout [groups, 64, 2] (bucket 0)."""
     xf = x.reshape(x.shape[0], -1)
-    return torch.stack([xf.sum(1), (xf * xf).sum(1)], 1)
+    out = torch.zeros(x.shape[0], 64, 2, dtype=torch.float64)
+    out[:, 0, 0] = xf.sum(1)
+    out[:, 0, 1] = (xf * xf).sum(1)
+    return out
 
 
 def check(got, want, atol, what=""):
@@ -60,10 +64,12 @@ def check(got, want, atol, what=""):
 
 
 def check_sums(got, x64, what=""):
-    want = sums64(x64)
-    got = got.cpu()
-    rel = ((got - want).abs() / (want.abs() + 1e-3 * x64[0].numel() ** 0.5)).max().item()
-    assert rel < 2e-6, f"{what}: stats rel err {rel:.3e}"
+    """bucketed fp64 sums of the kernel's own fp32 outputs vs the fp64 reference tensor: the only
+    differences are the outputs' fp32 rounding, so bound them by eps * sum|x| and eps * sum x^2."""
+    xf = x64.reshape(x64.shape[0], -1)
+    got = got.cpu().sum(1)                       # total over buckets -> [groups, 2]
+    assert ((got[:, 0] - xf.sum(1)).abs() <= 4e-6 * xf.abs().sum(1) + 1e-9).all(), f"{what}: sum"
+    assert ((got[:, 1] - (xf * xf).sum(1)).abs() <= 4e-6 * (xf * xf).sum(1) + 1e-9).all(), f"{what}: sumsq"
 
 
 # ---------------------------------------------------------------------------------------------

@@ -22,17 +22,17 @@ fi
 echo "== bench"
 timeout 600 python bench.py --steps $STEPS --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cat "$OUT/bench.json"; tail -3 "$OUT/bench.err"
-if [ "${SKIP_GENERIC:-0}" != "1" ]; then
-  timeout 600 python bench.py --steps 5 --warmup 2 --kernel-mode 1 --no-cpu-baseline > "$OUT/bench_generic.json" 2> "$OUT/bench_generic.err"
-  cat "$OUT/bench_generic.json"
-fi
+for km in ${EXTRA_MODES:-2}; do
+  timeout 600 python bench.py --steps 10 --warmup 3 --kernel-mode $km --no-cpu-baseline > "$OUT/bench_mode$km.json" 2> "$OUT/bench_mode$km.err"
+  cat "$OUT/bench_mode$km.json"
+done
 for w in ${EXTRA_WORKLOADS:-}; do
   timeout 600 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
   cat "$OUT/bench_$w.json"; tail -2 "$OUT/bench_$w.err"
 done
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   echo "== rocprofv3 kernel trace"
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- \
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- \
       python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile ) > "$OUT/rocprof.log" 2>&1
   echo "rocprof rc=$?"
   find "$OUT/prof" -name "*kernel_stats*" | head -3
@@ -40,10 +40,14 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
   # keep the merged-back payload small: the raw kernel trace can be large
   find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
 fi
-if [ -n "${PMC:-}" ]; then
-  echo "== rocprofv3 pmc"
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $PMC -d "$GRAFT_REPO_ROOT/$OUT/pmc" -o bench -- \
-      python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile ) > "$OUT/pmc.log" 2>&1
-  echo "pmc rc=$?"; ls "$OUT/pmc" | head
-fi
+# PMC passes: counters in their own runs (kernel-trace only), one counter group per pass
+i=0
+for grp in ${PMC_GROUPS:-}; do
+  i=$((i+1))
+  echo "== rocprofv3 pmc pass $i: $grp"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc ${grp//,/ } -d "$GRAFT_REPO_ROOT/$OUT/pmc$i" -o bench -- \
+      python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile ) > "$OUT/pmc$i.log" 2>&1
+  echo "pmc rc=$?"; ls "$OUT/pmc$i" | head -5
+  find "$OUT/pmc$i" -name "*.csv" -size +30M -delete
+done
 echo "== done"
