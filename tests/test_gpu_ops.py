@@ -153,7 +153,7 @@ def test_pw_conv_transpose_detecting(mode):
     from sudo_rm_rf_amd import ops
     Bt, C, L = 1, 128, 256
     x = (torch.arange(C, dtype=torch.float64)[:, None] * 1000 + torch.arange(L, dtype=torch.float64)[None, :])
-    x = (x / 1000).unsqueeze(0)
+    x = (x / 1e5).unsqueeze(0)          # <= 1.28: a row/col swap moves entries by >= 1e-2
     w = torch.zeros(C, C, 1, dtype=torch.float64)
     w[torch.arange(C), (torch.arange(C) * 7 + 3) % C, 0] = 1.0     # permutation matrix
     got = ops.pw_conv(dev32(x), dev32(w), dev32(torch.zeros(C, dtype=torch.float64)))
