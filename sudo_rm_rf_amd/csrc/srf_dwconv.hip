@@ -196,7 +196,7 @@ extern "C" int srf_dwconv5(const float* x, const float* w, const float* bias, fl
   const double inv_count = 1.0 / ((double)C * (double)Lin);
   SrfNormDev nd = srf_norm_dev(in_norm);
   hipStream_t st = (hipStream_t)stream;
-  const bool fast = srf_kernel_mode() == 0 && (Lin % (4 * stride) == 0) && srf_aligned16(x) &&
+  const bool fast = srf_kernel_mode() != 1 && (Lin % (4 * stride) == 0) && srf_aligned16(x) &&
                     srf_aligned16(y) && rows < (1L << 32);
   if (fast) {
     const unsigned blocks = (unsigned)((rows + 3) / 4);
@@ -355,7 +355,7 @@ extern "C" int srf_merge(const float* const* levels, const srf_norm* norms, int 
   a.D = D;
   const long rows = (long)Bt * C;
   hipStream_t st = (hipStream_t)stream;
-  const bool fast = srf_kernel_mode() == 0 && (L % 4 == 0) && aligned && rows < (1L << 32);
+  const bool fast = srf_kernel_mode() != 1 && (L % 4 == 0) && aligned && rows < (1L << 32);
   if (fast) {
     hipLaunchKernelGGL(srf_merge_fast_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, y,
                        out_sums, C, L, rows);

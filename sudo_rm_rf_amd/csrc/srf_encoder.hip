@@ -115,7 +115,7 @@ extern "C" int srf_encoder(const float* wav, const float* w, float* out, double*
   SRF_CHECK_ARG(K >= 3 && (K & 1), "srf_encoder: enc_kernel_size must be odd (got %d)", K);
   SRF_CHECK_ARG(Bt <= 65535, "srf_encoder: batch %d too large for one launch", Bt);
   hipStream_t st = (hipStream_t)stream;
-  if (srf_kernel_mode() == 0 && A == 1 && K == 21) {
+  if (srf_kernel_mode() != 1 && A == 1 && K == 21) {
     dim3 grid((L + 127) / 128, Bt);
     hipLaunchKernelGGL(srf_encoder_fast_kernel<21>, grid, dim3(256), 0, st, wav, w, out, sums, T, N, L);
   } else {

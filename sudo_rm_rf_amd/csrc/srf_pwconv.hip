@@ -224,7 +224,7 @@ extern "C" int srf_pw_conv(const float* x, const float* w, const float* bias, fl
   const bool mfma_ok = mode != 1 && (Cin % PW_BK == 0) && (L % 4 == 0) && Cout >= 32 && Cin >= 32 &&
                        srf_aligned16(x) && srf_aligned16(w);
   const int pro_sel = a.nrm.sums ? (a.nrm.prelu ? 2 : 1) : (a.nrm.prelu ? 3 : 0);
-  if (mfma_ok && mode == 0 && (Cin % 32 == 0)) return srf_pw_bf16x3_launch(a, pro_sel, st);
+  if (mfma_ok && mode == 0 && (Cin % 64 == 0)) return srf_pw_bf16x3_launch(a, pro_sel, st);
   if (mfma_ok) {
     const int nMt = (Cout + PW_BM - 1) / PW_BM, nLt = (L + PW_BN - 1) / PW_BN;
     const long total = (long)Bt * nMt * nLt;

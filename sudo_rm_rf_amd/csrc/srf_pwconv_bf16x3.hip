@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
   if (PRO == 2 || PRO == 3) slope = a.nrm.prelu[0];
 
   const int Cin = a.Cin, L = a.L, Cout = a.Cout;
+  const int nk_ = Cin / X3_BK;   // even (host checks Cin % 64 == 0)
   const float* xb = a.x + (size_t)b * Cin * L;
 
   // ---- staging assignment
@@ -65,23 +66,29 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
   const bool b_ok = (l0 + b_n) < L;   // L % 4 == 0 and n even -> both elements in range
   const float* b_src = xb + (size_t)b_kg * L + (l0 + b_n);
 
-  float4 ra[4];
-  float2 rb[8];
-  auto gload = [&](int k0) {
+  // Two register sets: tile t lives in set t&1.  Global loads are issued TWO k-tiles ahead of their
+  // use, so that a full MFMA phase plus a conversion phase of latency hiding covers every load (with
+  // one-tile prefetch the kernel measured latency-bound at ~7 % of the matrix pipe).
+  struct Regs {
+    float4 a[4];
+    float2 b[8];
+  };
+  Regs r0, r1;
+  auto gload = [&](Regs& r, int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      ra[i] = a_ok ? *reinterpret_cast<const float4*>(a_src + k0 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.a[i] = a_ok ? *reinterpret_cast<const float4*>(a_src + k0 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      rb[j] = b_ok ? *reinterpret_cast<const float2*>(b_src + (size_t)(k0 + j) * L) : make_float2(0.f, 0.f);
+      r.b[j] = b_ok ? *reinterpret_cast<const float2*>(b_src + (size_t)(k0 + j) * L) : make_float2(0.f, 0.f);
   };
-  auto lds_store = [&](int stage, int k0) {
+  auto lds_store = [&](const Regs& r, int stage, int k0) {
     char* base = smem + stage * X3_STAGE;
     // A: two 8-k packets per thread
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const float va[8] = {ra[2 * p].x, ra[2 * p].y, ra[2 * p].z, ra[2 * p].w,
-                           ra[2 * p + 1].x, ra[2 * p + 1].y, ra[2 * p + 1].z, ra[2 * p + 1].w};
+      const float va[8] = {r.a[2 * p].x, r.a[2 * p].y, r.a[2 * p].z, r.a[2 * p].w,
+                           r.a[2 * p + 1].x, r.a[2 * p + 1].y, r.a[2 * p + 1].z, r.a[2 * p + 1].w};
       bf16x8 hi, lo;
       srf_split8(va, hi, lo);
       const int off = a_m * X3_PITCH + (a_kh + 8 * p) * 2;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
     float v0[8], v1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float x0 = rb[j].x, x1 = rb[j].y;
+      float x0 = r.b[j].x, x1 = r.b[j].y;
       if (PRO == 1 || PRO == 2) {
         const int k = k0 + b_kg + j;
         const float sc = a.nrm.gamma[k] * rstd;
@@ -119,17 +126,11 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
   };
 
   f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-  const int nk = Cin / X3_BK;
-  gload(0);
-  lds_store(0, 0);
-  __syncthreads();
   // fragment addresses: row (lane&31) of the wave's 64-row slab, 16-B k-packet (lane>>5)
   const int frag = (lane & 31) * X3_PITCH + (lane >> 5) * 16;
   const int a_row0 = (wm * 64) * X3_PITCH + frag, a_row1 = a_row0 + 32 * X3_PITCH;
   const int b_row0 = (wn * 64) * X3_PITCH + frag, b_row1 = b_row0 + 32 * X3_PITCH;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int stage = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * X3_BK);
+  auto mma_tile = [&](int stage) {
     const char* base = smem + stage * X3_STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {   // two K=16 MFMA steps per 32-deep tile
@@ -155,8 +156,26 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
       acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
       acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
     }
-    if (kt + 1 < nk) lds_store(stage ^ 1, (kt + 1) * X3_BK);
+  };
+  // one pipeline step for tile kt (stage kt&1): first convert + store tile kt+1 (already in `nx`,
+  // loaded two steps ago) into the other stage and re-arm `nx` with tile kt+3, then the MFMAs of kt.
+  auto step = [&](Regs& nx, int kt) {
+    if (kt + 1 < nk_) {
+      lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
+      if (kt + 3 < nk_) gload(nx, (kt + 3) * X3_BK);
+    }
+    mma_tile(kt & 1);
     __syncthreads();
+  };
+
+  gload(r0, 0);
+  gload(r1, X3_BK);           // nk >= 2 (host guarantees Cin % 64 == 0)
+  lds_store(r0, 0, 0);
+  if (2 < nk_) gload(r0, 2 * X3_BK);
+  __syncthreads();
+  for (int kt = 0; kt < nk_; kt += 2) {
+    step(r1, kt);              // tile kt+1 lives in r1, tile kt+2 (in flight) in r0
+    step(r0, kt + 1);          // tile kt+2 lives in r0
   }
 
   float s = 0.f, q = 0.f;

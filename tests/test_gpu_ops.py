@@ -145,7 +145,8 @@ def test_pw_conv_mask_epilogue(mode):
     m = F.conv1d(torch.where(x >= 0, x, slope * x), w, bias)
     want = (torch.relu(m.view(Bt, S, N, L)) * enc.unsqueeze(1)).view(Bt, S * N, L)
     got = ops.pw_conv(dev32(x), dev32(w), dev32(bias), in_prelu=dev32(slope), mask_mul=dev32(enc))
-    check(got, want, 2e-5, "mask epilogue")
+    # un-normalised N(0,1) operands times |enc| up to 4: split-bf16 products carry ~2^-17 relative error
+    check(got, want, 2e-4 if mode == 0 else 2e-5, "mask epilogue")
 
 
 def test_pw_conv_transpose_detecting(mode):
