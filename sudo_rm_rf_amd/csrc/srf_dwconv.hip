@@ -116,11 +116,15 @@ __global__ __launch_bounds__(256) void srf_dwconv5_fast_kernel(
   float cz = 0.f, cw = 0.f;  // last two (transformed) inputs of the previous chunk = left halo of lane 0
 
   if (STRIDE == 1) {
-    float4 nxt = (lane < nin4) ? srf_tf4(xr[lane], rc) : zero4;
+    // prefetches are unconditional loads from a clamped index, zeroed afterwards by a select (a
+    // "cond ? load : 0" makes hipcc branch around the load and drain vmcnt(0): no prefetch at all)
+    float4 nxt = srf_tf4(xr[min(lane, nin4 - 1)], rc);
+    if (lane >= nin4) nxt = zero4;
     for (int it = 0; it < nchunks; ++it) {
       const float4 cur = nxt;
       const int g = it * 64 + lane;
-      nxt = (g + 64 < nin4) ? srf_tf4(xr[g + 64], rc) : zero4;
+      nxt = srf_tf4(xr[min(g + 64, nin4 - 1)], rc);
+      if (g + 64 >= nin4) nxt = zero4;
       float lz = __shfl_up(cur.z, 1, 64), lw = __shfl_up(cur.w, 1, 64);
       float rx = __shfl_down(cur.x, 1, 64), ry = __shfl_down(cur.y, 1, 64);
       const float nx0 = __shfl(nxt.x, 0, 64), ny0 = __shfl(nxt.y, 0, 64);
@@ -150,14 +154,18 @@ __global__ __launch_bounds__(256) void srf_dwconv5_fast_kernel(
   } else {
     // output group g (4 outputs j0..j0+3, j0 = 4g) needs inputs 2*j0-2 .. 2*j0+8:
     // float4 A = in[2g], B = in[2g+1], left halo = left neighbour's (B.z,B.w), right = right's A.x
-    float4 nA = (2 * lane < nin4) ? srf_tf4(xr[2 * lane], rc) : zero4;
-    float4 nB = (2 * lane + 1 < nin4) ? srf_tf4(xr[2 * lane + 1], rc) : zero4;
+    float4 nA = srf_tf4(xr[min(2 * lane, nin4 - 1)], rc);
+    float4 nB = srf_tf4(xr[min(2 * lane + 1, nin4 - 1)], rc);
+    if (2 * lane >= nin4) nA = zero4;
+    if (2 * lane + 1 >= nin4) nB = zero4;
     for (int it = 0; it < nchunks; ++it) {
       const float4 cA = nA, cB = nB;
       const int g = it * 64 + lane;
       const int gn = g + 64;
-      nA = (2 * gn < nin4) ? srf_tf4(xr[2 * gn], rc) : zero4;
-      nB = (2 * gn + 1 < nin4) ? srf_tf4(xr[2 * gn + 1], rc) : zero4;
+      nA = srf_tf4(xr[min(2 * gn, nin4 - 1)], rc);
+      nB = srf_tf4(xr[min(2 * gn + 1, nin4 - 1)], rc);
+      if (2 * gn >= nin4) nA = zero4;
+      if (2 * gn + 1 >= nin4) nB = zero4;
       float lz = __shfl_up(cB.z, 1, 64), lw = __shfl_up(cB.w, 1, 64);
       float rx = __shfl_down(cA.x, 1, 64);
       const float nx0 = __shfl(nA.x, 0, 64);

@@ -28,24 +28,63 @@ __device__ __forceinline__ int srf_xcd_remap(int id, int total) {
   return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
 }
 
-// Epilogue of one 32x32 MFMA accumulator tile whose top-left element is (m_base, l_base).
-// C/D layout of v_mfma_f32_32x32x*: col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-__device__ __forceinline__ void srf_pw_epilogue_tile(const PwArgs& a, const f32x16& acc, long b, int m_base,
-                                                     int l_base, int lane, float& s, float& q) {
-  const int l = l_base + (lane & 31);
-  const int kh = lane >> 5;
+// Epilogue of a 32(row) x 64(time) strip held as two 32x32 MFMA accumulator tiles (accL | accR), staged
+// through a wave-private LDS strip so that global traffic is row-contiguous 16-B per lane
+// (4 rows x 256 B per wavefront instruction) instead of 4-B scattered stores:
+//   C/D layout of v_mfma_f32_32x32x*: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// bias / residual / ReLU*enc / {sum,sumsq} are applied on the float4 side.  `strip` = 32*SRF_EPI_PITCH
+// floats, 16-B aligned, private to the calling wavefront (all 64 lanes must call).
+constexpr int SRF_EPI_PITCH = 68;
+
+__device__ __forceinline__ void srf_pw_epilogue_strip(const PwArgs& a, const f32x16& accL, const f32x16& accR,
+                                                      float* strip, long b, int m_base, int l_base, int lane,
+                                                      float& s, float& q) {
+  const int col = lane & 31, kh = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * kh;
-    if (m < a.Cout && l < a.L) {
-      const size_t idx = ((size_t)b * a.Cout + m) * a.L + l;
-      float v = acc[r] + a.bias[m];
-      if (a.residual) v += a.residual[idx];
-      if (a.epi_mask)
-        v = fmaxf(v, 0.f) * a.mul[((size_t)b * a.mul_channels + (m % a.mul_channels)) * a.L + l];
-      a.y[idx] = v;
-      s += v;
-      q = fmaf(v, v, q);
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+    strip[row * SRF_EPI_PITCH + col] = accL[r];
+    strip[row * SRF_EPI_PITCH + 32 + col] = accR[r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int c4 = (lane & 15) * 4;
+  const int l = l_base + c4;
+  const bool l_ok = l < a.L;  // L % 4 == 0 -> the whole float4 is in range
+  const size_t lc = l_ok ? l : 0;
+  const int mulC = a.mul_channels;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = i * 4 + (lane >> 4);
+    const int m = m_base + row;
+    const bool ok = l_ok && m < a.Cout;
+    const int mc = m < a.Cout ? m : 0;  // clamped: loads stay unconditional (no branch, no vmcnt drain)
+    float4 v = *reinterpret_cast<const float4*>(strip + row * SRF_EPI_PITCH + c4);
+    const float bs = a.bias[mc];
+    v.x += bs;
+    v.y += bs;
+    v.z += bs;
+    v.w += bs;
+    const size_t idx = ((size_t)b * a.Cout + mc) * a.L + lc;
+    if (a.residual) {
+      const float4 rv = *reinterpret_cast<const float4*>(a.residual + idx);
+      v.x += rv.x;
+      v.y += rv.y;
+      v.z += rv.z;
+      v.w += rv.w;
+    }
+    if (a.epi_mask) {
+      const float4 e = *reinterpret_cast<const float4*>(a.mul + ((size_t)b * mulC + (mc % mulC)) * a.L + lc);
+      v.x = fmaxf(v.x, 0.f) * e.x;
+      v.y = fmaxf(v.y, 0.f) * e.y;
+      v.z = fmaxf(v.z, 0.f) * e.z;
+      v.w = fmaxf(v.w, 0.f) * e.w;
+    }
+    if (ok) {
+      *reinterpret_cast<float4*>(a.y + idx) = v;
+      s += (v.x + v.y) + (v.z + v.w);
+      q = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, q))));
     }
   }
 }

@@ -82,9 +82,13 @@ constexpr int PW_LDB = PW_BN + 4;
 // PRO: 0 = identity, 1 = GlobLN, 2 = GlobLN + PReLU, 3 = PReLU only
 template <int PRO>
 __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int nLt, int total) {
-  __shared__ __attribute__((aligned(16))) float As[2][PW_BK][PW_LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][PW_BK][PW_LDB];
+  // operand tiles, later re-used as the epilogue's per-wave staging strips (4 waves x 2 strips)
+  constexpr int kTileFloats = 2 * PW_BK * PW_LDA + 2 * PW_BK * PW_LDB;
+  constexpr int kEpiFloats = 4 * 32 * SRF_EPI_PITCH;   // one strip per wave, used twice
+  __shared__ __attribute__((aligned(16))) float smem_f[kTileFloats > kEpiFloats ? kTileFloats : kEpiFloats];
   __shared__ double red[8];
+  float(*As)[PW_BK][PW_LDA] = reinterpret_cast<float(*)[PW_BK][PW_LDA]>(smem_f);
+  float(*Bs)[PW_BK][PW_LDB] = reinterpret_cast<float(*)[PW_BK][PW_LDB]>(smem_f + 2 * PW_BK * PW_LDA);
 
   // ---- XCD-aware tile numbering: hardware places block id on XCD id%8; give each XCD a contiguous
   // run of virtual ids so the nMt blocks that share one X tile hit the same L2 (bijective remap).
@@ -117,16 +121,22 @@ __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int
   auto gload = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
+      // unconditional load from a clamped row, masked afterwards (a "cond ? load : 0" select makes
+      // hipcc branch around each load and drain vmcnt(0), serialising the prefetch)
       const int m = m0 + a_m + 64 * p;
-      ra[p] = (m < Cout) ? *reinterpret_cast<const float4*>(a.w + (size_t)m * Cin + k0 + a_kq)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float msk = (m < Cout) ? 1.f : 0.f;
+      float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(m < Cout ? m : 0) * Cin + k0 + a_kq);
+      wv.x *= msk;
+      wv.y *= msk;
+      wv.z *= msk;
+      wv.w *= msk;
+      ra[p] = wv;
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int k = k0 + b_r + 8 * p;
       const int l = l0 + b_c;
-      float4 xv = (l < L) ? *reinterpret_cast<const float4*>(xb + (size_t)k * L + l)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)k * L + (l < L ? l : 0));  // cols >= L never stored
       if (PRO == 1 || PRO == 2) {
         const float sc = a.nrm.gamma[k] * rstd;
         const float sh = a.nrm.beta[k] - mean * sc;
@@ -182,13 +192,14 @@ __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int
     __syncthreads();
   }
 
-  // ---- epilogue (shared with the bf16x3 kernel): bias / residual / ReLU*enc / statistics
+  // ---- epilogue (shared with the bf16x3 kernel): per-wave LDS strips -> row-contiguous float4 I/O
   float s = 0.f, q = 0.f;
   const int mb = m0 + wm * 64, lb = l0 + wn * 64;
-  srf_pw_epilogue_tile(a, acc00, b, mb, lb, lane, s, q);
-  srf_pw_epilogue_tile(a, acc01, b, mb, lb + 32, lane, s, q);
-  srf_pw_epilogue_tile(a, acc10, b, mb + 32, lb, lane, s, q);
-  srf_pw_epilogue_tile(a, acc11, b, mb + 32, lb + 32, lane, s, q);
+  float* strip = smem_f + wave * (32 * SRF_EPI_PITCH);   // tiles are dead after the last barrier
+  srf_pw_epilogue_strip(a, acc00, acc01, strip, b, mb, lb, lane, s, q);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // strip reads done before it is rewritten
+  __builtin_amdgcn_wave_barrier();
+  srf_pw_epilogue_strip(a, acc10, acc11, strip, b, mb + 32, lb, lane, s, q);
   if (a.out_sums) srf_block_stats_atomic<4>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v), red);
 }
 

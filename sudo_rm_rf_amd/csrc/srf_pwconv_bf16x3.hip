@@ -62,9 +62,15 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
   const bool a_ok = (m0 + a_m) < Cout;
   const float* a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_kh;
   // B (X_b [k][time]): thread -> time pair n = 2*(tid&63), k-group kg = tid>>6 (8 consecutive k rows)
-  const int b_n = 2 * (tid & 63), b_kg = (tid >> 6) * 8;
+  // b_kg is wave-uniform: readfirstlane makes that provable, so the per-channel gamma/beta of the
+  // prologue become scalar (SMEM) loads instead of VMEM loads that would perturb the vmcnt pipeline
+  const int b_n = 2 * (tid & 63), b_kg = __builtin_amdgcn_readfirstlane(tid >> 6) * 8;
   const bool b_ok = (l0 + b_n) < L;   // L % 4 == 0 and n even -> both elements in range
-  const float* b_src = xb + (size_t)b_kg * L + (l0 + b_n);
+  // NOTE: loads are UNCONDITIONAL from clamped (always valid) addresses and masked afterwards: a
+  // "cond ? load : 0" select makes hipcc branch around every load and drain vmcnt(0) behind it, which
+  // serialises the whole prefetch pipeline (cdna_hip_programming.md "register or load" trap).
+  const float* b_src = xb + (size_t)b_kg * L + (b_ok ? (l0 + b_n) : 0);
+  const float a_msk = a_ok ? 1.f : 0.f;   // (out-of-range time columns are simply never stored)
 
   // Two register sets: tile t lives in set t&1.  Global loads are issued TWO k-tiles ahead of their
   // use, so that a full MFMA phase plus a conversion phase of latency hiding covers every load (with
@@ -77,18 +83,18 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
   auto gload = [&](Regs& r, int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      r.a[i] = a_ok ? *reinterpret_cast<const float4*>(a_src + k0 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.a[i] = *reinterpret_cast<const float4*>(a_src + k0 + 4 * i);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      r.b[j] = b_ok ? *reinterpret_cast<const float2*>(b_src + (size_t)(k0 + j) * L) : make_float2(0.f, 0.f);
+    for (int j = 0; j < 8; ++j) r.b[j] = *reinterpret_cast<const float2*>(b_src + (size_t)(k0 + j) * L);
   };
   auto lds_store = [&](const Regs& r, int stage, int k0) {
     char* base = smem + stage * X3_STAGE;
     // A: two 8-k packets per thread
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const float va[8] = {r.a[2 * p].x, r.a[2 * p].y, r.a[2 * p].z, r.a[2 * p].w,
-                           r.a[2 * p + 1].x, r.a[2 * p + 1].y, r.a[2 * p + 1].z, r.a[2 * p + 1].w};
+      const float va[8] = {r.a[2 * p].x * a_msk,     r.a[2 * p].y * a_msk,     r.a[2 * p].z * a_msk,
+                           r.a[2 * p].w * a_msk,     r.a[2 * p + 1].x * a_msk, r.a[2 * p + 1].y * a_msk,
+                           r.a[2 * p + 1].z * a_msk, r.a[2 * p + 1].w * a_msk};
       bf16x8 hi, lo;
       srf_split8(va, hi, lo);
       const int off = a_m * X3_PITCH + (a_kh + 8 * p) * 2;
@@ -160,10 +166,10 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
   // one pipeline step for tile kt (stage kt&1): first convert + store tile kt+1 (already in `nx`,
   // loaded two steps ago) into the other stage and re-arm `nx` with tile kt+3, then the MFMAs of kt.
   auto step = [&](Regs& nx, int kt) {
-    if (kt + 1 < nk_) {
-      lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
-      if (kt + 3 < nk_) gload(nx, (kt + 3) * X3_BK);
-    }
+    // loads are issued unconditionally (clamped to the last tile: a conditional load would make the
+    // compiler's vmcnt bookkeeping conservative and drain the younger register set as well)
+    if (kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
+    gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
     mma_tile(kt & 1);
     __syncthreads();
   };
@@ -171,19 +177,21 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
   gload(r0, 0);
   gload(r1, X3_BK);           // nk >= 2 (host guarantees Cin % 64 == 0)
   lds_store(r0, 0, 0);
-  if (2 < nk_) gload(r0, 2 * X3_BK);
+  gload(r0, min(2, nk_ - 1) * X3_BK);
   __syncthreads();
   for (int kt = 0; kt < nk_; kt += 2) {
     step(r1, kt);              // tile kt+1 lives in r1, tile kt+2 (in flight) in r0
     step(r0, kt + 1);          // tile kt+2 lives in r0
   }
 
+  // ---- epilogue: every wave stages its 64x64 tile through two private LDS strips (the operand
+  // images are dead after the loop's last barrier) and streams rows out as float4
   float s = 0.f, q = 0.f;
   const int mb = m0 + wm * 64, lb = l0 + wn * 64;
-  srf_pw_epilogue_tile(a, acc00, b, mb, lb, lane, s, q);
-  srf_pw_epilogue_tile(a, acc01, b, mb, lb + 32, lane, s, q);
-  srf_pw_epilogue_tile(a, acc10, b, mb + 32, lb, lane, s, q);
-  srf_pw_epilogue_tile(a, acc11, b, mb + 32, lb + 32, lane, s, q);
+  float* strip = reinterpret_cast<float*>(smem) + wave * (2 * 32 * SRF_EPI_PITCH);
+  srf_pw_epilogue_strip(a, acc00, acc01, strip, b, mb, lb, lane, s, q);
+  srf_pw_epilogue_strip(a, acc10, acc11, strip + 32 * SRF_EPI_PITCH, b, mb + 32, lb, lane, s, q);
+  __syncthreads();  // strips are re-used as reduction scratch below
   // all LDS reads finished at the loop's last barrier: reuse the first bytes as reduction scratch
   if (a.out_sums)
     srf_block_stats_atomic<4>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
