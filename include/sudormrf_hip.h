@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 2
+#define SRF_ABI_VERSION 3
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -90,6 +90,7 @@ const char* srf_last_error(void);
  *   2 = fast paths, but 1x1 convs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32). */
 void srf_set_kernel_mode(int mode);
 int srf_get_kernel_mode(void);
+void srf_set_debug_flags(int flags); /* bit0: main GEMM kernel without instruction-interleave hints */
 
 /* In-library profiler (bench.py): between begin/end every kernel launched through this library is
  * followed by a HIP event on the caller's stream; end() synchronises the stream and get(i) returns
@@ -141,6 +142,18 @@ int srf_gln_apply_add(const float* x, const float* q, float* y, const srf_norm* 
 int srf_pw_conv(const float* x, const float* w, const float* bias, float* y,
                 int Bt, int Cin, int Cout, int L, const srf_norm* in_norm, const float* residual,
                 double* out_sums, int epilogue_mask, const float* mul, int mul_channels, void* stream);
+
+/* Pre-packed weights for the split-precision GEMM (kernel mode 0): the fp32 weight [Cout,Cin] is split
+ * into bf16 hi/lo and laid out tile-by-tile ONCE (srf_forward does it at the start of every forward for
+ * all its 1x1 convolutions, in one launch).  srf_packed_pw_weight_bytes() = 0 when the shape does not
+ * qualify (needs Cin % 64 == 0, Cout >= 192); srf_pw_conv_packed() with w_packed = NULL (or a
+ * non-qualifying shape / mode) is exactly srf_pw_conv().  packed buffers: 16-B aligned device memory. */
+size_t srf_packed_pw_weight_bytes(int Cout, int Cin);
+int srf_pack_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n,
+                        void* stream);
+int srf_pw_conv_packed(const float* x, const float* w, const void* w_packed, const float* bias, float* y,
+                       int Bt, int Cin, int Cout, int L, const srf_norm* in_norm, const float* residual,
+                       double* out_sums, int epilogue_mask, const float* mul, int mul_channels, void* stream);
 
 /* Depthwise k=5, padding 2: y[r,j] = bias[c] + sum_k w[c,k] * f(x[r, stride*j+k-2]), r=(b,c), zero
  * outside AFTER f (the reference pads the normalised tensor).  x: [Bt,C,Lin], y: [Bt,C,Lout],

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 STAT_BUCKETS = 64
 
 SRF_OK = 0
@@ -55,6 +55,10 @@ _PROTOS = {
     "srf_gln_apply": (_i, [_vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _vp]),
     "srf_gln_apply_add": (_i, [_vp, _vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _vp]),
     "srf_pw_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _i, _vp, _i, _vp]),
+    "srf_set_debug_flags": (None, [_i]),
+    "srf_packed_pw_weight_bytes": (_sz, [_i, _i]),
+    "srf_pack_pw_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
+    "srf_pw_conv_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _i, _vp, _i, _vp]),
     "srf_dwconv5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp]),
     "srf_merge": (_i, [C.POINTER(_vp), C.POINTER(srf_norm), _i, _vp, _i, _i, _i, _vp, _vp]),
     "srf_decoder_scratch_floats": (_sz, [_i, _i, _i, _i, _i]),

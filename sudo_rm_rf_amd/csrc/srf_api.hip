@@ -24,6 +24,9 @@ void srf_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 int srf_kernel_mode() { return g_kernel_mode; }
+static int g_debug_flags = 0;
+int srf_debug_flags() { return g_debug_flags; }
+extern "C" void srf_set_debug_flags(int f) { g_debug_flags = f; }
 
 // ---- in-library HIP-event profiler: one event after every kernel launch on the caller's stream ------
 struct ProfMark {
@@ -131,6 +134,10 @@ struct srf_plan {
   size_t off_stats, stats_bytes, off_enc, off_xa, off_xb, off_xq, off_xu, off_y1, off_lv[SRF_MAX_DEPTH],
       off_masked, off_dec, total_bytes;
   int slots_per_block, n_slots;
+  // pre-packed (split-bf16) weights of the 1x1 convolutions: param index -> workspace offset (0 = none)
+  std::vector<int> pk_param, pk_cout, pk_cin;
+  std::vector<size_t> pk_off;
+  std::vector<size_t> pk_of_param;  // [n_params] offset or 0
 };
 
 static int plan_fail(srf_plan* p, int rc) {
@@ -153,9 +160,8 @@ extern "C" int srf_plan_create(const srf_config* c, int batch, int T, srf_plan**
   SRF_CHECK_ARG(c->enc_kernel_size >= 3 && (c->enc_kernel_size & 1),
                 "srf_plan_create: enc_kernel_size must be odd (the reference's mask multiply breaks "
                 "for even sizes)");
-  srf_plan* p = new (std::nothrow) srf_plan;
+  srf_plan* p = new (std::nothrow) srf_plan();
   SRF_CHECK_ARG(p != nullptr, "srf_plan_create: out of host memory");
-  memset(p, 0, sizeof(*p));
   p->cfg = *c;
   const bool gc = c->variant == SRF_VARIANT_GROUPCOMM;
   const int G = gc ? c->group_size : 1;
@@ -226,6 +232,25 @@ extern "C" int srf_plan_create(const srf_config* c, int batch, int T, srf_plan**
   for (int k = 0; k < D; ++k) p->off_lv[k] = take(F * batch * c->in_channels * (L >> k));
   p->off_masked = take(F * batch * p->SA * c->enc_num_basis * L);
   p->off_dec = take(F * srf_decoder_scratch_floats(batch, p->SA * c->enc_num_basis, p->SA, K, p->L));
+  // packed weights for the split-precision GEMM (only shapes the kernel supports)
+  p->pk_of_param.assign(p->n_params, 0);
+  auto add_pack = [&](int param, int cout, int cin) {
+    const size_t bytes = srf_packed_pw_weight_bytes(cout, cin);
+    if (!bytes) return;
+    const size_t o = take(bytes);
+    p->pk_param.push_back(param);
+    p->pk_cout.push_back(cout);
+    p->pk_cin.push_back(cin);
+    p->pk_off.push_back(o);
+    p->pk_of_param[param] = o;
+  };
+  add_pack(3, c->out_channels, c->enc_num_basis);
+  for (int i = 0; i < U; ++i) {
+    const int pu = p->p_block0 + i * p->p_block_stride + p->p_ublock_off;
+    add_pack(pu + 0, p->nC, p->nB);
+    add_pack(pu + 5 + 4 * D + 3, p->nB, p->nC);
+  }
+  add_pack(p->p_tail + 1, p->SA * c->enc_num_basis, c->out_channels);
   p->total_bytes = off;
   p->n_launches = 1 /*memset*/ + 2 + U * (D + 3 + (gc ? 2 : 0)) + 1 + 4;
   *out = p;
@@ -267,6 +292,21 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
   int rc;
 
   SRF_CHECK_HIP(hipMemsetAsync(stats, 0, p->stats_bytes, st));
+  // split + lay out every 1x1 weight for the split-precision GEMM, one launch (kernel mode 0 only)
+  const bool use_pack = srf_kernel_mode() == 0 && !p->pk_param.empty();
+  if (use_pack) {
+    std::vector<const float*> pw(p->pk_param.size());
+    std::vector<void*> pd(p->pk_param.size());
+    for (size_t i = 0; i < p->pk_param.size(); ++i) {
+      pw[i] = P[p->pk_param[i]];
+      pd[i] = ws + p->pk_off[i];
+    }
+    rc = srf_pack_pw_weights(pw.data(), pd.data(), p->pk_cout.data(), p->pk_cin.data(), (int)pw.size(), stream);
+    if (rc) return rc;
+  }
+  auto packed = [&](int param_index) -> const void* {
+    return (use_pack && p->pk_of_param[param_index]) ? (const void*)(ws + p->pk_of_param[param_index]) : nullptr;
+  };
 
   // ---- front end: encoder (+ ln statistics), ln folded into the bottleneck GEMM's operand load
   float* enc = fptr(p->off_enc);
@@ -276,8 +316,8 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
   float* nxt = fptr(p->off_xb);
   {
     srf_norm ln{slot(0), P[1], P[2], nullptr};
-    rc = srf_pw_conv(enc, P[3], P[4], cur, Bt, N, c.out_channels, L, &ln, nullptr, nullptr, 0, nullptr, 0,
-                     stream);
+    rc = srf_pw_conv_packed(enc, P[3], packed(3), P[4], cur, Bt, N, c.out_channels, L, &ln, nullptr, nullptr,
+                            0, nullptr, 0, stream);
     if (rc) return rc;
   }
 
@@ -301,8 +341,9 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
       s0 += 1;
     }
     // proj_1x1 conv (+ statistics for its GlobLN)            improved_sudormrf.py:205
-    rc = srf_pw_conv(xin, Pu[0], Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0), 0, nullptr, 0,
-                     stream);
+    const int pu_index = p->p_block0 + i * p->p_block_stride + p->p_ublock_off;
+    rc = srf_pw_conv_packed(xin, Pu[0], packed(pu_index), Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0),
+                            0, nullptr, 0, stream);
     if (rc) return rc;
     // depthwise pyramid                                       :206-211
     const float* levels[SRF_MAX_DEPTH];
@@ -337,7 +378,8 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
     // final_norm + PReLU folded into res_conv, + residual     :218-220
     const float* const* Pf = Pu + 5 + 4 * D;
     srf_norm fn{slot(s0 + 1 + D), Pf[0], Pf[1], Pf[2]};
-    rc = srf_pw_conv(merged, Pf[3], Pf[4], nxt, Bg, nC, nB, L, &fn, xin, nullptr, 0, nullptr, 0, stream);
+    rc = srf_pw_conv_packed(merged, Pf[3], packed(pu_index + 5 + 4 * D + 3), Pf[4], nxt, Bg, nC, nB, L, &fn, xin,
+                            nullptr, 0, nullptr, 0, stream);
     if (rc) return rc;
     float* t = cur;
     cur = nxt;
@@ -349,8 +391,8 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
   float* masked = fptr(p->off_masked);
   {
     srf_norm pre{nullptr, nullptr, nullptr, Pt[0]};
-    rc = srf_pw_conv(cur, Pt[1], Pt[2], masked, Bt, c.out_channels, p->SA * N, L, &pre, nullptr, nullptr, 1,
-                     enc, N, stream);
+    rc = srf_pw_conv_packed(cur, Pt[1], packed(p->p_tail + 1), Pt[2], masked, Bt, c.out_channels, p->SA * N, L,
+                            &pre, nullptr, nullptr, 1, enc, N, stream);
     if (rc) return rc;
   }
   rc = srf_decoder(masked, Pt[3], out, Bt, p->SA * N, p->SA, K, L, p->T, fptr(p->off_dec), stream);

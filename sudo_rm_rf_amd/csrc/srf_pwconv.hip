@@ -204,11 +204,39 @@ __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int
 }
 
 int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st);
+int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
+size_t srf_x3p_packed_bytes(int Cout, int Cin);
+bool srf_x3p_supported(int Cin, int Cout, int L);
+int srf_x3p_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n,
+                        hipStream_t st);
+
+extern "C" size_t srf_packed_pw_weight_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || !srf_x3p_supported(Cin, Cout, 4)) return 0;
+  return srf_x3p_packed_bytes(Cout, Cin);
+}
+
+extern "C" int srf_pack_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin,
+                                   int n, void* stream) {
+  SRF_CHECK_ARG(w && packed && Cout && Cin && n > 0, "srf_pack_pw_weights: bad arguments");
+  for (int i = 0; i < n; ++i)
+    SRF_CHECK_ARG(w[i] && packed[i] && srf_packed_pw_weight_bytes(Cout[i], Cin[i]) > 0 &&
+                      srf_aligned16(packed[i]),
+                  "srf_pack_pw_weights: entry %d unsupported (Cout=%d Cin=%d)", i, Cout[i], Cin[i]);
+  return srf_x3p_pack_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
+}
 
 extern "C" int srf_pw_conv(const float* x, const float* w, const float* bias, float* y, int Bt, int Cin,
                            int Cout, int L, const srf_norm* in_norm, const float* residual,
                            double* out_sums, int epilogue_mask, const float* mul, int mul_channels,
                            void* stream) {
+  return srf_pw_conv_packed(x, w, nullptr, bias, y, Bt, Cin, Cout, L, in_norm, residual, out_sums,
+                            epilogue_mask, mul, mul_channels, stream);
+}
+
+extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_packed, const float* bias,
+                                  float* y, int Bt, int Cin, int Cout, int L, const srf_norm* in_norm,
+                                  const float* residual, double* out_sums, int epilogue_mask, const float* mul,
+                                  int mul_channels, void* stream) {
   SRF_CHECK_ARG(x && w && bias && y, "srf_pw_conv: null pointer");
   SRF_CHECK_ARG(Bt > 0 && Cin > 0 && Cout > 0 && L > 0, "srf_pw_conv: bad sizes");
   SRF_CHECK_ARG(!epilogue_mask || (mul && mul_channels > 0), "srf_pw_conv: mask epilogue needs mul");
@@ -235,6 +263,8 @@ extern "C" int srf_pw_conv(const float* x, const float* w, const float* bias, fl
   const bool mfma_ok = mode != 1 && (Cin % PW_BK == 0) && (L % 4 == 0) && Cout >= 32 && Cin >= 32 &&
                        srf_aligned16(x) && srf_aligned16(w);
   const int pro_sel = a.nrm.sums ? (a.nrm.prelu ? 2 : 1) : (a.nrm.prelu ? 3 : 0);
+  if (mfma_ok && mode == 0 && w_packed && srf_x3p_supported(Cin, Cout, L) && srf_aligned16(w_packed))
+    return srf_pw_x3p_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
   if (mfma_ok && mode == 0 && (Cin % 64 == 0)) return srf_pw_bf16x3_launch(a, pro_sel, st);
   if (mfma_ok) {
     const int nMt = (Cout + PW_BM - 1) / PW_BM, nLt = (L + PW_BN - 1) / PW_BN;

@@ -79,16 +79,36 @@ def glob_ln(x, gamma, beta):
     return gln_apply(x, gln_stats(x, x.shape[0]), gamma, beta)
 
 
+def pack_pw_weight(weight):
+    """Split a 1x1 weight into bf16 hi/lo tiles for the split-precision GEMM (None if the shape does not
+    qualify).  srf_forward does this itself, once per forward, for all its 1x1 convolutions."""
+    dev = _chk(weight)
+    Cout = weight.shape[0]
+    Cin = weight.numel() // Cout
+    lib = _lib.load()
+    nbytes = lib.srf_packed_pw_weight_bytes(Cout, Cin)
+    if not nbytes:
+        return None
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.srf_pack_pw_weights((C.c_void_p * 1)(weight.data_ptr()), (C.c_void_p * 1)(packed.data_ptr()),
+                                       (C.c_int * 1)(Cout), (C.c_int * 1)(Cin), 1, _lib.current_stream(dev)),
+               "srf_pack_pw_weights")
+    return packed
+
+
 def pw_conv(x, weight, bias, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None, residual=None,
-            out_sums=None, mask_mul=None):
+            out_sums=None, mask_mul=None, packed=None):
     """1x1 conv with fused prologue / epilogue.  x [Bt,Cin,L], weight [Cout,Cin(,1)] -> [Bt,Cout,L]."""
     dev = _chk(x, weight, bias, in_sums, in_gamma, in_beta, in_prelu, residual, out_sums, mask_mul)
     Bt, Cin, L = x.shape
     Cout = weight.shape[0]
     assert weight.numel() == Cout * Cin
     y = torch.empty((Bt, Cout, L), dtype=torch.float32, device=dev)
-    rc = _lib.load().srf_pw_conv(
-        _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), Bt, Cin, Cout, L,
+    lib = _lib.load()
+    if packed is None and lib.srf_get_kernel_mode() == 0:
+        packed = pack_pw_weight(weight)
+    rc = lib.srf_pw_conv_packed(
+        _lib.ptr(x), _lib.ptr(weight), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(y), Bt, Cin, Cout, L,
         _norm(in_sums, in_gamma, in_beta, in_prelu), _lib.ptr(residual), _lib.ptr(out_sums),
         1 if mask_mul is not None else 0, _lib.ptr(mask_mul),
         mask_mul.shape[1] if mask_mul is not None else 0, _lib.current_stream(dev))
@@ -160,6 +180,10 @@ def mixture_consistency(pr_batch, input_mixture):
                                              Bt, S, T, _lib.current_stream(dev))
     _lib.check(rc, "srf_mixture_consistency")
     return out
+
+
+def set_debug_flags(flags):
+    _lib.load().srf_set_debug_flags(int(flags))
 
 
 def set_kernel_mode(mode):

@@ -18,7 +18,7 @@ SHAPES = {  # name: (Bt, Cin, Cout, L, prologue, residual, stats, mask)
 
 
 def main():
-    modes = [int(m) for m in (sys.argv[1:] or ["0", "2"])]
+    modes = sys.argv[1:] or ["2", "0", "0n", "0u"]   # 0 packed+sched hints, 0n packed no hints, 0u unpacked
     out = {}
     for name, (Bt, Cin, Cout, L, pro, res, stats, mask) in SHAPES.items():
         g = torch.Generator(device="cpu").manual_seed(0)
@@ -38,7 +38,17 @@ def main():
             kw.update(mask_mul=torch.randn(Bt, 512, L, generator=g).to(DEV))
         ref = None
         for mode in modes:
-            ops.set_kernel_mode(mode)
+            ops.set_kernel_mode(int(mode[0]))
+            ops.set_debug_flags(1 if mode.endswith("n") else 0)
+            kw["packed"] = ops.pack_pw_weight(w) if mode in ("0", "0n") else torch.zeros(0, device=DEV)
+            if kw["packed"] is None or kw["packed"].numel() == 0:
+                kw["packed"] = None
+                if mode in ("0", "0n"):
+                    continue
+            if mode == "0u":
+                import sudo_rm_rf_amd.ops as _o
+                _pack = _o.pack_pw_weight
+                _o.pack_pw_weight = lambda w_: None
             if stats:
                 kw["out_sums"] = ops.new_sums(Bt, DEV)
             y = ops.pw_conv(x, w, bias, **kw)
@@ -55,10 +65,13 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / n
             tf = 2.0 * Bt * Cin * Cout * L / (us * 1e-6) / 1e12
+            if mode == "0u":
+                _o.pack_pw_weight = _pack
             out[f"{name}/mode{mode}"] = {"us": round(us, 1), "TFLOPs_fp32_equiv": round(tf, 1),
                                          "max_abs_diff_vs_first_mode": err}
-            print(f"{name:16s} mode {mode}: {us:9.1f} us  {tf:7.1f} TF  diff {err:.2e}", flush=True)
+            print(f"{name:16s} mode {mode:3s}: {us:9.1f} us  {tf:7.1f} TF  diff {err:.2e}", flush=True)
         ops.set_kernel_mode(0)
+        ops.set_debug_flags(0)
     print(json.dumps(out))
 
 
