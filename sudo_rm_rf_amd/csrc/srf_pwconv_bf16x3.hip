@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
 // MFMA phases with too few co-resident waves to overlap them (MFMA pipe 21 % busy); a 256x128 /
 // 1-block-per-CU variant with explicit instruction interleaving measured slower still.
 // ---------------------------------------------------------------------------------------------
-template <int PRO>
+// ABL (ablation, diagnostics only; results are wrong when != 0): 1 = no A loads, 2 = no B loads,
+// 4 = no MFMAs, 8 = no conversion / LDS stores
+template <int PRO, int ABL = 0>
 __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int nMt, int nLt, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
 
@@ -245,11 +247,20 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
     float b[8];
   };
   Regs r0, r1;
-  auto gload = [&](Regs& r, int k0) {
-    r.a[0] = *reinterpret_cast<const float4*>(a_src + k0);
-    r.a[1] = *reinterpret_cast<const float4*>(a_src + k0 + 4);
+  if (ABL & 3) {   // ablation: registers that are never loaded still need defined contents
+    r0.a[0] = r0.a[1] = r1.a[0] = r1.a[1] = make_float4(1.f, 2.f, 3.f, 4.f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.b[j] = b_src[(size_t)(k0 + j) * L];
+    for (int j = 0; j < 8; ++j) r0.b[j] = r1.b[j] = 0.5f * j;
+  }
+  auto gload = [&](Regs& r, int k0) {
+    if (!(ABL & 1)) {
+      r.a[0] = *reinterpret_cast<const float4*>(a_src + k0);
+      r.a[1] = *reinterpret_cast<const float4*>(a_src + k0 + 4);
+    }
+    if (!(ABL & 2)) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.b[j] = b_src[(size_t)(k0 + j) * L];
+    }
   };
   auto lds_store = [&](const Regs& r, int stage, int k0) {
     char* base = smem + stage * X3_STAGE;
@@ -300,9 +311,9 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
     }
   };
   auto step = [&](Regs& nx, int kt) {
-    if (kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
+    if (!(ABL & 8) && kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
     gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
-    mma_tile(kt & 1);
+    if (!(ABL & 4)) mma_tile(kt & 1);
     __syncthreads();
   };
 
@@ -314,6 +325,9 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
   for (int kt = 0; kt < nk_; kt += 2) {
     step(r1, kt);
     step(r0, kt + 1);
+  }
+  if (ABL) {   // keep everything the ablated pipeline produced alive
+    asm volatile("" ::"v"(r0.a[0].x), "v"(r1.a[0].x), "v"(r0.b[0]), "v"(r1.b[0]), "v"(r0.a[1].w), "v"(r1.b[7]));
   }
 
   float s = 0.f, q = 0.f;
@@ -331,6 +345,20 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
   if ((srf_debug_flags() & 2) == 0) {   // default: 8-wave variant
     dim3 grid8((unsigned)total), block8(512);
+    const int abl = (srf_debug_flags() >> 8) & 15;   // diagnostics: ablated pipelines (PRO 0 only)
+    if (abl && pro == 0) {
+      switch (abl) {
+        case 1: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 1>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        case 2: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 2>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        case 3: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 3>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        case 4: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 4>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        case 8: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 8>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        case 12: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 12>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        default: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 15>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+      }
+      SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8_ablated", st);
+      return SRF_OK;
+    }
     switch (pro) {
       case 0: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<0>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
       case 1: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<1>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
