@@ -339,11 +339,182 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
                               reinterpret_cast<double*>(smem));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised variant (default): the ablation of the kernels above showed time ~ SUM of
+// {operand loads, split/convert + LDS stores, MFMAs, epilogue} -- the barrier-synchronised waves of a
+// block are always in the same phase, so the matrix pipe idles while they convert and vice versa.
+// Here a 512-thread block splits into 4 MMA wavefronts (64x64 accumulator tile each: only ds_read +
+// MFMA) and 4 LOADER wavefronts (global loads two k-tiles ahead, GlobLN/PReLU prologue, bf16 hi/lo
+// split, ds_write of the next stage): per k-tile the block costs max(convert, MFMA) instead of their
+// sum, and every SIMD always holds one wave of each kind per resident block.
+// ---------------------------------------------------------------------------------------------
+template <int PRO>
+__global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_ws_kernel(PwArgs a, int nMt, int nLt, int total) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB -> 2 blocks / CU
+
+  const int v = srf_xcd_remap(blockIdx.x, total);
+  const int mt = v % nMt;
+  const int lt = (v / nMt) % nLt;
+  const long b = v / (nMt * nLt);
+  const int m0 = mt * X3_BM, l0 = lt * X3_BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Cin = a.Cin, L = a.L, Cout = a.Cout;
+  const int nk_ = Cin / X3_BK;   // even (host checks Cin % 64 == 0)
+
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+  const int wm = (wave >> 1) & 1, wn = wave & 1;   // MMA waves 0..3: 2 x 2, 64 x 64 each
+
+  if (wave >= 4) {
+    // =========================== LOADER wavefronts ===========================
+    float mean = 0.f, rstd = 1.f, slope = 1.f;
+    if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
+    if (PRO == 2 || PRO == 3) slope = a.nrm.prelu[0];
+    const int t = tid - 256;
+    const float* xb = a.x + (size_t)b * Cin * L;
+    // A (weights [m][k]): rows (t>>2) and (t>>2)+64, 8-k packet pk = t&3 -> whole 128-B lines per row
+    const int a_m = t >> 2, a_pk = t & 3;
+    const bool a_ok0 = (m0 + a_m) < Cout, a_ok1 = (m0 + a_m + 64) < Cout;
+    const float* a_src0 = a.w + (size_t)(a_ok0 ? (m0 + a_m) : 0) * Cin + a_pk * 8;
+    const float* a_src1 = a.w + (size_t)(a_ok1 ? (m0 + a_m + 64) : 0) * Cin + a_pk * 8;
+    const float a_msk0 = a_ok0 ? 1.f : 0.f, a_msk1 = a_ok1 ? 1.f : 0.f;
+    const int a_lds = a_m * X3_PITCH + a_pk * 16;
+    // B (X_b [k][time]): time step n = t&127, k-half kh = t>>7 (wave-uniform): 16 k rows x 1 time step
+    const int b_n = t & 127, b_kh = ((wave - 4) >> 1) * 16;
+    const bool b_ok = (l0 + b_n) < L;
+    const float* b_src = xb + (size_t)b_kh * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
+    const int b_lds = b_n * X3_PITCH + b_kh * 2;
+
+    struct Regs {
+      float4 a[4];
+      float b[16];
+    };
+    Regs r0, r1;
+    auto gload = [&](Regs& r, int k0) {
+      r.a[0] = *reinterpret_cast<const float4*>(a_src0 + k0);
+      r.a[1] = *reinterpret_cast<const float4*>(a_src0 + k0 + 4);
+      r.a[2] = *reinterpret_cast<const float4*>(a_src1 + k0);
+      r.a[3] = *reinterpret_cast<const float4*>(a_src1 + k0 + 4);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) r.b[j] = b_src[(size_t)(k0 + j) * L];
+    };
+    auto lds_store = [&](const Regs& r, int stage, int k0) {
+      char* base = smem + stage * X3_STAGE;
+      bf16x8 hi, lo;
+      {
+        const float va[8] = {r.a[0].x * a_msk0, r.a[0].y * a_msk0, r.a[0].z * a_msk0, r.a[0].w * a_msk0,
+                             r.a[1].x * a_msk0, r.a[1].y * a_msk0, r.a[1].z * a_msk0, r.a[1].w * a_msk0};
+        srf_split8(va, hi, lo);
+        *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + a_lds) = hi;
+        *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + a_lds) = lo;
+      }
+      {
+        const float va[8] = {r.a[2].x * a_msk1, r.a[2].y * a_msk1, r.a[2].z * a_msk1, r.a[2].w * a_msk1,
+                             r.a[3].x * a_msk1, r.a[3].y * a_msk1, r.a[3].z * a_msk1, r.a[3].w * a_msk1};
+        srf_split8(va, hi, lo);
+        *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + 64 * X3_PITCH + a_lds) = hi;
+        *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + 64 * X3_PITCH + a_lds) = lo;
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float vb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float x0 = r.b[8 * p + j];
+          if (PRO == 1 || PRO == 2) {
+            const int k = k0 + b_kh + 8 * p + j;
+            const float sc = a.nrm.gamma[k] * rstd;
+            x0 = fmaf(x0, sc, a.nrm.beta[k] - mean * sc);
+          }
+          if (PRO == 2 || PRO == 3) x0 = srf_prelu(x0, slope);
+          vb[j] = x0;
+        }
+        srf_split8(vb, hi, lo);
+        *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + b_lds + 16 * p) = hi;
+        *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + b_lds + 16 * p) = lo;
+      }
+    };
+    auto step = [&](Regs& nx, int kt) {
+      if (kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
+      gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
+      __syncthreads();
+    };
+    gload(r0, 0);
+    gload(r1, X3_BK);
+    lds_store(r0, 0, 0);
+    gload(r0, min(2, nk_ - 1) * X3_BK);
+    __syncthreads();
+    for (int kt = 0; kt < nk_; kt += 2) {
+      step(r1, kt);
+      step(r0, kt + 1);
+    }
+    asm volatile("" ::"v"(r0.b[0]), "v"(r1.b[0]));   // surplus clamped prefetches stay well-defined
+  } else {
+    // ============================= MMA wavefronts =============================
+    const int frag = (lane & 31) * X3_PITCH + (lane >> 5) * 16;
+    const int a_row0 = (wm * 64) * X3_PITCH + frag, a_row1 = a_row0 + 32 * X3_PITCH;
+    const int b_row0 = (wn * 64) * X3_PITCH + frag, b_row1 = b_row0 + 32 * X3_PITCH;
+    __syncthreads();   // stage 0 ready
+    for (int kt = 0; kt < nk_; ++kt) {
+      const char* base = smem + (kt & 1) * X3_STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ko = ks * 32;
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row0 + ko);
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row1 + ko);
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row0 + ko);
+        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row1 + ko);
+        const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row0 + ko);
+        const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
+        const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
+        const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: MMA waves stream their tiles out through private LDS strips (operand stages dead)
+  float s = 0.f, q = 0.f;
+  if (wave < 4) {
+    const int mb = m0 + wm * 64, lb = l0 + wn * 64;
+    float* strip = reinterpret_cast<float*>(smem) + wave * (2 * 32 * SRF_EPI_PITCH);
+    srf_pw_epilogue_strip(a, acc00, acc01, strip, b, mb, lb, lane, s, q);
+    srf_pw_epilogue_strip(a, acc10, acc11, strip + 32 * SRF_EPI_PITCH, b, mb + 32, lb, lane, s, q);
+  }
+  __syncthreads();
+  if (a.out_sums)
+    srf_block_stats_atomic<8>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
+                              reinterpret_cast<double*>(smem));
+}
+
 int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
   const int nMt = (a.Cout + X3_BM - 1) / X3_BM, nLt = (a.L + X3_BN - 1) / X3_BN;
   const long total = (long)a.Bt * nMt * nLt;
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
-  if ((srf_debug_flags() & 2) == 0) {   // default: 8-wave variant
+  if ((srf_debug_flags() & 6) == 0) {   // default: wave-specialised variant
+    dim3 gridw((unsigned)total), blockw(512);
+    switch (pro) {
+      case 0: hipLaunchKernelGGL(srf_pw_bf16x3_ws_kernel<0>, gridw, blockw, 0, st, a, nMt, nLt, (int)total); break;
+      case 1: hipLaunchKernelGGL(srf_pw_bf16x3_ws_kernel<1>, gridw, blockw, 0, st, a, nMt, nLt, (int)total); break;
+      case 2: hipLaunchKernelGGL(srf_pw_bf16x3_ws_kernel<2>, gridw, blockw, 0, st, a, nMt, nLt, (int)total); break;
+      default: hipLaunchKernelGGL(srf_pw_bf16x3_ws_kernel<3>, gridw, blockw, 0, st, a, nMt, nLt, (int)total); break;
+    }
+    SRF_CHECK_LAUNCH("pw_conv_bf16x3_ws", st);
+    return SRF_OK;
+  }
+  if ((srf_debug_flags() & 2) == 0) {   // flag 4: 8-wave variant
     dim3 grid8((unsigned)total), block8(512);
     const int abl = (srf_debug_flags() >> 8) & 15;   // diagnostics: ablated pipelines (PRO 0 only)
     if (abl && pro == 0) {
