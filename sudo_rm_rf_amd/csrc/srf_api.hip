@@ -293,7 +293,8 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
 
   SRF_CHECK_HIP(hipMemsetAsync(stats, 0, p->stats_bytes, st));
   // split + lay out every 1x1 weight for the split-precision GEMM, one launch (kernel mode 0 only)
-  const bool use_pack = srf_kernel_mode() == 0 && !p->pk_param.empty();
+  // (the packed 256x128 kernel measured slower than the 128x128 8-wave kernel: opt-in via debug flag 8)
+  const bool use_pack = srf_kernel_mode() == 0 && (srf_debug_flags() & 8) && !p->pk_param.empty();
   if (use_pack) {
     std::vector<const float*> pw(p->pk_param.size());
     std::vector<void*> pd(p->pk_param.size());

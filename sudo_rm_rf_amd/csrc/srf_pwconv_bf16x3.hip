@@ -340,7 +340,8 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave-specialised variant (default): the ablation of the kernels above showed time ~ SUM of
+// Wave-specialised variant (debug flag 4; measured 165 us vs 152 us for the symmetric 8-wave kernel on
+// the proj_1x1 shape -- kept for A/B): the ablation of the kernels above showed time ~ SUM of
 // {operand loads, split/convert + LDS stores, MFMAs, epilogue} -- the barrier-synchronised waves of a
 // block are always in the same phase, so the matrix pipe idles while they convert and vice versa.
 // Here a 512-thread block splits into 4 MMA wavefronts (64x64 accumulator tile each: only ds_read +
@@ -503,7 +504,7 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
   const int nMt = (a.Cout + X3_BM - 1) / X3_BM, nLt = (a.L + X3_BN - 1) / X3_BN;
   const long total = (long)a.Bt * nMt * nLt;
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
-  if ((srf_debug_flags() & 6) == 0) {   // default: wave-specialised variant
+  if ((srf_debug_flags() & 4) != 0) {   // flag 4: wave-specialised variant (measured no faster: the loader side is the bottleneck)
     dim3 gridw((unsigned)total), blockw(512);
     switch (pro) {
       case 0: hipLaunchKernelGGL(srf_pw_bf16x3_ws_kernel<0>, gridw, blockw, 0, st, a, nMt, nLt, (int)total); break;
@@ -514,7 +515,7 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
     SRF_CHECK_LAUNCH("pw_conv_bf16x3_ws", st);
     return SRF_OK;
   }
-  if ((srf_debug_flags() & 2) == 0) {   // flag 4: 8-wave variant
+  if ((srf_debug_flags() & 2) == 0) {   // default: 8-wave variant (flag 2: 4-wave variant)
     dim3 grid8((unsigned)total), block8(512);
     const int abl = (srf_debug_flags() >> 8) & 15;   // diagnostics: ablated pipelines (PRO 0 only)
     if (abl && pro == 0) {

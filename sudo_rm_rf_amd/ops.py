@@ -105,8 +105,6 @@ def pw_conv(x, weight, bias, in_sums=None, in_gamma=None, in_beta=None, in_prelu
     assert weight.numel() == Cout * Cin
     y = torch.empty((Bt, Cout, L), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    if packed is None and lib.srf_get_kernel_mode() == 0:
-        packed = pack_pw_weight(weight)
     rc = lib.srf_pw_conv_packed(
         _lib.ptr(x), _lib.ptr(weight), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(y), Bt, Cin, Cout, L,
         _norm(in_sums, in_gamma, in_beta, in_prelu), _lib.ptr(residual), _lib.ptr(out_sums),
