@@ -168,6 +168,18 @@ int srf_dwconv5(const float* x, const float* w, const float* bias, float* y,
 int srf_merge(const float* const* levels, const srf_norm* norms, int D, float* y,
               int Bt, int C, int L, double* out_sums, void* stream);
 
+/* Fused depthwise pyramid of one U-ConvBlock (all D depthwise convs + their GlobLNs + the upsample/add
+ * merge) in two passes over y1: y1 [groups,C,L] = proj_1x1 conv output (in_norm = its GlobLN + PReLU,
+ * applied on load) -> merged [groups,C,L] (+ out_sums for final_norm).  w/bias/gamma/beta: D pointers
+ * each (spp_dw[k].conv.weight/.bias, spp_dw[k].norm.gamma/.beta).  Equivalent to D x srf_dwconv5 +
+ * srf_merge but moves 3 C*L instead of 7.75 C*L through HBM.  srf_pyramid_supported() tells whether
+ * the shape qualifies (L % (4*2^(D-1)) == 0, L >> (D-1) >= 8, row fits LDS). */
+int srf_pyramid_supported(int C, int L, int D);
+size_t srf_pyramid_scratch_bytes(int groups, int C, int D);
+int srf_pyramid(const float* y1, float* merged, const srf_norm* in_norm, const float* const* w,
+                const float* const* bias, const float* const* gamma, const float* const* beta, int groups,
+                int C, int L, int D, void* scratch, double* out_sums, void* stream);
+
 /* Transposed conv synthesis + crop: out[b,o,t] = sum_{ci,l,k: h*l+k-h=t} v[b,ci,l]*w[ci,o,k], t<T.
  * v: [Bt,Ci,L], w: [Ci,Co,K] (ConvTranspose1d layout), out: [Bt,Co,T].
  * scratch: device buffer of srf_decoder_scratch_floats() floats. */

@@ -60,6 +60,10 @@ _PROTOS = {
     "srf_pack_pw_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
     "srf_pw_conv_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _i, _vp, _i, _vp]),
     "srf_dwconv5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp]),
+    "srf_pyramid_supported": (_i, [_i, _i, _i]),
+    "srf_pyramid_scratch_bytes": (_sz, [_i, _i, _i]),
+    "srf_pyramid": (_i, [_vp, _vp, C.POINTER(srf_norm), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                        C.POINTER(_vp), _i, _i, _i, _i, _vp, _vp, _vp]),
     "srf_merge": (_i, [C.POINTER(_vp), C.POINTER(srf_norm), _i, _vp, _i, _i, _i, _vp, _vp]),
     "srf_decoder_scratch_floats": (_sz, [_i, _i, _i, _i, _i]),
     "srf_decoder": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -132,7 +132,8 @@ struct srf_plan {
   int p_block0, p_block_stride, p_ublock_off, p_tail;
   // workspace offsets (bytes)
   size_t off_stats, stats_bytes, off_enc, off_xa, off_xb, off_xq, off_xu, off_y1, off_lv[SRF_MAX_DEPTH],
-      off_masked, off_dec, total_bytes;
+      off_masked, off_dec, off_pyr, total_bytes;
+  int fused_pyramid;
   int slots_per_block, n_slots;
   // pre-packed (split-bf16) weights of the 1x1 convolutions: param index -> workspace offset (0 = none)
   std::vector<int> pk_param, pk_cout, pk_cin;
@@ -232,6 +233,8 @@ extern "C" int srf_plan_create(const srf_config* c, int batch, int T, srf_plan**
   for (int k = 0; k < D; ++k) p->off_lv[k] = take(F * batch * c->in_channels * (L >> k));
   p->off_masked = take(F * batch * p->SA * c->enc_num_basis * L);
   p->off_dec = take(F * srf_decoder_scratch_floats(batch, p->SA * c->enc_num_basis, p->SA, K, p->L));
+  p->fused_pyramid = srf_pyramid_supported(p->nC, p->L, D);
+  p->off_pyr = p->fused_pyramid ? take(srf_pyramid_scratch_bytes(p->Bg, p->nC, D)) : 0;
   // packed weights for the split-precision GEMM (only shapes the kernel supports)
   p->pk_of_param.assign(p->n_params, 0);
   auto add_pack = [&](int param, int cout, int cin) {
@@ -346,7 +349,25 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
     rc = srf_pw_conv_packed(xin, Pu[0], packed(pu_index), Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0),
                             0, nullptr, 0, stream);
     if (rc) return rc;
-    // depthwise pyramid                                       :206-211
+    // depthwise pyramid + upsample/add                         :206-216
+    float* merged = y1;   // the merged tensor aliases y1 (dead once every level has been produced)
+    const bool fused = p->fused_pyramid && srf_kernel_mode() == 0 && !(srf_debug_flags() & 16);
+    if (fused) {
+      // two passes over y1 with every level kept on chip (srf_pyramid.hip); merged cannot alias y1
+      // here because pass 2 re-reads y1 row by row while writing merged rows -> own buffer (level 0's)
+      const float *pw[SRF_MAX_DEPTH], *pb[SRF_MAX_DEPTH], *pg[SRF_MAX_DEPTH], *pbe[SRF_MAX_DEPTH];
+      for (int k = 0; k < D; ++k) {
+        const float* const* Pk = Pu + 5 + 4 * k;
+        pw[k] = Pk[0];
+        pb[k] = Pk[1];
+        pg[k] = Pk[2];
+        pbe[k] = Pk[3];
+      }
+      srf_norm in{slot(s0), Pu[2], Pu[3], Pu[4]};
+      merged = fptr(p->off_lv[0]);
+      rc = srf_pyramid(y1, merged, &in, pw, pb, pg, pbe, Bg, nC, L, D, ws + p->off_pyr, slot(s0 + 1 + D), stream);
+      if (rc) return rc;
+    } else {
     const float* levels[SRF_MAX_DEPTH];
     srf_norm norms[SRF_MAX_DEPTH];
     for (int k = 0; k < D; ++k) {
@@ -373,9 +394,9 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
       norms[k] = srf_norm{slot(s0 + 1 + k), Pk[2], Pk[3], nullptr};
     }
     // upsample + add                                          :214-216   (output aliases y1: dead)
-    float* merged = y1;
     rc = srf_merge(levels, norms, D, merged, Bg, nC, L, slot(s0 + 1 + D), stream);
     if (rc) return rc;
+    }
     // final_norm + PReLU folded into res_conv, + residual     :218-220
     const float* const* Pf = Pu + 5 + 4 * D;
     srf_norm fn{slot(s0 + 1 + D), Pf[0], Pf[1], Pf[2]};

@@ -1,0 +1,427 @@
+// K3+K4 fused -- the whole depthwise pyramid of a U-ConvBlock (D depthwise k=5 convs, each followed by
+// a GlobLN, then the bottom-up nearest-x2 upsample+add; reference: improved_sudormrf.py:178-194,
+// :206-216) in TWO passes over the expanded tensor instead of D+1 materialising kernels:
+//
+//   pass 1  srf_pyramid_moments   read y1 once; per (batch,channel) row run the *un-normalised* conv
+//                                  cascade C_0 = d_0, C_k = w_k (*) C_{k-1} on chip and emit only row
+//                                  moments {sum C_k, sum C_k^2, C_k[0], C_k[1], C_k[last]}
+//   finalize srf_pyramid_finalize  per example: every level's GlobLN {mean, rstd} from those moments
+//   pass 2  srf_pyramid_merge     read y1 again; recompute the cascade with the real GlobLNs on chip,
+//                                  write the merged tensor (+ its {sum,sumsq} for final_norm)
+//
+// Why pass 1 works without knowing any statistics: GlobLN is affine per row, n = a*d + b*1, and the
+// zero-padded conv is linear, so with alpha_k = prod a_m and a data-independent edge/constant term G_k
+//      d_k = alpha_k * C_k + G_k,     G_k = bias_k + a_{k-1} conv_k(G_{k-1}) + b_{k-1} conv_k(1)
+// G_k is a constant kappa_k in the interior and differs only at j = 0, 1 and L_k-1 (zero padding),
+// hence  sum d_k   = alpha sum C + (L-3) kappa + g0 + g1 + gl
+//        sum d_k^2 = alpha^2 sum C^2 + 2 alpha (kappa (sum C - e0 - e1 - el) + g0 e0 + g1 e1 + gl el)
+//                    + (L-3) kappa^2 + g0^2 + g1^2 + gl^2          (e* = edge values of C_k)
+// (validated against direct evaluation to 1e-16 in fp64).  HBM traffic per block drops from
+// 7.75 C*L (D+1 kernels, every level written and re-read) to 3 C*L (y1 read twice, merged written).
+//
+// One 256-thread block per row; the row's levels live in LDS ([0..3] and [L_k+4..L_k+7] are physical
+// zero pads so that taps never need masks).  Requires L % (4 * 2^(D-1)) == 0 and L >> (D-1) >= 8;
+// otherwise srf_forward falls back to the per-level kernels (srf_dwconv.hip).
+#include "srf_common.h"
+
+struct PyrArgs {
+  const float* y1;
+  float* merged;
+  SrfNormDev in_norm;   // GlobLN (+PReLU) of proj_1x1, applied to y1 on load
+  double in_inv_count;
+  const float* w[SRF_MAX_DEPTH];
+  const float* bias[SRF_MAX_DEPTH];
+  const float* gamma[SRF_MAX_DEPTH];
+  const float* beta[SRF_MAX_DEPTH];
+  const float* lvl;     // [groups][D][2] {mean, rstd}    (pass 2)
+  double* mom;          // [rows][D][5]                   (pass 1)
+  double* out_sums;     // merged statistics              (pass 2)
+  int C, L, D;
+};
+
+__device__ __forceinline__ float srf_dot5(const float* w, float x0, float x1, float x2, float x3, float x4,
+                                          float init) {
+  return fmaf(w[4], x4, fmaf(w[3], x3, fmaf(w[2], x2, fmaf(w[1], x1, fmaf(w[0], x0, init)))));
+}
+
+// MOMENTS = true : pass 1 (raw cascade, moments out);  false : pass 2 (real GlobLNs, merged out)
+template <bool MOMENTS>
+__global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = a.L, D = a.D, C = a.C;
+  const long row = blockIdx.x;
+  const int c = (int)(row % C);
+  const long g = row / C;
+  const int tid = threadIdx.x;
+
+  // LDS carve: bufB = level 0 (L+8 floats), bufA = proj output o, later levels 1..D-1 back to back
+  float* bufB = lds;
+  float* bufA = lds + (L + 8);
+  int offA[SRF_MAX_DEPTH];
+  int lv_total = 0;
+  offA[0] = 0;
+#pragma unroll
+  for (int k = 1; k < SRF_MAX_DEPTH; ++k) {
+    offA[k] = lv_total;
+    if (k < D) lv_total += (L >> k) + 8;
+  }
+  const int sizeA = max(L + 8, lv_total);
+  double* red = reinterpret_cast<double*>(lds + (L + 8) + ((sizeA + 3) & ~3));   // 8-B aligned: sizes % 4 == 0
+
+  // ---- per-row coefficients
+  float mean, rstd;
+  float sc = 1.f, sh = 0.f;
+  if (a.in_norm.sums) {
+    srf_finalize_stats(a.in_norm.sums, g, a.in_inv_count, mean, rstd);
+    sc = a.in_norm.gamma[c] * rstd;
+    sh = a.in_norm.beta[c] - mean * sc;
+  }
+  const bool act = a.in_norm.prelu != nullptr;
+  const float slope = act ? a.in_norm.prelu[0] : 1.f;
+  float wk[SRF_MAX_DEPTH][5], bk[SRF_MAX_DEPTH], ak[SRF_MAX_DEPTH], ck[SRF_MAX_DEPTH];
+#pragma unroll
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+    if (k < D) {
+#pragma unroll
+      for (int t = 0; t < 5; ++t) wk[k][t] = a.w[k][c * 5 + t];
+      bk[k] = a.bias[k][c];
+      if (MOMENTS) {
+        ak[k] = 1.f;   // raw cascade: identity "norm", no bias below level 0
+        ck[k] = 0.f;
+        if (k > 0) bk[k] = 0.f;
+      } else {
+        const float m = a.lvl[(g * D + k) * 2 + 0], r = a.lvl[(g * D + k) * 2 + 1];
+        ak[k] = a.gamma[k][c] * r;
+        ck[k] = a.beta[k][c] - m * ak[k];
+      }
+    }
+  }
+
+  // ---- zero pads of every buffer (4 floats each side)
+  if (tid < 4) {
+    bufB[tid] = 0.f;
+    bufB[4 + L + tid] = 0.f;
+    bufA[tid] = 0.f;
+    bufA[4 + L + tid] = 0.f;
+  }
+
+  // ---- step 1: o = PReLU(GlobLN(y1)) -> bufA
+  const float4* yrow = reinterpret_cast<const float4*>(a.y1 + (size_t)row * L);
+  const int n4 = L >> 2;
+  for (int q = tid; q < n4; q += 256) {
+    float4 v = yrow[q];
+    v.x = fmaf(v.x, sc, sh);
+    v.y = fmaf(v.y, sc, sh);
+    v.z = fmaf(v.z, sc, sh);
+    v.w = fmaf(v.w, sc, sh);
+    if (act) {
+      v.x = srf_prelu(v.x, slope);
+      v.y = srf_prelu(v.y, slope);
+      v.z = srf_prelu(v.z, slope);
+      v.w = srf_prelu(v.w, slope);
+    }
+    *reinterpret_cast<float4*>(bufA + 4 + 4 * q) = v;
+  }
+  __syncthreads();
+
+  double s1[SRF_MAX_DEPTH], s2[SRF_MAX_DEPTH];
+#pragma unroll
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) s1[k] = s2[k] = 0.0;
+
+  // ---- step 2: level 0 (stride 1) from bufA -> bufB
+  for (int q = tid; q < n4; q += 256) {
+    const float* p = bufA + 4 + 4 * q;   // o[4q]
+    const float2 lo = *reinterpret_cast<const float2*>(p - 2);
+    const float4 mi = *reinterpret_cast<const float4*>(p);
+    const float2 hi = *reinterpret_cast<const float2*>(p + 4);
+    float4 d;
+    d.x = srf_dot5(wk[0], lo.x, lo.y, mi.x, mi.y, mi.z, bk[0]);
+    d.y = srf_dot5(wk[0], lo.y, mi.x, mi.y, mi.z, mi.w, bk[0]);
+    d.z = srf_dot5(wk[0], mi.x, mi.y, mi.z, mi.w, hi.x, bk[0]);
+    d.w = srf_dot5(wk[0], mi.y, mi.z, mi.w, hi.x, hi.y, bk[0]);
+    if (MOMENTS) {
+      s1[0] += (double)((d.x + d.y) + (d.z + d.w));
+      s2[0] += (double)fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+      if (q == 0) {
+        a.mom[(row * D + 0) * 5 + 2] = (double)d.x;
+        a.mom[(row * D + 0) * 5 + 3] = (double)d.y;
+      }
+      if (q == n4 - 1) a.mom[(row * D + 0) * 5 + 4] = (double)d.w;
+    } else {
+      d.x = fmaf(d.x, ak[0], ck[0]);
+      d.y = fmaf(d.y, ak[0], ck[0]);
+      d.z = fmaf(d.z, ak[0], ck[0]);
+      d.w = fmaf(d.w, ak[0], ck[0]);
+    }
+    *reinterpret_cast<float4*>(bufB + 4 + 4 * q) = d;
+  }
+  __syncthreads();   // bufA (o) is dead from here on: it now hosts levels 1..D-1
+
+  // ---- step 3: levels 1..D-1 (stride 2); level k reads level k-1
+#pragma unroll
+  for (int k = 1; k < SRF_MAX_DEPTH; ++k) {
+    if (k < D) {
+      const int Lk = L >> k;
+      const float* src = (k == 1) ? bufB : (bufA + offA[k - 1]);
+      float* dst = bufA + offA[k];
+      if (tid < 4) {
+        dst[tid] = 0.f;
+        dst[4 + Lk + tid] = 0.f;
+      }
+      const int nq = Lk >> 2;
+      for (int q = tid; q < nq; q += 256) {
+        const float* p = src + 4 + 8 * q;   // in[2 * (4q)]
+        const float2 l2 = *reinterpret_cast<const float2*>(p - 2);
+        const float4 A = *reinterpret_cast<const float4*>(p);
+        const float4 B = *reinterpret_cast<const float4*>(p + 4);
+        const float r = p[8];
+        float4 d;
+        d.x = srf_dot5(wk[k], l2.x, l2.y, A.x, A.y, A.z, bk[k]);
+        d.y = srf_dot5(wk[k], A.x, A.y, A.z, A.w, B.x, bk[k]);
+        d.z = srf_dot5(wk[k], A.z, A.w, B.x, B.y, B.z, bk[k]);
+        d.w = srf_dot5(wk[k], B.x, B.y, B.z, B.w, r, bk[k]);
+        if (MOMENTS) {
+          s1[k] += (double)((d.x + d.y) + (d.z + d.w));
+          s2[k] += (double)fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+          if (q == 0) {
+            a.mom[(row * D + k) * 5 + 2] = (double)d.x;
+            a.mom[(row * D + k) * 5 + 3] = (double)d.y;
+          }
+          if (q == nq - 1) a.mom[(row * D + k) * 5 + 4] = (double)d.w;
+        } else {
+          d.x = fmaf(d.x, ak[k], ck[k]);
+          d.y = fmaf(d.y, ak[k], ck[k]);
+          d.z = fmaf(d.z, ak[k], ck[k]);
+          d.w = fmaf(d.w, ak[k], ck[k]);
+        }
+        *reinterpret_cast<float4*>(dst + 4 + 4 * q) = d;
+      }
+      __syncthreads();
+    }
+  }
+
+  if (MOMENTS) {
+    // ---- block reduction of the 2D row moments -> mom[row][k][0..1]
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+      if (k < D) {
+        const double r1 = srf_wave_sum(s1[k]), r2 = srf_wave_sum(s2[k]);
+        if (lane == 0) {
+          red[(w * SRF_MAX_DEPTH + k) * 2 + 0] = r1;
+          red[(w * SRF_MAX_DEPTH + k) * 2 + 1] = r2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * D) {
+      const int k = tid >> 1, j = tid & 1;
+      double t = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) t += red[(ww * SRF_MAX_DEPTH + k) * 2 + j];
+      a.mom[(row * D + k) * 5 + j] = t;
+    }
+  } else {
+    // ---- step 4: merged[j] = n_0[j] + (n_1[j>>1] + (... + n_{D-1}[j>>(D-1)]))   (reference order)
+    float4* mrow = reinterpret_cast<float4*>(a.merged + (size_t)row * L);
+    double ms = 0.0, mq = 0.0;
+    for (int q = tid; q < n4; q += 256) {
+      float t = 0.f;
+      bool have = false;
+#pragma unroll
+      for (int k = SRF_MAX_DEPTH - 1; k >= 2; --k) {
+        if (k < D) {
+          const float nk = bufA[offA[k] + 4 + ((4 * q) >> k)];
+          t = have ? nk + t : nk;
+          have = true;
+        }
+      }
+      float4 o = *reinterpret_cast<const float4*>(bufB + 4 + 4 * q);
+      if (D > 1) {
+        const float2 e = *reinterpret_cast<const float2*>(bufA + offA[1] + 4 + 2 * q);
+        const float ta = have ? e.x + t : e.x, tb = have ? e.y + t : e.y;
+        o.x += ta;
+        o.y += ta;
+        o.z += tb;
+        o.w += tb;
+      }
+      mrow[q] = o;
+      ms += (double)((o.x + o.y) + (o.z + o.w));
+      mq += (double)fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, o.w * o.w)));
+    }
+    if (a.out_sums) srf_block_stats_atomic<4>(ms, mq, srf_stat_slot(a.out_sums, g, row), red);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: per example, all levels' {mean, rstd} from the row moments (fp64)
+// ---------------------------------------------------------------------------------------------
+struct PyrFinArgs {
+  const double* mom;   // [groups*C][D][5] {S1, S2, e0, e1, el}
+  const float* w[SRF_MAX_DEPTH];
+  const float* bias[SRF_MAX_DEPTH];
+  const float* gamma[SRF_MAX_DEPTH];
+  const float* beta[SRF_MAX_DEPTH];
+  float* lvl;          // [groups][D][2]
+  int C, L, D;
+};
+
+#define SRF_FIN_CPT 8   // channels per thread (C <= 256 * 8)
+__global__ __launch_bounds__(256) void srf_pyramid_finalize_kernel(PyrFinArgs a) {
+  __shared__ double red[16];
+  __shared__ float bc[2];
+  const long g = blockIdx.x;
+  const int tid = threadIdx.x, C = a.C, D = a.D;
+  double alpha[SRF_FIN_CPT], kap[SRF_FIN_CPT], g0[SRF_FIN_CPT], g1[SRF_FIN_CPT], gl[SRF_FIN_CPT];
+#pragma unroll
+  for (int i = 0; i < SRF_FIN_CPT; ++i) {
+    alpha[i] = 1.0;
+    kap[i] = g0[i] = g1[i] = gl[i] = 0.0;
+  }
+  for (int k = 0; k < D; ++k) {
+    const int Lk = a.L >> k;
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int i = 0; i < SRF_FIN_CPT; ++i) {
+      const int c = tid + 256 * i;
+      if (c < C) {
+        const double* m = a.mom + ((g * C + c) * D + k) * 5;
+        const double S1 = m[0], S2 = m[1], e0 = m[2], e1 = m[3], el = m[4];
+        s += alpha[i] * S1 + (Lk - 3) * kap[i] + g0[i] + g1[i] + gl[i];
+        q += alpha[i] * alpha[i] * S2 +
+             2.0 * alpha[i] * (kap[i] * (S1 - e0 - e1 - el) + g0[i] * e0 + g1[i] * e1 + gl[i] * el) +
+             (Lk - 3) * kap[i] * kap[i] + g0[i] * g0[i] + g1[i] * g1[i] + gl[i] * gl[i];
+      }
+    }
+    s = srf_wave_sum(s);
+    q = srf_wave_sum(q);
+    if ((tid & 63) == 0) {
+      red[(tid >> 6) * 2] = s;
+      red[(tid >> 6) * 2 + 1] = q;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double ts = 0.0, tq = 0.0;
+      for (int w = 0; w < 4; ++w) {
+        ts += red[2 * w];
+        tq += red[2 * w + 1];
+      }
+      const double n = (double)C * (double)Lk;
+      const double mean = ts / n;
+      double var = tq / n - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      bc[0] = (float)mean;
+      bc[1] = (float)(1.0 / sqrt(var + 1e-8));
+      a.lvl[(g * D + k) * 2 + 0] = bc[0];
+      a.lvl[(g * D + k) * 2 + 1] = bc[1];
+    }
+    __syncthreads();
+    const float mean_f = bc[0], rstd_f = bc[1];
+    if (k + 1 < D) {
+#pragma unroll
+      for (int i = 0; i < SRF_FIN_CPT; ++i) {
+        const int c = tid + 256 * i;
+        if (c < C) {
+          // exactly the fp32 coefficients pass 2 will use
+          const float af = a.gamma[k][c] * rstd_f;
+          const float bf = a.beta[k][c] - mean_f * af;
+          const double A = (double)af, B = (double)bf;
+          const float* ww = a.w[k + 1] + c * 5;
+          const double w0 = ww[0], w1 = ww[1], w2 = ww[2], w3 = ww[3], w4 = ww[4];
+          const double bs = (double)a.bias[k + 1][c];
+          const double sw = w0 + w1 + w2 + w3 + w4;
+          const double nk = bs + A * kap[i] * sw + B * sw;
+          const double n0 = bs + A * (w2 * g0[i] + w3 * g1[i] + w4 * kap[i]) + B * (w2 + w3 + w4);
+          const double n1 = bs + A * (w0 * g0[i] + w1 * g1[i] + (w2 + w3 + w4) * kap[i]) + B * sw;
+          const double nl = bs + A * ((w0 + w1 + w2) * kap[i] + w3 * gl[i]) + B * (w0 + w1 + w2 + w3);
+          kap[i] = nk;
+          g0[i] = n0;
+          g1[i] = n1;
+          gl[i] = nl;
+          alpha[i] *= A;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+static size_t pyr_lds_bytes(int L, int D) {
+  size_t sizeA = (size_t)L + 8, lv = 0;
+  for (int k = 1; k < D; ++k) lv += (size_t)(L >> k) + 8;
+  if (lv > sizeA) sizeA = lv;
+  sizeA = (sizeA + 3) & ~(size_t)3;
+  return sizeof(float) * ((size_t)L + 8 + sizeA) + sizeof(double) * (4 * SRF_MAX_DEPTH * 2 + 8);
+}
+
+extern "C" int srf_pyramid_supported(int C, int L, int D) {
+  if (D < 1 || D > SRF_MAX_DEPTH || C > 256 * SRF_FIN_CPT) return 0;
+  if (L % (4 << (D - 1)) != 0 || (L >> (D - 1)) < 8) return 0;
+  return pyr_lds_bytes(L, D) <= 160 * 1024 - 1024;
+}
+
+extern "C" size_t srf_pyramid_scratch_bytes(int groups, int C, int D) {
+  // moments [groups*C][D][5] fp64 | level statistics [groups][D][2] fp32
+  return sizeof(double) * (size_t)groups * C * D * 5 + sizeof(float) * (size_t)groups * D * 2 + 64;
+}
+
+static bool g_pyr_attr_set = false;
+
+extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_norm,
+                           const float* const* w, const float* const* bias, const float* const* gamma,
+                           const float* const* beta, int groups, int C, int L, int D, void* scratch,
+                           double* out_sums, void* stream) {
+  SRF_CHECK_ARG(y1 && merged && w && bias && gamma && beta && scratch, "srf_pyramid: null pointer");
+  SRF_CHECK_ARG(groups > 0 && C > 0 && L > 0, "srf_pyramid: bad sizes");
+  SRF_CHECK_ARG(srf_pyramid_supported(C, L, D), "srf_pyramid: unsupported shape C=%d L=%d D=%d", C, L, D);
+  SRF_CHECK_ARG(srf_aligned16(y1) && srf_aligned16(merged) && srf_aligned16(scratch),
+                "srf_pyramid: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const long rows = (long)groups * C;
+  SRF_CHECK_ARG(rows < (1L << 31), "srf_pyramid: too many rows");
+  double* mom = reinterpret_cast<double*>(scratch);
+  float* lvl = reinterpret_cast<float*>(mom + (size_t)rows * D * 5);
+  PyrArgs a;
+  PyrFinArgs f;
+  a.y1 = y1;
+  a.merged = merged;
+  a.in_norm = srf_norm_dev(in_norm);
+  a.in_inv_count = 1.0 / ((double)C * (double)L);
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+    const int kk = k < D ? k : 0;
+    SRF_CHECK_ARG(w[kk] && bias[kk] && gamma[kk] && beta[kk], "srf_pyramid: null level parameter %d", kk);
+    a.w[k] = f.w[k] = w[kk];
+    a.bias[k] = f.bias[k] = bias[kk];
+    a.gamma[k] = f.gamma[k] = gamma[kk];
+    a.beta[k] = f.beta[k] = beta[kk];
+  }
+  a.lvl = lvl;
+  a.mom = mom;
+  a.out_sums = out_sums;
+  a.C = C;
+  a.L = L;
+  a.D = D;
+  f.mom = mom;
+  f.lvl = lvl;
+  f.C = C;
+  f.L = L;
+  f.D = D;
+  const size_t ldsb = pyr_lds_bytes(L, D);
+  if (ldsb > 64 * 1024 && !g_pyr_attr_set) {
+    SRF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&srf_pyramid_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SRF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&srf_pyramid_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    g_pyr_attr_set = true;
+  }
+  hipLaunchKernelGGL(srf_pyramid_kernel<true>, dim3((unsigned)rows), dim3(256), ldsb, st, a);
+  SRF_CHECK_LAUNCH("pyramid_moments", st);
+  hipLaunchKernelGGL(srf_pyramid_finalize_kernel, dim3((unsigned)groups), dim3(256), 0, st, f);
+  SRF_CHECK_LAUNCH("pyramid_finalize", st);
+  hipLaunchKernelGGL(srf_pyramid_kernel<false>, dim3((unsigned)rows), dim3(256), ldsb, st, a);
+  SRF_CHECK_LAUNCH("pyramid_merge", st);
+  return SRF_OK;
+}

@@ -142,6 +142,25 @@ def merge(levels, sums, gammas, betas, out_sums=None):
     return y
 
 
+def pyramid(y1, in_sums, in_gamma, in_beta, in_prelu, weights, biases, gammas, betas, out_sums=None):
+    """Fused depthwise pyramid + merge: y1 [groups,C,L] -> merged [groups,C,L] (srf_pyramid)."""
+    dev = _chk(y1, in_sums, in_gamma, in_beta, in_prelu, *weights, *biases, *gammas, *betas, out_sums)
+    groups, Cc, L = y1.shape
+    D = len(weights)
+    lib = _lib.load()
+    if not lib.srf_pyramid_supported(Cc, L, D):
+        raise _lib.SrfError("srf_pyramid: unsupported shape C=%d L=%d D=%d" % (Cc, L, D))
+    merged = torch.empty_like(y1)
+    scratch = torch.empty(lib.srf_pyramid_scratch_bytes(groups, Cc, D), dtype=torch.uint8, device=dev)
+    arr = lambda ts: (C.c_void_p * D)(*[t.data_ptr() for t in ts])
+    n = _lib.make_norm(in_sums, in_gamma, in_beta, in_prelu)
+    rc = lib.srf_pyramid(_lib.ptr(y1), _lib.ptr(merged), C.byref(n), arr(weights), arr(biases), arr(gammas),
+                         arr(betas), groups, Cc, L, D, _lib.ptr(scratch), _lib.ptr(out_sums),
+                         _lib.current_stream(dev))
+    _lib.check(rc, "srf_pyramid")
+    return merged
+
+
 def decoder(v, weight, T):
     """v [Bt,Ci,L], weight [Ci,Co,K] -> [Bt,Co,T]  (improved_sudormrf.py:272-279,300,316-318)."""
     dev = _chk(v, weight)

@@ -32,6 +32,16 @@ def flops_per_example(variant, B, C, U, D, K, N, S, T, G=1):
     return 2.0 * mac
 
 
+def pyramid_fused(C, L, D):
+    """Mirror of srf_pyramid_supported() (csrc/srf_pyramid.hip)."""
+    if D < 1 or D > 8 or C > 2048:
+        return False
+    if L % (4 << (D - 1)) or (L >> (D - 1)) < 8:
+        return False
+    size_a = max(L + 8, sum((L >> k) + 8 for k in range(1, D)))
+    return 4 * (L + 8 + ((size_a + 3) & ~3)) + 8 * 72 <= 160 * 1024 - 1024
+
+
 def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
     """(family, algorithmic_bytes, flops) for every kernel launch of one srf_forward, in launch order
     (mirrors srf_api.hip).  Bytes = tensors each kernel must read + write once, fp32."""
@@ -51,11 +61,17 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
             out.append(("tac", f * Bt * B * L * 2, 2.0 * Bt * L * (2 * G * n * h + h * h + n * h + G * n * h)))
             out.append(("gln_apply_add", f * Bt * B * L * 3, 3.0 * Bt * B * L))
         out.append(pw(nB, nC, Bg))
-        for k in range(D):
-            lin = L if k == 0 else L >> (k - 1)
-            lout = L >> k
-            out.append(("dwconv5", f * Bg * nC * (lin + lout), 2.0 * 5 * Bg * nC * lout))
-        out.append(("merge", f * Bg * nC * (sum(L >> k for k in range(D)) + L), 2.0 * D * Bg * nC * L))
+        dw_flops = 2.0 * 5 * Bg * nC * sum(L >> k for k in range(D))
+        if pyramid_fused(nC, L, D):
+            out.append(("pyramid_moments", f * Bg * nC * L, dw_flops))
+            out.append(("pyramid_finalize", 8.0 * Bg * nC * D * 5, 0.0))
+            out.append(("pyramid_merge", f * Bg * nC * L * 2, dw_flops + 2.0 * D * Bg * nC * L))
+        else:
+            for k in range(D):
+                lin = L if k == 0 else L >> (k - 1)
+                lout = L >> k
+                out.append(("dwconv5", f * Bg * nC * (lin + lout), 2.0 * 5 * Bg * nC * lout))
+            out.append(("merge", f * Bg * nC * (sum(L >> k for k in range(D)) + L), 2.0 * D * Bg * nC * L))
         out.append(pw(nC, nB, Bg, extra_in=nB))
     out.append(pw(B, SA * N, Bt, extra_in=N))
     out.append(("transpose", f * 2 * SA * N * SA * K, 0.0))

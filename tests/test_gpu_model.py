@@ -87,6 +87,21 @@ def test_intermediates_match_oracle(manifest, name):
     assert np.abs(masked - tr["masked"]).max() < 1e-4
 
 
+@pytest.mark.parametrize("name", ["cfg1_improved_u8", "cfg3_groupcomm_u8"])
+def test_unfused_pyramid_agrees(manifest, name):
+    """debug flag 16 = per-level depthwise/merge kernels instead of the fused pyramid."""
+    from sudo_rm_rf_amd import ops
+    cfg, sd, wav, gold = load_case(manifest, name)
+    model = build(cfg, sd)
+    try:
+        ops.set_debug_flags(16)
+        with torch.no_grad():
+            out = model(torch.from_numpy(wav).to(DEV)).cpu().numpy()
+    finally:
+        ops.set_debug_flags(0)
+    assert np.abs(out - gold["out"]).max() <= TOL
+
+
 def test_batch32_examples_are_independent_at_full_size(manifest):
     """BASELINE cfg 2 at its full size (batch 32): every example must reproduce the golden output of
     the same waveform run on its own -- nothing on the path mixes examples."""

@@ -205,6 +205,37 @@ def test_merge(mode, Bt, C, L, D):
     check_sums(osums, u, "merge sums")
 
 
+@pytest.mark.parametrize("Bt,C,L,D", [(2, 64, 3200, 5), (2, 16, 6400, 6), (1, 8, 128, 4), (3, 20, 256, 2),
+                                      (2, 4, 64, 1), (1, 5, 12800, 6), (2, 3, 64, 3)])
+def test_fused_pyramid(Bt, C, L, D):
+    """srf_pyramid (two passes, statistics through the linearity of conv o GlobLN) == the reference's
+    chain DilatedConvNorm x D + upsample/add (improved_sudormrf.py:206-216)."""
+    from sudo_rm_rf_amd import ops
+    y1 = rnd(Bt, C, L, seed=100, scale=1.4, shift=0.2)
+    g_in, b_in = rnd(C, seed=101, scale=0.3, shift=1.0), rnd(C, seed=102, scale=0.3)
+    slope = torch.tensor([0.23], dtype=torch.float64)
+    W = [rnd(C, 1, 5, seed=110 + k, scale=0.5) for k in range(D)]
+    Bi = [rnd(C, seed=120 + k, scale=0.2) for k in range(D)]
+    Ga = [rnd(C, seed=130 + k, scale=0.3, shift=1.0) for k in range(D)]
+    Be = [rnd(C, seed=140 + k, scale=0.3) for k in range(D)]
+    cur = gln64(y1, g_in, b_in)
+    cur = torch.where(cur >= 0, cur, slope * cur)
+    outs = []
+    for k in range(D):
+        d = F.conv1d(cur, W[k], Bi[k], stride=1 if k == 0 else 2, padding=2, groups=C)
+        cur = gln64(d, Ga[k], Be[k])
+        outs.append(cur)
+    u = outs[-1]
+    for k in range(D - 2, -1, -1):
+        u = outs[k] + u.repeat_interleave(2, dim=-1)
+    osums = ops.new_sums(Bt, DEV)
+    got = ops.pyramid(dev32(y1), sums64(y1).to(DEV), dev32(g_in), dev32(b_in), dev32(slope),
+                      [dev32(t) for t in W], [dev32(t) for t in Bi], [dev32(t) for t in Ga],
+                      [dev32(t) for t in Be], out_sums=osums)
+    check(got, u, 5e-5, "fused pyramid")
+    check_sums(osums, u, "fused pyramid sums")
+
+
 @pytest.mark.parametrize("Bt,Ci,Co,K,L,T", [(2, 64, 2, 21, 100, 1000), (1, 96, 2, 21, 64, 633),
                                             (2, 32, 4, 11, 40, 200), (1, 1024, 2, 21, 320, 3200)])
 def test_decoder(mode, Bt, Ci, Co, K, L, T):
