@@ -36,6 +36,7 @@ struct PyrArgs {
   const float* lvl;     // [groups][D][2] {mean, rstd}    (pass 2)
   double* mom;          // [rows][D][5]                   (pass 1)
   double* out_sums;     // merged statistics              (pass 2)
+  long rows;
   int C, L, D;
 };
 
@@ -49,10 +50,20 @@ template <bool MOMENTS>
 __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int L = a.L, D = a.D, C = a.C;
-  const long row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n4 = L >> 2;
+  // Persistent blocks: each block walks rows blockIdx.x, +gridDim.x, ... and keeps the NEXT row's first
+  // 1024 float4 groups in flight (registers) while it works on the current row, so the global-load
+  // latency of a row is hidden behind the previous row's on-chip phases.
+  float4 pre[4];
+  {
+    const float4* y0 = reinterpret_cast<const float4*>(a.y1 + (size_t)blockIdx.x * L);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[i] = y0[min(tid + 256 * i, n4 - 1)];
+  }
+  for (long row = blockIdx.x; row < a.rows; row += gridDim.x) {
   const int c = (int)(row % C);
   const long g = row / C;
-  const int tid = threadIdx.x;
 
   // LDS carve: bufB = level 0 (L+8 floats), bufA = proj output o, later levels 1..D-1 back to back
   float* bufB = lds;
@@ -78,24 +89,27 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
   }
   const bool act = a.in_norm.prelu != nullptr;
   const float slope = act ? a.in_norm.prelu[0] : 1.f;
-  float wk[SRF_MAX_DEPTH][5], bk[SRF_MAX_DEPTH], ak[SRF_MAX_DEPTH], ck[SRF_MAX_DEPTH];
+  // per-level coefficients are fetched right where a level is computed (wave-uniform -> scalar loads
+  // with short live ranges; holding all D levels at once cost ~190 VGPRs and 2/3 of the occupancy)
+  struct Lv {
+    float w[5], b, a, c;
+  };
+  auto level_coef = [&](int k) {
+    Lv lv;
 #pragma unroll
-  for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
-    if (k < D) {
-#pragma unroll
-      for (int t = 0; t < 5; ++t) wk[k][t] = a.w[k][c * 5 + t];
-      bk[k] = a.bias[k][c];
-      if (MOMENTS) {
-        ak[k] = 1.f;   // raw cascade: identity "norm", no bias below level 0
-        ck[k] = 0.f;
-        if (k > 0) bk[k] = 0.f;
-      } else {
-        const float m = a.lvl[(g * D + k) * 2 + 0], r = a.lvl[(g * D + k) * 2 + 1];
-        ak[k] = a.gamma[k][c] * r;
-        ck[k] = a.beta[k][c] - m * ak[k];
-      }
+    for (int t = 0; t < 5; ++t) lv.w[t] = a.w[k][c * 5 + t];
+    lv.b = a.bias[k][c];
+    if (MOMENTS) {
+      lv.a = 1.f;   // raw cascade: identity "norm", no bias below level 0
+      lv.c = 0.f;
+      if (k > 0) lv.b = 0.f;
+    } else {
+      const float m = a.lvl[(g * D + k) * 2 + 0], r = a.lvl[(g * D + k) * 2 + 1];
+      lv.a = a.gamma[k][c] * r;
+      lv.c = a.beta[k][c] - m * lv.a;
     }
-  }
+    return lv;
+  };
 
   // ---- zero pads of every buffer (4 floats each side)
   if (tid < 4) {
@@ -105,11 +119,10 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
     bufA[4 + L + tid] = 0.f;
   }
 
-  // ---- step 1: o = PReLU(GlobLN(y1)) -> bufA
+  // ---- step 1: o = PReLU(GlobLN(y1)) -> bufA.  Groups 0..1023 come from the prefetch registers,
+  // longer rows load their remaining groups here (4 loads in flight per thread).
   const float4* yrow = reinterpret_cast<const float4*>(a.y1 + (size_t)row * L);
-  const int n4 = L >> 2;
-  for (int q = tid; q < n4; q += 256) {
-    float4 v = yrow[q];
+  auto put_o = [&](float4 v, int q) {
     v.x = fmaf(v.x, sc, sh);
     v.y = fmaf(v.y, sc, sh);
     v.z = fmaf(v.z, sc, sh);
@@ -120,7 +133,22 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
       v.z = srf_prelu(v.z, slope);
       v.w = srf_prelu(v.w, slope);
     }
-    *reinterpret_cast<float4*>(bufA + 4 + 4 * q) = v;
+    if (q < n4) *reinterpret_cast<float4*>(bufA + 4 + 4 * q) = v;
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) put_o(pre[i], tid + 256 * i);
+  for (int base = 1024; base < n4; base += 1024) {
+    float4 t4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t4[i] = yrow[min(base + tid + 256 * i, n4 - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put_o(t4[i], base + tid + 256 * i);
+  }
+  {  // prefetch the next row of this block (clamped to a valid row: surplus loads are harmless)
+    const long nrow = (row + gridDim.x < a.rows) ? row + gridDim.x : row;
+    const float4* yn = reinterpret_cast<const float4*>(a.y1 + (size_t)nrow * L);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[i] = yn[min(tid + 256 * i, n4 - 1)];
   }
   __syncthreads();
 
@@ -129,16 +157,17 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
   for (int k = 0; k < SRF_MAX_DEPTH; ++k) s1[k] = s2[k] = 0.0;
 
   // ---- step 2: level 0 (stride 1) from bufA -> bufB
+  const Lv l0 = level_coef(0);
   for (int q = tid; q < n4; q += 256) {
     const float* p = bufA + 4 + 4 * q;   // o[4q]
     const float2 lo = *reinterpret_cast<const float2*>(p - 2);
     const float4 mi = *reinterpret_cast<const float4*>(p);
     const float2 hi = *reinterpret_cast<const float2*>(p + 4);
     float4 d;
-    d.x = srf_dot5(wk[0], lo.x, lo.y, mi.x, mi.y, mi.z, bk[0]);
-    d.y = srf_dot5(wk[0], lo.y, mi.x, mi.y, mi.z, mi.w, bk[0]);
-    d.z = srf_dot5(wk[0], mi.x, mi.y, mi.z, mi.w, hi.x, bk[0]);
-    d.w = srf_dot5(wk[0], mi.y, mi.z, mi.w, hi.x, hi.y, bk[0]);
+    d.x = srf_dot5(l0.w, lo.x, lo.y, mi.x, mi.y, mi.z, l0.b);
+    d.y = srf_dot5(l0.w, lo.y, mi.x, mi.y, mi.z, mi.w, l0.b);
+    d.z = srf_dot5(l0.w, mi.x, mi.y, mi.z, mi.w, hi.x, l0.b);
+    d.w = srf_dot5(l0.w, mi.y, mi.z, mi.w, hi.x, hi.y, l0.b);
     if (MOMENTS) {
       s1[0] += (double)((d.x + d.y) + (d.z + d.w));
       s2[0] += (double)fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
@@ -148,10 +177,10 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
       }
       if (q == n4 - 1) a.mom[(row * D + 0) * 5 + 4] = (double)d.w;
     } else {
-      d.x = fmaf(d.x, ak[0], ck[0]);
-      d.y = fmaf(d.y, ak[0], ck[0]);
-      d.z = fmaf(d.z, ak[0], ck[0]);
-      d.w = fmaf(d.w, ak[0], ck[0]);
+      d.x = fmaf(d.x, l0.a, l0.c);
+      d.y = fmaf(d.y, l0.a, l0.c);
+      d.z = fmaf(d.z, l0.a, l0.c);
+      d.w = fmaf(d.w, l0.a, l0.c);
     }
     *reinterpret_cast<float4*>(bufB + 4 + 4 * q) = d;
   }
@@ -162,6 +191,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
   for (int k = 1; k < SRF_MAX_DEPTH; ++k) {
     if (k < D) {
       const int Lk = L >> k;
+      const Lv lk = level_coef(k);
       const float* src = (k == 1) ? bufB : (bufA + offA[k - 1]);
       float* dst = bufA + offA[k];
       if (tid < 4) {
@@ -176,10 +206,10 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
         const float4 B = *reinterpret_cast<const float4*>(p + 4);
         const float r = p[8];
         float4 d;
-        d.x = srf_dot5(wk[k], l2.x, l2.y, A.x, A.y, A.z, bk[k]);
-        d.y = srf_dot5(wk[k], A.x, A.y, A.z, A.w, B.x, bk[k]);
-        d.z = srf_dot5(wk[k], A.z, A.w, B.x, B.y, B.z, bk[k]);
-        d.w = srf_dot5(wk[k], B.x, B.y, B.z, B.w, r, bk[k]);
+        d.x = srf_dot5(lk.w, l2.x, l2.y, A.x, A.y, A.z, lk.b);
+        d.y = srf_dot5(lk.w, A.x, A.y, A.z, A.w, B.x, lk.b);
+        d.z = srf_dot5(lk.w, A.z, A.w, B.x, B.y, B.z, lk.b);
+        d.w = srf_dot5(lk.w, B.x, B.y, B.z, B.w, r, lk.b);
         if (MOMENTS) {
           s1[k] += (double)((d.x + d.y) + (d.z + d.w));
           s2[k] += (double)fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
@@ -189,10 +219,10 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
           }
           if (q == nq - 1) a.mom[(row * D + k) * 5 + 4] = (double)d.w;
         } else {
-          d.x = fmaf(d.x, ak[k], ck[k]);
-          d.y = fmaf(d.y, ak[k], ck[k]);
-          d.z = fmaf(d.z, ak[k], ck[k]);
-          d.w = fmaf(d.w, ak[k], ck[k]);
+          d.x = fmaf(d.x, lk.a, lk.c);
+          d.y = fmaf(d.y, lk.a, lk.c);
+          d.z = fmaf(d.z, lk.a, lk.c);
+          d.w = fmaf(d.w, lk.a, lk.c);
         }
         *reinterpret_cast<float4*>(dst + 4 + 4 * q) = d;
       }
@@ -251,6 +281,8 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
     }
     if (a.out_sums) srf_block_stats_atomic<4>(ms, mq, srf_stat_slot(a.out_sums, g, row), red);
   }
+  __syncthreads();   // the next row re-uses every LDS buffer
+  }  // row loop
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -401,6 +433,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
   a.lvl = lvl;
   a.mom = mom;
   a.out_sums = out_sums;
+  a.rows = rows;
   a.C = C;
   a.L = L;
   a.D = D;
@@ -417,11 +450,30 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     g_pyr_attr_set = true;
   }
-  hipLaunchKernelGGL(srf_pyramid_kernel<true>, dim3((unsigned)rows), dim3(256), ldsb, st, a);
+  // persistent grids: exactly as many blocks as are co-resident (registers + LDS), rows strided
+  auto resident_blocks = [&](const void* fn) -> long {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, ldsb) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    const long n = (long)per_cu * cus;
+    return n < rows ? n : rows;
+  };
+  static long cached_n1 = 0, cached_n2 = 0;
+  static size_t cached_lds = 0;
+  if (cached_lds != ldsb) {
+    cached_n1 = resident_blocks(reinterpret_cast<const void*>(&srf_pyramid_kernel<true>));
+    cached_n2 = resident_blocks(reinterpret_cast<const void*>(&srf_pyramid_kernel<false>));
+    cached_lds = ldsb;
+  }
+  const long nblk1 = cached_n1 < rows ? cached_n1 : rows, nblk2 = cached_n2 < rows ? cached_n2 : rows;
+  hipLaunchKernelGGL(srf_pyramid_kernel<true>, dim3((unsigned)nblk1), dim3(256), ldsb, st, a);
   SRF_CHECK_LAUNCH("pyramid_moments", st);
   hipLaunchKernelGGL(srf_pyramid_finalize_kernel, dim3((unsigned)groups), dim3(256), 0, st, f);
   SRF_CHECK_LAUNCH("pyramid_finalize", st);
-  hipLaunchKernelGGL(srf_pyramid_kernel<false>, dim3((unsigned)rows), dim3(256), ldsb, st, a);
+  hipLaunchKernelGGL(srf_pyramid_kernel<false>, dim3((unsigned)nblk2), dim3(256), ldsb, st, a);
   SRF_CHECK_LAUNCH("pyramid_merge", st);
   return SRF_OK;
 }
