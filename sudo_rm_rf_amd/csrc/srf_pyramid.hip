@@ -55,13 +55,21 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
   // Persistent blocks: each block walks rows blockIdx.x, +gridDim.x, ... and keeps the NEXT row's first
   // 1024 float4 groups in flight (registers) while it works on the current row, so the global-load
   // latency of a row is hidden behind the previous row's on-chip phases.
+  // Each block owns a CONTIGUOUS chunk of rows (so the example index, hence the proj GlobLN statistics,
+  // rarely changes inside a block: the fp64 finalisation is redone only when it does).
+  const long rows_per_block = (a.rows + gridDim.x - 1) / gridDim.x;
+  const long row_beg = (long)blockIdx.x * rows_per_block;
+  const long row_end = min(row_beg + rows_per_block, a.rows);
+  if (row_beg >= row_end) return;
   float4 pre[4];
   {
-    const float4* y0 = reinterpret_cast<const float4*>(a.y1 + (size_t)blockIdx.x * L);
+    const float4* y0 = reinterpret_cast<const float4*>(a.y1 + (size_t)row_beg * L);
 #pragma unroll
     for (int i = 0; i < 4; ++i) pre[i] = y0[min(tid + 256 * i, n4 - 1)];
   }
-  for (long row = blockIdx.x; row < a.rows; row += gridDim.x) {
+  long cur_g = -1;
+  float in_mean = 0.f, in_rstd = 1.f;
+  for (long row = row_beg; row < row_end; ++row) {
   const int c = (int)(row % C);
   const long g = row / C;
 
@@ -80,12 +88,14 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
   double* red = reinterpret_cast<double*>(lds + (L + 8) + ((sizeA + 3) & ~3));   // 8-B aligned: sizes % 4 == 0
 
   // ---- per-row coefficients
-  float mean, rstd;
   float sc = 1.f, sh = 0.f;
   if (a.in_norm.sums) {
-    srf_finalize_stats(a.in_norm.sums, g, a.in_inv_count, mean, rstd);
-    sc = a.in_norm.gamma[c] * rstd;
-    sh = a.in_norm.beta[c] - mean * sc;
+    if (g != cur_g) {   // block-uniform branch
+      srf_finalize_stats(a.in_norm.sums, g, a.in_inv_count, in_mean, in_rstd);
+      cur_g = g;
+    }
+    sc = a.in_norm.gamma[c] * in_rstd;
+    sh = a.in_norm.beta[c] - in_mean * sc;
   }
   const bool act = a.in_norm.prelu != nullptr;
   const float slope = act ? a.in_norm.prelu[0] : 1.f;
@@ -145,16 +155,17 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
     for (int i = 0; i < 4; ++i) put_o(t4[i], base + tid + 256 * i);
   }
   {  // prefetch the next row of this block (clamped to a valid row: surplus loads are harmless)
-    const long nrow = (row + gridDim.x < a.rows) ? row + gridDim.x : row;
+    const long nrow = (row + 1 < row_end) ? row + 1 : row;
     const float4* yn = reinterpret_cast<const float4*>(a.y1 + (size_t)nrow * L);
 #pragma unroll
     for (int i = 0; i < 4; ++i) pre[i] = yn[min(tid + 256 * i, n4 - 1)];
   }
   __syncthreads();
 
-  double s1[SRF_MAX_DEPTH], s2[SRF_MAX_DEPTH];
+  // row moments: <= 16 values per thread and level in fp32, fp32 wave reduction, fp64 only across waves
+  float s1[SRF_MAX_DEPTH], s2[SRF_MAX_DEPTH];
 #pragma unroll
-  for (int k = 0; k < SRF_MAX_DEPTH; ++k) s1[k] = s2[k] = 0.0;
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) s1[k] = s2[k] = 0.f;
 
   // ---- step 2: level 0 (stride 1) from bufA -> bufB
   const Lv l0 = level_coef(0);
@@ -169,8 +180,8 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
     d.z = srf_dot5(l0.w, mi.x, mi.y, mi.z, mi.w, hi.x, l0.b);
     d.w = srf_dot5(l0.w, mi.y, mi.z, mi.w, hi.x, hi.y, l0.b);
     if (MOMENTS) {
-      s1[0] += (double)((d.x + d.y) + (d.z + d.w));
-      s2[0] += (double)fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+      s1[0] += (d.x + d.y) + (d.z + d.w);
+      s2[0] += fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
       if (q == 0) {
         a.mom[(row * D + 0) * 5 + 2] = (double)d.x;
         a.mom[(row * D + 0) * 5 + 3] = (double)d.y;
@@ -211,8 +222,8 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
         d.z = srf_dot5(lk.w, A.z, A.w, B.x, B.y, B.z, lk.b);
         d.w = srf_dot5(lk.w, B.x, B.y, B.z, B.w, r, lk.b);
         if (MOMENTS) {
-          s1[k] += (double)((d.x + d.y) + (d.z + d.w));
-          s2[k] += (double)fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+          s1[k] += (d.x + d.y) + (d.z + d.w);
+          s2[k] += fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
           if (q == 0) {
             a.mom[(row * D + k) * 5 + 2] = (double)d.x;
             a.mom[(row * D + k) * 5 + 3] = (double)d.y;
@@ -236,10 +247,15 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
 #pragma unroll
     for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
       if (k < D) {
-        const double r1 = srf_wave_sum(s1[k]), r2 = srf_wave_sum(s2[k]);
+        float r1 = s1[k], r2 = s2[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          r1 += __shfl_xor(r1, o, 64);
+          r2 += __shfl_xor(r2, o, 64);
+        }
         if (lane == 0) {
-          red[(w * SRF_MAX_DEPTH + k) * 2 + 0] = r1;
-          red[(w * SRF_MAX_DEPTH + k) * 2 + 1] = r2;
+          red[(w * SRF_MAX_DEPTH + k) * 2 + 0] = (double)r1;
+          red[(w * SRF_MAX_DEPTH + k) * 2 + 1] = (double)r2;
         }
       }
     }
