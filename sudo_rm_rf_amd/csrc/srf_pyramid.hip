@@ -34,6 +34,7 @@ struct PyrArgs {
   const float* gamma[SRF_MAX_DEPTH];
   const float* beta[SRF_MAX_DEPTH];
   const float* lvl;     // [groups][D][2] {mean, rstd}    (pass 2)
+  const float* in_mr;   // [groups][2] {mean, rstd} of in_norm, pre-finalised (tiled kernels)
   double* mom;          // [rows][D][5]                   (pass 1)
   double* out_sums;     // merged statistics              (pass 2)
   long rows;
@@ -302,6 +303,258 @@ __global__ __launch_bounds__(256) void srf_pyramid_kernel(PyrArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tiled variant (preferred): one WAVEFRONT per (row, time tile of TS level-0 outputs), no block
+// barriers at all.  The block-per-row kernel above is latency-bound (7 barriers per row, <= 16 waves
+// per CU: measured 157 + 188 us per U-ConvBlock, no better than the per-level kernels); here every
+// wave owns a private ~6 KB LDS slice, recomputes a halo of h_k = 2 h_{k+1} + 4 positions per level
+// (h_{D-1} = 0) instead of synchronising with its neighbours, and ~20+ independent waves per CU keep
+// HBM busy.  Row moments of pass 1 are accumulated with fp64 atomics over the few tiles of a row.
+// ---------------------------------------------------------------------------------------------
+struct PyrTile {
+  int TS, tiles;          // level-0 outputs per tile, tiles per row
+  int h[SRF_MAX_DEPTH];   // halo per level (level-k units)
+  int wave_floats;        // LDS floats per wave
+  long tasks;             // rows * tiles
+};
+
+template <bool MOMENTS>
+__global__ __launch_bounds__(256) void srf_pyramid_tile_kernel(PyrArgs a, PyrTile t) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = a.L, D = a.D, C = a.C;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long task = (long)blockIdx.x * 4 + wave;
+  if (task >= t.tasks) return;   // wave-uniform; no block-level synchronisation anywhere below
+  const long row = task / t.tiles;
+  const int tile = (int)(task - row * t.tiles);
+  const int c = (int)(row % C);
+  const long g = row / C;
+  const int j0 = tile * t.TS;
+
+  float* bufB = lds + wave * t.wave_floats;        // level 0
+  const int len0 = t.TS + 2 * t.h[0] + 8;          // o / level-0 buffer length incl. 4 + 4 pad
+  float* bufA = bufB + len0;                       // o, later levels 1..D-1
+  int offA[SRF_MAX_DEPTH];
+  {
+    int o = 0;
+    offA[0] = 0;
+#pragma unroll
+    for (int k = 1; k < SRF_MAX_DEPTH; ++k) {
+      offA[k] = o;
+      if (k < D) o += (t.TS >> k) + 2 * t.h[k] + 8;
+    }
+  }
+
+  float sc = 1.f, sh = 0.f;
+  if (a.in_norm.sums) {   // statistics pre-finalised once per example by srf_stats_finalize_kernel
+    const float mean = a.in_mr[2 * g], rstd = a.in_mr[2 * g + 1];
+    sc = a.in_norm.gamma[c] * rstd;
+    sh = a.in_norm.beta[c] - mean * sc;
+  }
+  const bool act = a.in_norm.prelu != nullptr;
+  const float slope = act ? a.in_norm.prelu[0] : 1.f;
+  struct Lv {
+    float w[5], b, a, c;
+  };
+  auto level_coef = [&](int k) {
+    Lv lv;
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt) lv.w[tt] = a.w[k][c * 5 + tt];
+    lv.b = a.bias[k][c];
+    if (MOMENTS) {
+      lv.a = 1.f;
+      lv.c = 0.f;
+      if (k > 0) lv.b = 0.f;
+    } else {
+      const float m = a.lvl[(g * D + k) * 2 + 0], r = a.lvl[(g * D + k) * 2 + 1];
+      lv.a = a.gamma[k][c] * r;
+      lv.c = a.beta[k][c] - m * lv.a;
+    }
+    return lv;
+  };
+  auto wave_sync = [&]() {   // LDS ops of one wave execute in order; this only pins the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // ---- step 1: o on positions [lo0 - 4, lo0 + TS + 2 h0 + 4)  (zero outside the row)
+  const int lo0 = j0 - t.h[0];
+  const float4* yrow = reinterpret_cast<const float4*>(a.y1 + (size_t)row * L);
+  const int n4 = L >> 2;
+  for (int q = lane; q < (len0 >> 2); q += 64) {
+    const int p4 = ((lo0 - 4) >> 2) + q;   // float4 group index in the row (may be out of range)
+    const bool ok = p4 >= 0 && p4 < n4;
+    float4 v = yrow[min(max(p4, 0), n4 - 1)];
+    v.x = fmaf(v.x, sc, sh);
+    v.y = fmaf(v.y, sc, sh);
+    v.z = fmaf(v.z, sc, sh);
+    v.w = fmaf(v.w, sc, sh);
+    if (act) {
+      v.x = srf_prelu(v.x, slope);
+      v.y = srf_prelu(v.y, slope);
+      v.z = srf_prelu(v.z, slope);
+      v.w = srf_prelu(v.w, slope);
+    }
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(bufA + 4 * q) = v;
+  }
+  wave_sync();
+
+  float s1[SRF_MAX_DEPTH], s2[SRF_MAX_DEPTH];
+#pragma unroll
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) s1[k] = s2[k] = 0.f;
+
+  // ---- step 2: level 0 on [lo0, lo0 + TS + 2 h0)
+  {
+    const Lv l0 = level_coef(0);
+    const int nq = (t.TS + 2 * t.h[0]) >> 2;
+    for (int q = lane; q < nq; q += 64) {
+      const float* p = bufA + 4 + 4 * q;
+      const float2 lo = *reinterpret_cast<const float2*>(p - 2);
+      const float4 mi = *reinterpret_cast<const float4*>(p);
+      const float2 hi = *reinterpret_cast<const float2*>(p + 4);
+      float4 d;
+      d.x = srf_dot5(l0.w, lo.x, lo.y, mi.x, mi.y, mi.z, l0.b);
+      d.y = srf_dot5(l0.w, lo.y, mi.x, mi.y, mi.z, mi.w, l0.b);
+      d.z = srf_dot5(l0.w, mi.x, mi.y, mi.z, mi.w, hi.x, l0.b);
+      d.w = srf_dot5(l0.w, mi.y, mi.z, mi.w, hi.x, hi.y, l0.b);
+      const int pos = lo0 + 4 * q;
+      if (MOMENTS) {
+        if (pos >= j0 && pos < j0 + t.TS) {   // own range only (halo belongs to the neighbours)
+          s1[0] += (d.x + d.y) + (d.z + d.w);
+          s2[0] += fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+          if (pos == 0) {
+            a.mom[(row * D + 0) * 5 + 2] = (double)d.x;
+            a.mom[(row * D + 0) * 5 + 3] = (double)d.y;
+          }
+          if (pos == L - 4) a.mom[(row * D + 0) * 5 + 4] = (double)d.w;
+        }
+      } else {
+        d.x = fmaf(d.x, l0.a, l0.c);
+        d.y = fmaf(d.y, l0.a, l0.c);
+        d.z = fmaf(d.z, l0.a, l0.c);
+        d.w = fmaf(d.w, l0.a, l0.c);
+      }
+      if (pos < 0 || pos >= L) d = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding of the next conv
+      *reinterpret_cast<float4*>(bufB + 4 + 4 * q) = d;
+    }
+  }
+  wave_sync();
+
+  // ---- step 3: levels 1..D-1
+#pragma unroll
+  for (int k = 1; k < SRF_MAX_DEPTH; ++k) {
+    if (k < D) {
+      const int Lk = L >> k;
+      const Lv lk = level_coef(k);
+      const float* src = (k == 1) ? bufB : (bufA + offA[k - 1]);
+      float* dst = bufA + offA[k];
+      const int own_lo = j0 >> k, own_len = t.TS >> k;
+      const int lo = own_lo - t.h[k];
+      const int nq = (own_len + 2 * t.h[k]) >> 2;
+      for (int q = lane; q < nq; q += 64) {
+        const float* p = src + 8 + 8 * q;   // input position 2 * (lo + 4q)
+        const float2 l2 = *reinterpret_cast<const float2*>(p - 2);
+        const float4 A = *reinterpret_cast<const float4*>(p);
+        const float4 B = *reinterpret_cast<const float4*>(p + 4);
+        const float r = p[8];
+        float4 d;
+        d.x = srf_dot5(lk.w, l2.x, l2.y, A.x, A.y, A.z, lk.b);
+        d.y = srf_dot5(lk.w, A.x, A.y, A.z, A.w, B.x, lk.b);
+        d.z = srf_dot5(lk.w, A.z, A.w, B.x, B.y, B.z, lk.b);
+        d.w = srf_dot5(lk.w, B.x, B.y, B.z, B.w, r, lk.b);
+        const int pos = lo + 4 * q;
+        if (MOMENTS) {
+          if (pos >= own_lo && pos < own_lo + own_len) {
+            s1[k] += (d.x + d.y) + (d.z + d.w);
+            s2[k] += fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+            if (pos == 0) {
+              a.mom[(row * D + k) * 5 + 2] = (double)d.x;
+              a.mom[(row * D + k) * 5 + 3] = (double)d.y;
+            }
+            if (pos == Lk - 4) a.mom[(row * D + k) * 5 + 4] = (double)d.w;
+          }
+        } else {
+          d.x = fmaf(d.x, lk.a, lk.c);
+          d.y = fmaf(d.y, lk.a, lk.c);
+          d.z = fmaf(d.z, lk.a, lk.c);
+          d.w = fmaf(d.w, lk.a, lk.c);
+        }
+        if (pos < 0 || pos >= Lk) d = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(dst + 4 + 4 * q) = d;
+      }
+      wave_sync();
+    }
+  }
+
+  if (MOMENTS) {
+#pragma unroll
+    for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+      if (k < D) {
+        float r1 = s1[k], r2 = s2[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          r1 += __shfl_xor(r1, o, 64);
+          r2 += __shfl_xor(r2, o, 64);
+        }
+        if (lane == 0) {
+          atomicAdd(&a.mom[(row * D + k) * 5 + 0], (double)r1);
+          atomicAdd(&a.mom[(row * D + k) * 5 + 1], (double)r2);
+        }
+      }
+    }
+  } else {
+    // ---- step 4: merge the tile's own level-0 range
+    float4* mrow = reinterpret_cast<float4*>(a.merged + (size_t)row * L + j0);
+    float ms = 0.f, mq = 0.f;
+    for (int q = lane; q < (t.TS >> 2); q += 64) {
+      float tt = 0.f;
+      bool have = false;
+#pragma unroll
+      for (int k = SRF_MAX_DEPTH - 1; k >= 2; --k) {
+        if (k < D) {
+          const float nk = bufA[offA[k] + 4 + t.h[k] + ((4 * q) >> k)];
+          tt = have ? nk + tt : nk;
+          have = true;
+        }
+      }
+      float4 o = *reinterpret_cast<const float4*>(bufB + 4 + t.h[0] + 4 * q);
+      if (D > 1) {
+        const float2 e = *reinterpret_cast<const float2*>(bufA + offA[1] + 4 + t.h[1] + 2 * q);
+        const float ta = have ? e.x + tt : e.x, tb = have ? e.y + tt : e.y;
+        o.x += ta;
+        o.y += ta;
+        o.z += tb;
+        o.w += tb;
+      }
+      mrow[q] = o;
+      ms += (o.x + o.y) + (o.z + o.w);
+      mq += fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, o.w * o.w)));
+    }
+    if (a.out_sums) {
+      const double ds = srf_wave_sum((double)ms), dq = srf_wave_sum((double)mq);
+      if (lane == 0) {
+        double* dst = srf_stat_slot(a.out_sums, g, task);
+        atomicAdd(dst, ds);
+        atomicAdd(dst + 1, dq);
+      }
+    }
+  }
+}
+
+// {sum,sumsq} buckets -> {mean, rstd} per group, once (one wavefront per group)
+__global__ __launch_bounds__(64) void srf_stats_finalize_kernel(const double* sums, double inv_count,
+                                                                float* out) {
+  float mean, rstd;
+  srf_finalize_stats(sums, blockIdx.x, inv_count, mean, rstd);
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = mean;
+    out[2 * blockIdx.x + 1] = rstd;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // finalize: per example, all levels' {mean, rstd} from the row moments (fp64)
 // ---------------------------------------------------------------------------------------------
 struct PyrFinArgs {
@@ -413,7 +666,40 @@ extern "C" int srf_pyramid_supported(int C, int L, int D) {
 
 extern "C" size_t srf_pyramid_scratch_bytes(int groups, int C, int D) {
   // moments [groups*C][D][5] fp64 | level statistics [groups][D][2] fp32
-  return sizeof(double) * (size_t)groups * C * D * 5 + sizeof(float) * (size_t)groups * D * 2 + 64;
+  return sizeof(double) * (size_t)groups * C * D * 5 + sizeof(float) * (size_t)groups * (D * 2 + 2) + 64;
+}
+
+// Tile choice for the wave-per-tile kernels: TS = q * 4 * 2^(D-1) with q | (L / (4*2^(D-1))), 384..1024
+// level-0 outputs per tile when such a divisor exists.  Returns false -> use the block-per-row kernel.
+static bool pyr_pick_tile(int L, int D, PyrTile* t) {
+  const int unit = 4 << (D - 1);
+  const int m = L / unit;
+  int best = 0;
+  for (int q = 1; q <= m; ++q) {
+    if (m % q) continue;
+    const int ts = q * unit;
+    if (ts >= 384 && ts <= 1024) {
+      if (!best || abs(ts - 640) < abs(best - 640)) best = ts;
+    }
+  }
+  if (!best || best == L) return false;
+  t->TS = best;
+  t->tiles = L / best;
+  int h = 0;
+  for (int k = SRF_MAX_DEPTH - 1; k >= 0; --k) {
+    if (k >= D) {
+      t->h[k] = 0;
+      continue;
+    }
+    t->h[k] = (k == D - 1) ? 0 : 2 * h + 4;
+    h = t->h[k];
+  }
+  const int len0 = best + 2 * t->h[0] + 8;
+  int lv = 0;
+  for (int k = 1; k < D; ++k) lv += (best >> k) + 2 * t->h[k] + 8;
+  const int lenA = lv > len0 ? lv : len0;
+  t->wave_floats = len0 + ((lenA + 3) & ~3);
+  return (size_t)t->wave_floats * 4 * sizeof(float) <= 64 * 1024;
 }
 
 static bool g_pyr_attr_set = false;
@@ -447,6 +733,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
     a.beta[k] = f.beta[k] = beta[kk];
   }
   a.lvl = lvl;
+  a.in_mr = lvl + (size_t)groups * D * 2;
   a.mom = mom;
   a.out_sums = out_sums;
   a.rows = rows;
@@ -458,6 +745,25 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
   f.C = C;
   f.L = L;
   f.D = D;
+  PyrTile tile;
+  if (!(srf_debug_flags() & 32) && pyr_pick_tile(L, D, &tile)) {
+    tile.tasks = rows * tile.tiles;
+    const size_t tl = (size_t)tile.wave_floats * 4 * sizeof(float);
+    const unsigned nb = (unsigned)((tile.tasks + 3) / 4);
+    SRF_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * (size_t)rows * D * 5, st));
+    if (a.in_norm.sums) {
+      hipLaunchKernelGGL(srf_stats_finalize_kernel, dim3((unsigned)groups), dim3(64), 0, st, a.in_norm.sums,
+                         a.in_inv_count, const_cast<float*>(a.in_mr));
+      SRF_CHECK_LAUNCH("stats_finalize", st);
+    }
+    hipLaunchKernelGGL(srf_pyramid_tile_kernel<true>, dim3(nb), dim3(256), tl, st, a, tile);
+    SRF_CHECK_LAUNCH("pyramid_moments", st);
+    hipLaunchKernelGGL(srf_pyramid_finalize_kernel, dim3((unsigned)groups), dim3(256), 0, st, f);
+    SRF_CHECK_LAUNCH("pyramid_finalize", st);
+    hipLaunchKernelGGL(srf_pyramid_tile_kernel<false>, dim3(nb), dim3(256), tl, st, a, tile);
+    SRF_CHECK_LAUNCH("pyramid_merge", st);
+    return SRF_OK;
+  }
   const size_t ldsb = pyr_lds_bytes(L, D);
   if (ldsb > 64 * 1024 && !g_pyr_attr_set) {
     SRF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&srf_pyramid_kernel<true>),

@@ -42,6 +42,17 @@ def pyramid_fused(C, L, D):
     return 4 * (L + 8 + ((size_a + 3) & ~3)) + 8 * 72 <= 160 * 1024 - 1024
 
 
+def pyramid_tiled(L, D):
+    """Mirror of pyr_pick_tile() (csrc/srf_pyramid.hip): wave-per-tile kernels are used."""
+    unit = 4 << (D - 1)
+    m = L // unit
+    cands = [q * unit for q in range(1, m + 1) if m % q == 0 and 384 <= q * unit <= 1024]
+    if not cands:
+        return False
+    best = min(cands, key=lambda ts: (abs(ts - 640), ts))
+    return best != L
+
+
 def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
     """(family, algorithmic_bytes, flops) for every kernel launch of one srf_forward, in launch order
     (mirrors srf_api.hip).  Bytes = tensors each kernel must read + write once, fp32."""
@@ -63,6 +74,8 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
         out.append(pw(nB, nC, Bg))
         dw_flops = 2.0 * 5 * Bg * nC * sum(L >> k for k in range(D))
         if pyramid_fused(nC, L, D):
+            if pyramid_tiled(L, D):
+                out.append(("stats_finalize", 8.0 * Bg * 130, 0.0))
             out.append(("pyramid_moments", f * Bg * nC * L, dw_flops))
             out.append(("pyramid_finalize", 8.0 * Bg * nC * D * 5, 0.0))
             out.append(("pyramid_merge", f * Bg * nC * L * 2, dw_flops + 2.0 * D * Bg * nC * L))
