@@ -173,9 +173,9 @@ int srf_merge(const float* const* levels, const srf_norm* norms, int D, float* y
  * applied on load) -> merged [groups,C,L] (+ out_sums for final_norm).  w/bias/gamma/beta: D pointers
  * each (spp_dw[k].conv.weight/.bias, spp_dw[k].norm.gamma/.beta).  Equivalent to D x srf_dwconv5 +
  * srf_merge but moves 3 C*L instead of 7.75 C*L through HBM.  srf_pyramid_supported() tells whether
- * the shape qualifies (L % (4*2^(D-1)) == 0, L >> (D-1) >= 8, row fits LDS). */
+ * the shape qualifies (L % (4*2^(D-1)) == 0, L >> (D-1) >= 8, row fits LDS).  merged may alias y1. */
 int srf_pyramid_supported(int C, int L, int D);
-size_t srf_pyramid_scratch_bytes(int groups, int C, int D);
+size_t srf_pyramid_scratch_bytes(int groups, int C, int L, int D);
 int srf_pyramid(const float* y1, float* merged, const srf_norm* in_norm, const float* const* w,
                 const float* const* bias, const float* const* gamma, const float* const* beta, int groups,
                 int C, int L, int D, void* scratch, double* out_sums, void* stream);

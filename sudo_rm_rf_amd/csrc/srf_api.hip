@@ -234,7 +234,7 @@ extern "C" int srf_plan_create(const srf_config* c, int batch, int T, srf_plan**
   p->off_masked = take(F * batch * p->SA * c->enc_num_basis * L);
   p->off_dec = take(F * srf_decoder_scratch_floats(batch, p->SA * c->enc_num_basis, p->SA, K, p->L));
   p->fused_pyramid = srf_pyramid_supported(p->nC, p->L, D);
-  p->off_pyr = p->fused_pyramid ? take(srf_pyramid_scratch_bytes(p->Bg, p->nC, D)) : 0;
+  p->off_pyr = p->fused_pyramid ? take(srf_pyramid_scratch_bytes(p->Bg, p->nC, p->L, D)) : 0;
   // packed weights for the split-precision GEMM (only shapes the kernel supports)
   p->pk_of_param.assign(p->n_params, 0);
   auto add_pack = [&](int param, int cout, int cin) {
@@ -353,8 +353,7 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
     float* merged = y1;   // the merged tensor aliases y1 (dead once every level has been produced)
     const bool fused = p->fused_pyramid && srf_kernel_mode() == 0 && !(srf_debug_flags() & 16);
     if (fused) {
-      // two passes over y1 with every level kept on chip (srf_pyramid.hip); merged cannot alias y1
-      // here because pass 2 re-reads y1 row by row while writing merged rows -> own buffer (level 0's)
+      // two passes with every level kept on chip (srf_pyramid.hip); merged aliases y1 (allowed)
       const float *pw[SRF_MAX_DEPTH], *pb[SRF_MAX_DEPTH], *pg[SRF_MAX_DEPTH], *pbe[SRF_MAX_DEPTH];
       for (int k = 0; k < D; ++k) {
         const float* const* Pk = Pu + 5 + 4 * k;
@@ -364,7 +363,6 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
         pbe[k] = Pk[3];
       }
       srf_norm in{slot(s0), Pu[2], Pu[3], Pu[4]};
-      merged = fptr(p->off_lv[0]);
       rc = srf_pyramid(y1, merged, &in, pw, pb, pg, pbe, Bg, nC, L, D, ws + p->off_pyr, slot(s0 + 1 + D), stream);
       if (rc) return rc;
     } else {

@@ -35,6 +35,7 @@ struct PyrArgs {
   const float* beta[SRF_MAX_DEPTH];
   const float* lvl;     // [groups][D][2] {mean, rstd}    (pass 2)
   const float* in_mr;   // [groups][2] {mean, rstd} of in_norm, pre-finalised (tiled kernels)
+  float* d0;            // [rows][L] raw level-0 conv output: written by tiled pass 1, read by tiled pass 2
   double* mom;          // [rows][D][5]                   (pass 1)
   double* out_sums;     // merged statistics              (pass 2)
   long rows;
@@ -378,36 +379,37 @@ __global__ __launch_bounds__(256) void srf_pyramid_tile_kernel(PyrArgs a, PyrTil
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
 
-  // ---- step 1: o on positions [lo0 - 4, lo0 + TS + 2 h0 + 4)  (zero outside the row)
   const int lo0 = j0 - t.h[0];
-  const float4* yrow = reinterpret_cast<const float4*>(a.y1 + (size_t)row * L);
   const int n4 = L >> 2;
-  for (int q = lane; q < (len0 >> 2); q += 64) {
-    const int p4 = ((lo0 - 4) >> 2) + q;   // float4 group index in the row (may be out of range)
-    const bool ok = p4 >= 0 && p4 < n4;
-    float4 v = yrow[min(max(p4, 0), n4 - 1)];
-    v.x = fmaf(v.x, sc, sh);
-    v.y = fmaf(v.y, sc, sh);
-    v.z = fmaf(v.z, sc, sh);
-    v.w = fmaf(v.w, sc, sh);
-    if (act) {
-      v.x = srf_prelu(v.x, slope);
-      v.y = srf_prelu(v.y, slope);
-      v.z = srf_prelu(v.z, slope);
-      v.w = srf_prelu(v.w, slope);
-    }
-    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(bufA + 4 * q) = v;
-  }
-  wave_sync();
-
   float s1[SRF_MAX_DEPTH], s2[SRF_MAX_DEPTH];
 #pragma unroll
   for (int k = 0; k < SRF_MAX_DEPTH; ++k) s1[k] = s2[k] = 0.f;
 
-  // ---- step 2: level 0 on [lo0, lo0 + TS + 2 h0)
-  {
+  if (MOMENTS) {
+    // ---- pass 1, step 1: o = PReLU(GlobLN(y1)) on [lo0 - 4, lo0 + TS + 2 h0 + 4)  (zero outside the row)
+    const float4* yrow = reinterpret_cast<const float4*>(a.y1 + (size_t)row * L);
+    for (int q = lane; q < (len0 >> 2); q += 64) {
+      const int p4 = ((lo0 - 4) >> 2) + q;   // float4 group index in the row (may be out of range)
+      const bool ok = p4 >= 0 && p4 < n4;
+      float4 v = yrow[min(max(p4, 0), n4 - 1)];
+      v.x = fmaf(v.x, sc, sh);
+      v.y = fmaf(v.y, sc, sh);
+      v.z = fmaf(v.z, sc, sh);
+      v.w = fmaf(v.w, sc, sh);
+      if (act) {
+        v.x = srf_prelu(v.x, slope);
+        v.y = srf_prelu(v.y, slope);
+        v.z = srf_prelu(v.z, slope);
+        v.w = srf_prelu(v.w, slope);
+      }
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(bufA + 4 * q) = v;
+    }
+    wave_sync();
+    // ---- pass 1, step 2: raw level 0 on [lo0, lo0 + TS + 2 h0); the tile's own range goes to HBM (d0)
+    // so that pass 2 starts from it instead of redoing the GlobLN + PReLU + conv of y1
     const Lv l0 = level_coef(0);
+    float4* drow = reinterpret_cast<float4*>(a.d0 + (size_t)row * L);
     const int nq = (t.TS + 2 * t.h[0]) >> 2;
     for (int q = lane; q < nq; q += 64) {
       const float* p = bufA + 4 + 4 * q;
@@ -420,23 +422,33 @@ __global__ __launch_bounds__(256) void srf_pyramid_tile_kernel(PyrArgs a, PyrTil
       d.z = srf_dot5(l0.w, mi.x, mi.y, mi.z, mi.w, hi.x, l0.b);
       d.w = srf_dot5(l0.w, mi.y, mi.z, mi.w, hi.x, hi.y, l0.b);
       const int pos = lo0 + 4 * q;
-      if (MOMENTS) {
-        if (pos >= j0 && pos < j0 + t.TS) {   // own range only (halo belongs to the neighbours)
-          s1[0] += (d.x + d.y) + (d.z + d.w);
-          s2[0] += fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
-          if (pos == 0) {
-            a.mom[(row * D + 0) * 5 + 2] = (double)d.x;
-            a.mom[(row * D + 0) * 5 + 3] = (double)d.y;
-          }
-          if (pos == L - 4) a.mom[(row * D + 0) * 5 + 4] = (double)d.w;
+      if (pos >= j0 && pos < j0 + t.TS) {   // own range only (halo belongs to the neighbours)
+        drow[pos >> 2] = d;
+        s1[0] += (d.x + d.y) + (d.z + d.w);
+        s2[0] += fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+        if (pos == 0) {
+          a.mom[(row * D + 0) * 5 + 2] = (double)d.x;
+          a.mom[(row * D + 0) * 5 + 3] = (double)d.y;
         }
-      } else {
-        d.x = fmaf(d.x, l0.a, l0.c);
-        d.y = fmaf(d.y, l0.a, l0.c);
-        d.z = fmaf(d.z, l0.a, l0.c);
-        d.w = fmaf(d.w, l0.a, l0.c);
+        if (pos == L - 4) a.mom[(row * D + 0) * 5 + 4] = (double)d.w;
       }
       if (pos < 0 || pos >= L) d = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding of the next conv
+      *reinterpret_cast<float4*>(bufB + 4 + 4 * q) = d;
+    }
+  } else {
+    // ---- pass 2, steps 1+2: n_0 = GlobLN_0(d0) straight from HBM on [lo0, lo0 + TS + 2 h0)
+    const Lv l0 = level_coef(0);
+    const float4* drow = reinterpret_cast<const float4*>(a.d0 + (size_t)row * L);
+    const int nq = (t.TS + 2 * t.h[0]) >> 2;
+    for (int q = lane; q < nq; q += 64) {
+      const int p4 = (lo0 >> 2) + q;
+      const bool ok = p4 >= 0 && p4 < n4;
+      float4 d = drow[min(max(p4, 0), n4 - 1)];
+      d.x = fmaf(d.x, l0.a, l0.c);
+      d.y = fmaf(d.y, l0.a, l0.c);
+      d.z = fmaf(d.z, l0.a, l0.c);
+      d.w = fmaf(d.w, l0.a, l0.c);
+      if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(bufB + 4 + 4 * q) = d;
     }
   }
@@ -664,9 +676,14 @@ extern "C" int srf_pyramid_supported(int C, int L, int D) {
   return pyr_lds_bytes(L, D) <= 160 * 1024 - 1024;
 }
 
-extern "C" size_t srf_pyramid_scratch_bytes(int groups, int C, int D) {
-  // moments [groups*C][D][5] fp64 | level statistics [groups][D][2] fp32
-  return sizeof(double) * (size_t)groups * C * D * 5 + sizeof(float) * (size_t)groups * (D * 2 + 2) + 64;
+// scratch layout: moments [groups*C][D][5] fp64 | {mean,rstd} per level [groups][D][2] + of in_norm
+// [groups][2] fp32 | (256-B aligned) raw level-0 tensor d0 [groups*C][L] fp32
+static size_t pyr_small_bytes(int groups, int C, int D) {
+  const size_t b = sizeof(double) * (size_t)groups * C * D * 5 + sizeof(float) * (size_t)groups * (D * 2 + 2);
+  return (b + 255) & ~(size_t)255;
+}
+extern "C" size_t srf_pyramid_scratch_bytes(int groups, int C, int L, int D) {
+  return pyr_small_bytes(groups, C, D) + sizeof(float) * (size_t)groups * C * L;
 }
 
 // Tile choice for the wave-per-tile kernels: TS = q * 4 * 2^(D-1) with q | (L / (4*2^(D-1))), 384..1024
@@ -734,6 +751,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
   }
   a.lvl = lvl;
   a.in_mr = lvl + (size_t)groups * D * 2;
+  a.d0 = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + pyr_small_bytes(groups, C, D));
   a.mom = mom;
   a.out_sums = out_sums;
   a.rows = rows;

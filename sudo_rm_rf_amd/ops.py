@@ -151,7 +151,7 @@ def pyramid(y1, in_sums, in_gamma, in_beta, in_prelu, weights, biases, gammas, b
     if not lib.srf_pyramid_supported(Cc, L, D):
         raise _lib.SrfError("srf_pyramid: unsupported shape C=%d L=%d D=%d" % (Cc, L, D))
     merged = torch.empty_like(y1)
-    scratch = torch.empty(lib.srf_pyramid_scratch_bytes(groups, Cc, D), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(lib.srf_pyramid_scratch_bytes(groups, Cc, L, D), dtype=torch.uint8, device=dev)
     arr = lambda ts: (C.c_void_p * D)(*[t.data_ptr() for t in ts])
     n = _lib.make_norm(in_sums, in_gamma, in_beta, in_prelu)
     rc = lib.srf_pyramid(_lib.ptr(y1), _lib.ptr(merged), C.byref(n), arr(weights), arr(biases), arr(gammas),
