@@ -346,6 +346,30 @@ __global__ __launch_bounds__(256) void srf_pyramid_tile_kernel(PyrArgs a, PyrTil
     }
   }
 
+  // ---- per-task coefficient table in LDS: ONE batch of (vector) loads for all D levels, issued together
+  // with the first data loads, instead of D dependent rounds of scalar loads (each ~1-2 us under load)
+  float* coef = bufB + t.wave_floats - 8 * SRF_MAX_DEPTH;   // [level][8] = w0..w4, bias, a, c
+  {
+    const int k = lane >> 3, j = lane & 7;
+    float v = 0.f;
+    if (k < D) {
+      if (j < 5) {
+        v = a.w[k][c * 5 + j];
+      } else if (j == 5) {
+        v = (MOMENTS && k > 0) ? 0.f : a.bias[k][c];
+      } else if (MOMENTS) {
+        v = (j == 6) ? 1.f : 0.f;
+      } else {
+        const float m = a.lvl[(g * D + k) * 2 + 0], r = a.lvl[(g * D + k) * 2 + 1];
+        const float aa = a.gamma[k][c] * r;
+        v = (j == 6) ? aa : (a.beta[k][c] - m * aa);
+      }
+    }
+    coef[lane] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // table visible to the whole wave
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   float sc = 1.f, sh = 0.f;
   if (a.in_norm.sums) {   // statistics pre-finalised once per example by srf_stats_finalize_kernel
     const float mean = a.in_mr[2 * g], rstd = a.in_mr[2 * g + 1];
@@ -357,20 +381,18 @@ __global__ __launch_bounds__(256) void srf_pyramid_tile_kernel(PyrArgs a, PyrTil
   struct Lv {
     float w[5], b, a, c;
   };
-  auto level_coef = [&](int k) {
+  auto level_coef = [&](int k) {   // broadcast reads (uniform address)
+    const float4 c0 = *reinterpret_cast<const float4*>(coef + 8 * k);
+    const float4 c1 = *reinterpret_cast<const float4*>(coef + 8 * k + 4);
     Lv lv;
-#pragma unroll
-    for (int tt = 0; tt < 5; ++tt) lv.w[tt] = a.w[k][c * 5 + tt];
-    lv.b = a.bias[k][c];
-    if (MOMENTS) {
-      lv.a = 1.f;
-      lv.c = 0.f;
-      if (k > 0) lv.b = 0.f;
-    } else {
-      const float m = a.lvl[(g * D + k) * 2 + 0], r = a.lvl[(g * D + k) * 2 + 1];
-      lv.a = a.gamma[k][c] * r;
-      lv.c = a.beta[k][c] - m * lv.a;
-    }
+    lv.w[0] = c0.x;
+    lv.w[1] = c0.y;
+    lv.w[2] = c0.z;
+    lv.w[3] = c0.w;
+    lv.w[4] = c1.x;
+    lv.b = c1.y;
+    lv.a = c1.z;
+    lv.c = c1.w;
     return lv;
   };
   auto wave_sync = [&]() {   // LDS ops of one wave execute in order; this only pins the compiler
@@ -715,7 +737,7 @@ static bool pyr_pick_tile(int L, int D, PyrTile* t) {
   int lv = 0;
   for (int k = 1; k < D; ++k) lv += (best >> k) + 2 * t->h[k] + 8;
   const int lenA = lv > len0 ? lv : len0;
-  t->wave_floats = len0 + ((lenA + 3) & ~3);
+  t->wave_floats = len0 + ((lenA + 3) & ~3) + 8 * SRF_MAX_DEPTH;   // + coefficient table
   return (size_t)t->wave_floats * 4 * sizeof(float) <= 64 * 1024;
 }
 
