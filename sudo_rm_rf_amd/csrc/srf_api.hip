@@ -233,7 +233,7 @@ extern "C" int srf_plan_create(const srf_config* c, int batch, int T, srf_plan**
   for (int k = 0; k < D; ++k) p->off_lv[k] = take(F * batch * c->in_channels * (L >> k));
   p->off_masked = take(F * batch * p->SA * c->enc_num_basis * L);
   p->off_dec = take(F * srf_decoder_scratch_floats(batch, p->SA * c->enc_num_basis, p->SA, K, p->L));
-  p->fused_pyramid = srf_pyramid_supported(p->nC, p->L, D);
+  p->fused_pyramid = srf_pyramid_supported(p->nC, p->L, D);   // (evaluated with the default debug flags)
   p->off_pyr = p->fused_pyramid ? take(srf_pyramid_scratch_bytes(p->Bg, p->nC, p->L, D)) : 0;
   // packed weights for the split-precision GEMM (only shapes the kernel supports)
   p->pk_of_param.assign(p->n_params, 0);

@@ -692,9 +692,12 @@ static size_t pyr_lds_bytes(int L, int D) {
   return sizeof(float) * ((size_t)L + 8 + sizeA) + sizeof(double) * (4 * SRF_MAX_DEPTH * 2 + 8);
 }
 
+bool srf_pyramid_reg_supported(int L, int D);
 extern "C" int srf_pyramid_supported(int C, int L, int D) {
   if (D < 1 || D > SRF_MAX_DEPTH || C > 256 * SRF_FIN_CPT) return 0;
-  if (L % (4 << (D - 1)) != 0 || (L >> (D - 1)) < 8) return 0;
+  if ((L >> (D - 1)) < 8 || (L % (1 << (D - 1))) != 0) return 0;   // finalize needs distinct edge positions
+  if (!(srf_debug_flags() & 64) && srf_pyramid_reg_supported(L, D)) return 1;   // register-resident kernels
+  if (L % (4 << (D - 1)) != 0) return 0;                              // LDS kernels work on float4 groups
   return pyr_lds_bytes(L, D) <= 160 * 1024 - 1024;
 }
 
@@ -741,6 +744,26 @@ static bool pyr_pick_tile(int L, int D, PyrTile* t) {
   return (size_t)t->wave_floats * 4 * sizeof(float) <= 64 * 1024;
 }
 
+// register-resident kernels (srf_pyramid_reg.hip)
+struct PyrRegArgs {
+  const float* y1;
+  float* d0;
+  float* merged;
+  SrfNormDev in_norm;
+  const float* in_mr;
+  const float* w[SRF_MAX_DEPTH];
+  const float* bias[SRF_MAX_DEPTH];
+  const float* gamma[SRF_MAX_DEPTH];
+  const float* beta[SRF_MAX_DEPTH];
+  const float* lvl;
+  double* mom;
+  double* out_sums;
+  long tasks;
+  int C, L, D, tiles, own;
+};
+bool srf_pyramid_reg_supported(int L, int D);
+int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st);
+
 static bool g_pyr_attr_set = false;
 
 extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_norm,
@@ -785,6 +808,39 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
   f.C = C;
   f.L = L;
   f.D = D;
+  if (!(srf_debug_flags() & 64) && srf_pyramid_reg_supported(L, D)) {
+    PyrRegArgs r;
+    r.y1 = y1;
+    r.d0 = a.d0;
+    r.merged = merged;
+    r.in_norm = a.in_norm;
+    r.in_mr = a.in_mr;
+    for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+      r.w[k] = a.w[k];
+      r.bias[k] = a.bias[k];
+      r.gamma[k] = a.gamma[k];
+      r.beta[k] = a.beta[k];
+    }
+    r.lvl = lvl;
+    r.mom = mom;
+    r.out_sums = out_sums;
+    r.C = C;
+    r.L = L;
+    r.D = D;
+    r.tasks = 0;
+    r.tiles = r.own = 0;
+    SRF_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * (size_t)rows * D * 5, st));
+    if (a.in_norm.sums) {
+      hipLaunchKernelGGL(srf_stats_finalize_kernel, dim3((unsigned)groups), dim3(64), 0, st, a.in_norm.sums,
+                         a.in_inv_count, const_cast<float*>(a.in_mr));
+      SRF_CHECK_LAUNCH("stats_finalize", st);
+    }
+    int rc = srf_pyramid_reg_launch(r, true, rows, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(srf_pyramid_finalize_kernel, dim3((unsigned)groups), dim3(256), 0, st, f);
+    SRF_CHECK_LAUNCH("pyramid_finalize", st);
+    return srf_pyramid_reg_launch(r, false, rows, st);
+  }
   PyrTile tile;
   if (!(srf_debug_flags() & 32) && pyr_pick_tile(L, D, &tile)) {
     tile.tasks = rows * tile.tiles;

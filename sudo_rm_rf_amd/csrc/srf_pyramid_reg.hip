@@ -1,0 +1,343 @@
+// Register-resident variant of the fused depthwise pyramid (see srf_pyramid.hip for the algebra and
+// the three-step structure moments -> finalize -> merge).
+//
+// PMC counters of the LDS-tiled kernels showed them LDS-bound (LDS array busy ~80 % of the kernel, half
+// of it bank conflicts of the stride-2 level reads) with ~600 VALU + ~380 SALU instructions per
+// 640-sample tile.  Here every lane owns CH = 16 (D <= 5) or 32 (D <= 6) CONSECUTIVE time steps of a
+// row, so a lane's level-k values (CH >> k of them) are exactly the ones its own outputs upsample
+// from: the whole cascade and the bottom-up merge run in registers, the only cross-lane traffic is
+// the 2-left / <=2-right conv halo per level (wavefront shuffles), and there is no LDS and no barrier.
+// A wavefront covers 64 chunks = 2 halo chunks + up to 60 own chunks + 2 halo chunks (the dependency
+// cone of the deepest level reaches 30 (62) level-0 samples = 2 chunks); halo lanes recompute what the
+// neighbouring wavefront owns.  Global accesses are 4 (8) float4 per lane at a 64-B (128-B) lane
+// stride: every byte of a line is used by the same wavefront, L1 merges the pieces.
+#include "srf_common.h"
+
+struct PyrRegArgs {
+  const float* y1;     // pass 1 input
+  float* d0;           // raw level-0 conv output: written by pass 1, read by pass 2
+  float* merged;       // pass 2 output (may alias y1)
+  SrfNormDev in_norm;  // proj_1x1 GlobLN (+PReLU)
+  const float* in_mr;  // [groups][2] pre-finalised {mean, rstd} of in_norm
+  const float* w[SRF_MAX_DEPTH];
+  const float* bias[SRF_MAX_DEPTH];
+  const float* gamma[SRF_MAX_DEPTH];
+  const float* beta[SRF_MAX_DEPTH];
+  const float* lvl;    // [groups][D][2] {mean, rstd} per level (pass 2)
+  double* mom;         // [rows][D][5] (pass 1; zeroed by the host)
+  double* out_sums;    // merged statistics (pass 2)
+  long tasks;          // rows * tiles
+  int C, L, D, tiles, own;   // own = own chunks per tile
+};
+
+template <int N>
+__device__ __forceinline__ void srf_zero(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = 0.f;
+}
+
+// stride-1 k=5 conv over a lane's chunk: out[i] = b + sum_t w[t] * x[i + t - 2], halo from neighbours
+template <int N>
+__device__ __forceinline__ void srf_conv_s1(const float (&x)[N], float (&out)[N], const float* w, float b) {
+  const float l2 = __shfl_up(x[N - 2], 1, 64), l1 = __shfl_up(x[N - 1], 1, 64);
+  const float r0 = __shfl_down(x[0], 1, 64), r1 = __shfl_down(x[1], 1, 64);
+  float e[N + 4];
+  e[0] = l2;
+  e[1] = l1;
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i + 2] = x[i];
+  e[N + 2] = r0;
+  e[N + 3] = r1;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    out[i] = fmaf(w[4], e[i + 4], fmaf(w[3], e[i + 3], fmaf(w[2], e[i + 2], fmaf(w[1], e[i + 1], fmaf(w[0], e[i], b)))));
+}
+
+// stride-2 k=5 conv: out[j] = b + sum_t w[t] * x[2j + t - 2]
+template <int N>
+__device__ __forceinline__ void srf_conv_s2(const float (&x)[N], float (&out)[N / 2], const float* w, float b) {
+  const float l2 = __shfl_up(x[N - 2], 1, 64), l1 = __shfl_up(x[N - 1], 1, 64);
+  const float r0 = __shfl_down(x[0], 1, 64);
+  float e[N + 3];
+  e[0] = l2;
+  e[1] = l1;
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i + 2] = x[i];
+  e[N + 2] = r0;
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j)
+    out[j] = fmaf(w[4], e[2 * j + 4],
+                  fmaf(w[3], e[2 * j + 3], fmaf(w[2], e[2 * j + 2], fmaf(w[1], e[2 * j + 1], fmaf(w[0], e[2 * j], b)))));
+}
+
+template <int N>
+__device__ __forceinline__ void srf_affine_mask(float (&v)[N], float a, float c, bool valid) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = valid ? fmaf(v[i], a, c) : 0.f;
+}
+
+template <int N>
+__device__ __forceinline__ void srf_acc_moments(const float (&v)[N], float& s, float& q) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    s += v[i];
+    q = fmaf(v[i], v[i], q);
+  }
+}
+
+struct LvCoef {
+  float w[5], b, a, c;
+};
+
+// pass-1 edge bookkeeping: level-k values at row positions 0, 1 and L_k - 1 (N = values per lane)
+template <int N>
+__device__ __forceinline__ void srf_pyr_edges(double* m5, const float (&v)[N], int ci, int nchunks) {
+  if (ci == 0) {
+    m5[2] = (double)v[0];
+    if (N >= 2) m5[3] = (double)v[N >= 2 ? 1 : 0];
+  }
+  if (N == 1 && ci == 1) m5[3] = (double)v[0];
+  if (ci == nchunks - 1) m5[4] = (double)v[N - 1];
+}
+
+// MOMENTS: pass 1 (raw cascade; writes d0 + row moments).  !MOMENTS: pass 2 (d0 -> merged).
+template <bool MOMENTS, int CH>
+__global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long task = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (task >= a.tasks) return;   // wave-uniform
+  const int L = a.L, D = a.D, C = a.C;
+  const long row = task / a.tiles;
+  const int tile = (int)(task - row * a.tiles);
+  const int c = (int)(row % C);
+  const long g = row / C;
+  const int nchunks = L / CH;
+  const int ci = tile * a.own - 2 + lane;          // this lane's chunk index in the row
+  const bool valid = ci >= 0 && ci < nchunks;      // inside the row (else: zero padding)
+  const bool own = valid && lane >= 2 && lane < 2 + a.own;
+  const int cic = min(max(ci, 0), nchunks - 1);    // clamped for unconditional loads
+
+  // per-level coefficients (wave-uniform -> scalar loads, all issued up front)
+  LvCoef lc[SRF_MAX_DEPTH];
+#pragma unroll
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+    if (k < D && (CH >> k) >= 1) {
+#pragma unroll
+      for (int t = 0; t < 5; ++t) lc[k].w[t] = a.w[k][c * 5 + t];
+      lc[k].b = (MOMENTS && k > 0) ? 0.f : a.bias[k][c];
+      if (MOMENTS) {
+        lc[k].a = 1.f;
+        lc[k].c = 0.f;
+      } else {
+        const float m = a.lvl[(g * D + k) * 2 + 0], r = a.lvl[(g * D + k) * 2 + 1];
+        lc[k].a = a.gamma[k][c] * r;
+        lc[k].c = a.beta[k][c] - m * lc[k].a;
+      }
+    }
+  }
+
+  float x0[CH];
+  if (MOMENTS) {
+    // ---- o = PReLU(GlobLN(y1)), then the raw level-0 conv
+    float sc = 1.f, sh = 0.f;
+    if (a.in_norm.sums) {
+      const float mean = a.in_mr[2 * g], rstd = a.in_mr[2 * g + 1];
+      sc = a.in_norm.gamma[c] * rstd;
+      sh = a.in_norm.beta[c] - mean * sc;
+    }
+    const bool act = a.in_norm.prelu != nullptr;
+    const float slope = act ? a.in_norm.prelu[0] : 1.f;
+    const float4* src = reinterpret_cast<const float4*>(a.y1 + (size_t)row * L + (size_t)cic * CH);
+    float o[CH];
+#pragma unroll
+    for (int i = 0; i < CH / 4; ++i) {
+      const float4 v = src[i];
+      o[4 * i + 0] = v.x;
+      o[4 * i + 1] = v.y;
+      o[4 * i + 2] = v.z;
+      o[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      float v = fmaf(o[i], sc, sh);
+      if (act) v = srf_prelu(v, slope);
+      o[i] = valid ? v : 0.f;
+    }
+    srf_conv_s1<CH>(o, x0, lc[0].w, lc[0].b);
+    if (own) {
+      float4* dst = reinterpret_cast<float4*>(a.d0 + (size_t)row * L + (size_t)ci * CH);
+#pragma unroll
+      for (int i = 0; i < CH / 4; ++i) dst[i] = make_float4(x0[4 * i], x0[4 * i + 1], x0[4 * i + 2], x0[4 * i + 3]);
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) x0[i] = valid ? x0[i] : 0.f;
+  } else {
+    const float4* src = reinterpret_cast<const float4*>(a.d0 + (size_t)row * L + (size_t)cic * CH);
+#pragma unroll
+    for (int i = 0; i < CH / 4; ++i) {
+      const float4 v = src[i];
+      x0[4 * i + 0] = v.x;
+      x0[4 * i + 1] = v.y;
+      x0[4 * i + 2] = v.z;
+      x0[4 * i + 3] = v.w;
+    }
+    srf_affine_mask<CH>(x0, lc[0].a, lc[0].c, valid);
+  }
+
+  // ---- levels 1..D-1 in registers (each level halves the per-lane count)
+  float x1[CH / 2], x2[CH / 4], x3[CH / 8], x4[CH / 16], x5[CH / 32 > 0 ? CH / 32 : 1];
+  srf_zero(x1);
+  srf_zero(x2);
+  srf_zero(x3);
+  srf_zero(x4);
+  srf_zero(x5);
+  float s1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  double* mrow = a.mom + (size_t)row * D * 5;
+  if (MOMENTS && own) {
+    srf_acc_moments<CH>(x0, s1[0], s2[0]);
+    srf_pyr_edges<CH>(mrow, x0, ci, nchunks);
+  }
+  if (D > 1) {
+    srf_conv_s2<CH>(x0, x1, lc[1].w, lc[1].b);
+    srf_affine_mask<CH / 2>(x1, lc[1].a, lc[1].c, valid);
+    if (MOMENTS && own) {
+      srf_acc_moments<CH / 2>(x1, s1[1], s2[1]);
+      srf_pyr_edges<CH / 2>(mrow + 5, x1, ci, nchunks);
+    }
+  }
+  if (D > 2) {
+    srf_conv_s2<CH / 2>(x1, x2, lc[2].w, lc[2].b);
+    srf_affine_mask<CH / 4>(x2, lc[2].a, lc[2].c, valid);
+    if (MOMENTS && own) {
+      srf_acc_moments<CH / 4>(x2, s1[2], s2[2]);
+      srf_pyr_edges<CH / 4>(mrow + 10, x2, ci, nchunks);
+    }
+  }
+  if (D > 3) {
+    srf_conv_s2<CH / 4>(x2, x3, lc[3].w, lc[3].b);
+    srf_affine_mask<CH / 8>(x3, lc[3].a, lc[3].c, valid);
+    if (MOMENTS && own) {
+      srf_acc_moments<CH / 8>(x3, s1[3], s2[3]);
+      srf_pyr_edges<CH / 8>(mrow + 15, x3, ci, nchunks);
+    }
+  }
+  if (D > 4) {
+    srf_conv_s2<CH / 8>(x3, x4, lc[4].w, lc[4].b);
+    srf_affine_mask<CH / 16>(x4, lc[4].a, lc[4].c, valid);
+    if (MOMENTS && own) {
+      srf_acc_moments<CH / 16>(x4, s1[4], s2[4]);
+      srf_pyr_edges<CH / 16>(mrow + 20, x4, ci, nchunks);
+    }
+  }
+  if constexpr (CH >= 32) {
+    if (D > 5) {
+      srf_conv_s2<CH / 16>(x4, x5, lc[5].w, lc[5].b);
+      srf_affine_mask<CH / 32>(x5, lc[5].a, lc[5].c, valid);
+      if (MOMENTS && own) {
+        srf_acc_moments<CH / 32>(x5, s1[5], s2[5]);
+        srf_pyr_edges<CH / 32>(mrow + 25, x5, ci, nchunks);
+      }
+    }
+  }
+
+  if (MOMENTS) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (k < D) {
+        float r1 = s1[k], r2 = s2[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          r1 += __shfl_xor(r1, o, 64);
+          r2 += __shfl_xor(r2, o, 64);
+        }
+        if (lane == 0) {
+          atomicAdd(&mrow[k * 5 + 0], (double)r1);
+          atomicAdd(&mrow[k * 5 + 1], (double)r2);
+        }
+      }
+    }
+  } else {
+    // ---- merged[i] = n0[i] + (n1[i>>1] + (n2[i>>2] + ...))  -- everything is lane-local
+    float ms = 0.f, mq = 0.f;
+    float outv[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      float t = 0.f;
+      bool have = false;
+      if (D > 5 && CH >= 32) {
+        t = x5[i >> 5];
+        have = true;
+      }
+      if (D > 4) {
+        const float v = x4[i >> 4];
+        t = have ? v + t : v;
+        have = true;
+      }
+      if (D > 3) {
+        const float v = x3[i >> 3];
+        t = have ? v + t : v;
+        have = true;
+      }
+      if (D > 2) {
+        const float v = x2[i >> 2];
+        t = have ? v + t : v;
+        have = true;
+      }
+      if (D > 1) {
+        const float v = x1[i >> 1];
+        t = have ? v + t : v;
+        have = true;
+      }
+      const float v = have ? x0[i] + t : x0[i];
+      outv[i] = v;
+      ms += v;
+      mq = fmaf(v, v, mq);
+    }
+    if (own) {
+      float4* dst = reinterpret_cast<float4*>(a.merged + (size_t)row * L + (size_t)ci * CH);
+#pragma unroll
+      for (int i = 0; i < CH / 4; ++i)
+        dst[i] = make_float4(outv[4 * i], outv[4 * i + 1], outv[4 * i + 2], outv[4 * i + 3]);
+    } else {
+      ms = 0.f;
+      mq = 0.f;
+    }
+    if (a.out_sums) {
+      const double ds = srf_wave_sum((double)ms), dq = srf_wave_sum((double)mq);
+      if (lane == 0) {
+        double* dst = srf_stat_slot(a.out_sums, g, task);
+        atomicAdd(dst, ds);
+        atomicAdd(dst + 1, dq);
+      }
+    }
+  }
+}
+
+bool srf_pyramid_reg_supported(int L, int D) {
+  if (D <= 5) return L % 16 == 0 && L / 16 >= 4;
+  if (D == 6) return L % 32 == 0 && L / 32 >= 4;
+  return false;
+}
+
+// moments / finalize / merge launches are driven by srf_pyramid() in srf_pyramid.hip
+int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st) {
+  const int CH = a.D <= 5 ? 16 : 32;
+  const int nchunks = a.L / CH;
+  a.tiles = (nchunks + 59) / 60;
+  a.own = (nchunks + a.tiles - 1) / a.tiles;
+  a.tasks = rows * a.tiles;
+  const unsigned nb = (unsigned)((a.tasks + 3) / 4);
+  if (CH == 16) {
+    if (moments)
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16>), dim3(nb), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 16>), dim3(nb), dim3(256), 0, st, a);
+  } else {
+    if (moments)
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32>), dim3(nb), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 32>), dim3(nb), dim3(256), 0, st, a);
+  }
+  SRF_CHECK_LAUNCH(moments ? "pyramid_moments" : "pyramid_merge", st);
+  return SRF_OK;
+}

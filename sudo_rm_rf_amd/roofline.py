@@ -36,14 +36,21 @@ def pyramid_fused(C, L, D):
     """Mirror of srf_pyramid_supported() (csrc/srf_pyramid.hip)."""
     if D < 1 or D > 8 or C > 2048:
         return False
-    if L % (4 << (D - 1)) or (L >> (D - 1)) < 8:
+    if (L >> (D - 1)) < 8 or L % (1 << (D - 1)):
+        return False
+    if (D <= 5 and L % 16 == 0 and L // 16 >= 4) or (D == 6 and L % 32 == 0 and L // 32 >= 4):
+        return True
+    if L % (4 << (D - 1)):
         return False
     size_a = max(L + 8, sum((L >> k) + 8 for k in range(1, D)))
     return 4 * (L + 8 + ((size_a + 3) & ~3)) + 8 * 72 <= 160 * 1024 - 1024
 
 
 def pyramid_tiled(L, D):
-    """Mirror of pyr_pick_tile() (csrc/srf_pyramid.hip): wave-per-tile kernels are used."""
+    """True when srf_pyramid() runs its stats_finalize pre-kernel: register-resident kernels
+    (srf_pyramid_reg_supported) or the LDS-tiled ones (pyr_pick_tile)."""
+    if (D <= 5 and L % 16 == 0 and L // 16 >= 4) or (D == 6 and L % 32 == 0 and L // 32 >= 4):
+        return True
     unit = 4 << (D - 1)
     m = L // unit
     cands = [q * unit for q in range(1, m + 1) if m % q == 0 and 384 <= q * unit <= 1024]

@@ -205,9 +205,11 @@ def test_merge(mode, Bt, C, L, D):
     check_sums(osums, u, "merge sums")
 
 
+@pytest.mark.parametrize("flags", [0, 64, 96], ids=["registers", "lds-tiles", "lds-rows"])
 @pytest.mark.parametrize("Bt,C,L,D", [(2, 64, 3200, 5), (2, 16, 6400, 6), (1, 8, 128, 4), (3, 20, 256, 2),
-                                      (2, 4, 64, 1), (1, 5, 12800, 6), (2, 3, 64, 3)])
-def test_fused_pyramid(Bt, C, L, D):
+                                      (2, 4, 64, 1), (1, 5, 12800, 6), (2, 3, 64, 3), (2, 6, 3232, 5),
+                                      (1, 3, 3264, 6)])
+def test_fused_pyramid(Bt, C, L, D, flags):
     """srf_pyramid (two passes, statistics through the linearity of conv o GlobLN) == the reference's
     chain DilatedConvNorm x D + upsample/add (improved_sudormrf.py:206-216)."""
     from sudo_rm_rf_amd import ops
@@ -229,11 +231,22 @@ def test_fused_pyramid(Bt, C, L, D):
     for k in range(D - 2, -1, -1):
         u = outs[k] + u.repeat_interleave(2, dim=-1)
     osums = ops.new_sums(Bt, DEV)
-    got = ops.pyramid(dev32(y1), sums64(y1).to(DEV), dev32(g_in), dev32(b_in), dev32(slope),
-                      [dev32(t) for t in W], [dev32(t) for t in Bi], [dev32(t) for t in Ga],
-                      [dev32(t) for t in Be], out_sums=osums)
+    from sudo_rm_rf_amd import _lib
+    ops.set_debug_flags(flags)
+    try:
+        if not _lib.load().srf_pyramid_supported(C, L, D):
+            pytest.skip("shape not supported by this kernel family")
+        got = _run_pyramid(ops, y1, g_in, b_in, slope, W, Bi, Ga, Be, osums)
+    finally:
+        ops.set_debug_flags(0)
     check(got, u, 5e-5, "fused pyramid")
     check_sums(osums, u, "fused pyramid sums")
+
+
+def _run_pyramid(ops, y1, g_in, b_in, slope, W, Bi, Ga, Be, osums):
+    return ops.pyramid(dev32(y1), sums64(y1).to(DEV), dev32(g_in), dev32(b_in), dev32(slope),
+                      [dev32(t) for t in W], [dev32(t) for t in Bi], [dev32(t) for t in Ga],
+                      [dev32(t) for t in Be], out_sums=osums)
 
 
 @pytest.mark.parametrize("Bt,Ci,Co,K,L,T", [(2, 64, 2, 21, 100, 1000), (1, 96, 2, 21, 64, 633),
