@@ -759,6 +759,7 @@ struct PyrRegArgs {
   double* mom;
   double* out_sums;
   long tasks;
+  long tpw;
   int C, L, D, tiles, own;
 };
 bool srf_pyramid_reg_supported(int L, int D);
@@ -827,7 +828,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
     r.C = C;
     r.L = L;
     r.D = D;
-    r.tasks = 0;
+    r.tasks = r.tpw = 0;
     r.tiles = r.own = 0;
     SRF_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * (size_t)rows * D * 5, st));
     if (a.in_norm.sums) {
@@ -870,12 +871,16 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
   }
   // persistent grids: exactly as many blocks as are co-resident (registers + LDS), rows strided
   auto resident_blocks = [&](const void* fn) -> long {
-    int per_cu = 0, dev = 0, cus = 256;
+    int per_cu = 0, dev = 0;
+    static int cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, ldsb) != hipSuccess || per_cu < 1)
       per_cu = 1;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
+    if (!cus) {
+      hipDeviceProp_t prop;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                ? prop.multiProcessorCount
+                : 256;
+    }
     const long n = (long)per_cu * cus;
     return n < rows ? n : rows;
   };

@@ -27,6 +27,7 @@ struct PyrRegArgs {
   double* mom;         // [rows][D][5] (pass 1; zeroed by the host)
   double* out_sums;    // merged statistics (pass 2)
   long tasks;          // rows * tiles
+  long tpw;            // tasks per (persistent) wavefront
   int C, L, D, tiles, own;   // own = own chunks per tile
 };
 
@@ -104,18 +105,37 @@ __device__ __forceinline__ void srf_pyr_edges(double* m5, const float (&v)[N], i
 template <bool MOMENTS, int CH>
 __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   const int lane = threadIdx.x & 63;
-  const long task = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (task >= a.tasks) return;   // wave-uniform
   const int L = a.L, D = a.D, C = a.C;
+  const int nchunks = L / CH;
+  // Persistent wavefronts: wave w of the grid owns the contiguous task range [w*tpw, (w+1)*tpw) (tasks of
+  // one row are adjacent, so the per-row coefficients are reused) and keeps the NEXT task's input chunk
+  // in flight while it computes the current one -- without it every wave of a CU sits through the full
+  // HBM latency at the start of each task at the same time.
+  const long wave_id = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long t_beg = wave_id * a.tpw;
+  const long t_end = min(t_beg + a.tpw, a.tasks);
+  if (t_beg >= t_end) return;   // wave-uniform
+  const float* in_base = MOMENTS ? a.y1 : a.d0;
+  auto chunk_src = [&](long task) {
+    const long row_ = task / a.tiles;
+    const int tile_ = (int)(task - row_ * a.tiles);
+    const int ci_ = min(max(tile_ * a.own - 2 + lane, 0), nchunks - 1);   // clamped: loads unconditional
+    return reinterpret_cast<const float4*>(in_base + (size_t)row_ * L + (size_t)ci_ * CH);
+  };
+  float4 pre[CH / 4];
+  {
+    const float4* src = chunk_src(t_beg);
+#pragma unroll
+    for (int i = 0; i < CH / 4; ++i) pre[i] = src[i];
+  }
+  for (long task = t_beg; task < t_end; ++task) {
   const long row = task / a.tiles;
   const int tile = (int)(task - row * a.tiles);
   const int c = (int)(row % C);
   const long g = row / C;
-  const int nchunks = L / CH;
   const int ci = tile * a.own - 2 + lane;          // this lane's chunk index in the row
   const bool valid = ci >= 0 && ci < nchunks;      // inside the row (else: zero padding)
   const bool own = valid && lane >= 2 && lane < 2 + a.own;
-  const int cic = min(max(ci, 0), nchunks - 1);    // clamped for unconditional loads
 
   // per-level coefficients (wave-uniform -> scalar loads, all issued up front)
   LvCoef lc[SRF_MAX_DEPTH];
@@ -147,11 +167,10 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     }
     const bool act = a.in_norm.prelu != nullptr;
     const float slope = act ? a.in_norm.prelu[0] : 1.f;
-    const float4* src = reinterpret_cast<const float4*>(a.y1 + (size_t)row * L + (size_t)cic * CH);
     float o[CH];
 #pragma unroll
     for (int i = 0; i < CH / 4; ++i) {
-      const float4 v = src[i];
+      const float4 v = pre[i];
       o[4 * i + 0] = v.x;
       o[4 * i + 1] = v.y;
       o[4 * i + 2] = v.z;
@@ -172,16 +191,21 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) x0[i] = valid ? x0[i] : 0.f;
   } else {
-    const float4* src = reinterpret_cast<const float4*>(a.d0 + (size_t)row * L + (size_t)cic * CH);
 #pragma unroll
     for (int i = 0; i < CH / 4; ++i) {
-      const float4 v = src[i];
+      const float4 v = pre[i];
       x0[4 * i + 0] = v.x;
       x0[4 * i + 1] = v.y;
       x0[4 * i + 2] = v.z;
       x0[4 * i + 3] = v.w;
     }
     srf_affine_mask<CH>(x0, lc[0].a, lc[0].c, valid);
+  }
+
+  {  // prefetch the next task's chunk (clamped to this wave's last task: surplus loads are harmless)
+    const float4* src = chunk_src(task + 1 < t_end ? task + 1 : task);
+#pragma unroll
+    for (int i = 0; i < CH / 4; ++i) pre[i] = src[i];
   }
 
   // ---- levels 1..D-1 in registers (each level halves the per-lane count)
@@ -311,6 +335,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
       }
     }
   }
+  }  // task loop
 }
 
 bool srf_pyramid_reg_supported(int L, int D) {
@@ -326,7 +351,26 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
   a.tiles = (nchunks + 59) / 60;
   a.own = (nchunks + a.tiles - 1) / a.tiles;
   a.tasks = rows * a.tiles;
-  const unsigned nb = (unsigned)((a.tasks + 3) / 4);
+  // persistent grid: exactly the co-resident wavefronts of this kernel (cached occupancy query)
+  static long cached_waves[2][2] = {{0, 0}, {0, 0}};
+  long& cw = cached_waves[CH == 16 ? 0 : 1][moments ? 0 : 1];
+  if (!cw) {
+    int dev = 0, cus = 256, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    const void* fn = CH == 16 ? (moments ? (const void*)&srf_pyramid_reg_kernel<true, 16>
+                                         : (const void*)&srf_pyramid_reg_kernel<false, 16>)
+                              : (moments ? (const void*)&srf_pyramid_reg_kernel<true, 32>
+                                         : (const void*)&srf_pyramid_reg_kernel<false, 32>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    cw = (long)cus * per_cu * 4;
+  }
+  long nwaves = cw;
+  if (nwaves > a.tasks) nwaves = a.tasks;
+  a.tpw = (a.tasks + nwaves - 1) / nwaves;
+  nwaves = (a.tasks + a.tpw - 1) / a.tpw;
+  const unsigned nb = (unsigned)((nwaves + 3) / 4);
   if (CH == 16) {
     if (moments)
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16>), dim3(nb), dim3(256), 0, st, a);
