@@ -86,6 +86,31 @@ __device__ __forceinline__ void srf_acc_moments(const float (&v)[N], float& s, f
   }
 }
 
+// Wavefront sum with DPP row operations (VALU only; __shfl_xor lowers to ds_bpermute, an LDS-pipe
+// instruction with ~50+ cycles of latency per step).  The total ends up in lane 63.
+__device__ __forceinline__ float srf_dpp_wave_sum(float v) {
+  auto dpp = [](float x, int ctrl_id) {
+    const int xi = __float_as_int(x);
+    int r;
+    switch (ctrl_id) {
+      case 0: r = __builtin_amdgcn_update_dpp(0, xi, 0x111, 0xf, 0xf, true); break;   // row_shr:1
+      case 1: r = __builtin_amdgcn_update_dpp(0, xi, 0x112, 0xf, 0xf, true); break;   // row_shr:2
+      case 2: r = __builtin_amdgcn_update_dpp(0, xi, 0x114, 0xf, 0xf, true); break;   // row_shr:4
+      case 3: r = __builtin_amdgcn_update_dpp(0, xi, 0x118, 0xf, 0xf, true); break;   // row_shr:8
+      case 4: r = __builtin_amdgcn_update_dpp(0, xi, 0x142, 0xa, 0xf, true); break;   // row_bcast:15 -> rows 1,3
+      default: r = __builtin_amdgcn_update_dpp(0, xi, 0x143, 0xc, 0xf, true); break;  // row_bcast:31 -> rows 2,3
+    }
+    return __int_as_float(r);
+  };
+  v += dpp(v, 0);
+  v += dpp(v, 1);
+  v += dpp(v, 2);
+  v += dpp(v, 3);   // lane 15 of every row holds its row sum
+  v += dpp(v, 4);   // lanes 31 / 63 hold the sum of rows 0-1 / 2-3
+  v += dpp(v, 5);   // lane 63 holds the wavefront sum
+  return v;
+}
+
 struct LvCoef {
   float w[5], b, a, c;
 };
@@ -102,7 +127,9 @@ __device__ __forceinline__ void srf_pyr_edges(double* m5, const float (&v)[N], i
 }
 
 // MOMENTS: pass 1 (raw cascade; writes d0 + row moments).  !MOMENTS: pass 2 (d0 -> merged).
-template <bool MOMENTS, int CH>
+// PERSIST: wavefronts loop over a contiguous task range with next-task prefetch (measured faster for
+// pass 1, slower for pass 2 whose one-task-per-wave form keeps 8 waves per SIMD resident).
+template <bool MOMENTS, int CH, bool PERSIST = MOMENTS>
 __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   const int lane = threadIdx.x & 63;
   const int L = a.L, D = a.D, C = a.C;
@@ -112,8 +139,8 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   // in flight while it computes the current one -- without it every wave of a CU sits through the full
   // HBM latency at the start of each task at the same time.
   const long wave_id = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long t_beg = wave_id * a.tpw;
-  const long t_end = min(t_beg + a.tpw, a.tasks);
+  const long t_beg = PERSIST ? wave_id * a.tpw : wave_id;
+  const long t_end = PERSIST ? min(t_beg + a.tpw, a.tasks) : min(t_beg + 1, a.tasks);
   if (t_beg >= t_end) return;   // wave-uniform
   const float* in_base = MOMENTS ? a.y1 : a.d0;
   auto chunk_src = [&](long task) {
@@ -202,7 +229,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     srf_affine_mask<CH>(x0, lc[0].a, lc[0].c, valid);
   }
 
-  {  // prefetch the next task's chunk (clamped to this wave's last task: surplus loads are harmless)
+  if (PERSIST) {  // prefetch the next task's chunk (clamped to this wave's last task: surplus loads are harmless)
     const float4* src = chunk_src(task + 1 < t_end ? task + 1 : task);
 #pragma unroll
     for (int i = 0; i < CH / 4; ++i) pre[i] = src[i];
@@ -268,13 +295,8 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k < D) {
-        float r1 = s1[k], r2 = s2[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          r1 += __shfl_xor(r1, o, 64);
-          r2 += __shfl_xor(r2, o, 64);
-        }
-        if (lane == 0) {
+        const float r1 = srf_dpp_wave_sum(s1[k]), r2 = srf_dpp_wave_sum(s2[k]);
+        if (lane == 63) {
           atomicAdd(&mrow[k * 5 + 0], (double)r1);
           atomicAdd(&mrow[k * 5 + 1], (double)r2);
         }
@@ -366,7 +388,7 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     cw = (long)cus * per_cu * 4;
   }
-  long nwaves = cw;
+  long nwaves = moments ? cw : a.tasks;   // pass 2 is not persistent (PERSIST defaults to MOMENTS)
   if (nwaves > a.tasks) nwaves = a.tasks;
   a.tpw = (a.tasks + nwaves - 1) / nwaves;
   nwaves = (a.tasks + a.tpw - 1) / a.tpw;
