@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--kernel-mode", type=int, default=0,
                     help="0 fast (split-bf16x3 MFMA GEMMs), 1 generic kernels only, 2 fast with exact-fp32 MFMA GEMMs")
+    ap.add_argument("--debug-flags", type=int, default=0, help="library debug flags (A/B of kernel variants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -152,6 +153,7 @@ def main():
     import sudo_rm_rf.dnn.models.groupcomm_sudormrf_v2 as sudormrf_gc_v2
     _lib.load()
     ops.set_kernel_mode(args.kernel_mode)
+    ops.set_debug_flags(args.debug_flags)
 
     variant, kw, T, fs, def_batch = WORKLOADS[args.workload]
     batch = args.batch or def_batch

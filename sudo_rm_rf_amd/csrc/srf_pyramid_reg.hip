@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   // HBM latency at the start of each task at the same time.
   const long wave_id = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long t_beg = PERSIST ? wave_id * a.tpw : wave_id;
-  const long t_end = PERSIST ? min(t_beg + a.tpw, a.tasks) : min(t_beg + 1, a.tasks);
-  if (t_beg >= t_end) return;   // wave-uniform
+  if (t_beg >= a.tasks) return;   // wave-uniform
+  const long t_end = PERSIST ? min(t_beg + a.tpw, a.tasks) : t_beg + 1;   // exactly one trip when !PERSIST
   const float* in_base = MOMENTS ? a.y1 : a.d0;
   auto chunk_src = [&](long task) {
     const long row_ = task / a.tiles;
@@ -373,36 +373,39 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
   a.tiles = (nchunks + 59) / 60;
   a.own = (nchunks + a.tiles - 1) / a.tiles;
   a.tasks = rows * a.tiles;
-  // persistent grid: exactly the co-resident wavefronts of this kernel (cached occupancy query)
-  static long cached_waves[2][2] = {{0, 0}, {0, 0}};
-  long& cw = cached_waves[CH == 16 ? 0 : 1][moments ? 0 : 1];
-  if (!cw) {
+  // pass 1 persistent (grid = co-resident wavefronts, cached occupancy query) unless debug flag 128
+  const bool persist = moments && !(srf_debug_flags() & 128);
+  static long cached_waves[2] = {0, 0};
+  long& cw = cached_waves[CH == 16 ? 0 : 1];
+  if (persist && !cw) {
     int dev = 0, cus = 256, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       cus = prop.multiProcessorCount;
-    const void* fn = CH == 16 ? (moments ? (const void*)&srf_pyramid_reg_kernel<true, 16>
-                                         : (const void*)&srf_pyramid_reg_kernel<false, 16>)
-                              : (moments ? (const void*)&srf_pyramid_reg_kernel<true, 32>
-                                         : (const void*)&srf_pyramid_reg_kernel<false, 32>);
+    const void* fn = CH == 16 ? (const void*)&srf_pyramid_reg_kernel<true, 16, true>
+                              : (const void*)&srf_pyramid_reg_kernel<true, 32, true>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     cw = (long)cus * per_cu * 4;
   }
-  long nwaves = moments ? cw : a.tasks;   // pass 2 is not persistent (PERSIST defaults to MOMENTS)
+  long nwaves = persist ? cw : a.tasks;
   if (nwaves > a.tasks) nwaves = a.tasks;
   a.tpw = (a.tasks + nwaves - 1) / nwaves;
   nwaves = (a.tasks + a.tpw - 1) / a.tpw;
   const unsigned nb = (unsigned)((nwaves + 3) / 4);
   if (CH == 16) {
-    if (moments)
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16>), dim3(nb), dim3(256), 0, st, a);
+    if (moments && persist)
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, true>), dim3(nb), dim3(256), 0, st, a);
+    else if (moments)
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, false>), dim3(nb), dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 16>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 16, false>), dim3(nb), dim3(256), 0, st, a);
   } else {
-    if (moments)
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32>), dim3(nb), dim3(256), 0, st, a);
+    if (moments && persist)
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32, true>), dim3(nb), dim3(256), 0, st, a);
+    else if (moments)
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32, false>), dim3(nb), dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 32>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 32, false>), dim3(nb), dim3(256), 0, st, a);
   }
   SRF_CHECK_LAUNCH(moments ? "pyramid_moments" : "pyramid_merge", st);
   return SRF_OK;
