@@ -761,6 +761,7 @@ struct PyrRegArgs {
   long tasks;
   long tpw;
   int C, L, D, tiles, own;
+  int abl;
 };
 bool srf_pyramid_reg_supported(int L, int D);
 int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st);
@@ -829,7 +830,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
     r.L = L;
     r.D = D;
     r.tasks = r.tpw = 0;
-    r.tiles = r.own = 0;
+    r.tiles = r.own = r.abl = 0;
     SRF_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * (size_t)rows * D * 5, st));
     if (a.in_norm.sums) {
       hipLaunchKernelGGL(srf_stats_finalize_kernel, dim3((unsigned)groups), dim3(64), 0, st, a.in_norm.sums,

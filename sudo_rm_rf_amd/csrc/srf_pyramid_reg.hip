@@ -29,6 +29,7 @@ struct PyrRegArgs {
   long tasks;          // rows * tiles
   long tpw;            // tasks per (persistent) wavefront
   int C, L, D, tiles, own;   // own = own chunks per tile
+  int abl;             // diagnostics: 1 = plain stores instead of moment atomics, 2 = no wave reductions
 };
 
 template <int N>
@@ -295,10 +296,16 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k < D) {
-        const float r1 = srf_dpp_wave_sum(s1[k]), r2 = srf_dpp_wave_sum(s2[k]);
+        const float r1 = (a.abl & 2) ? s1[k] : srf_dpp_wave_sum(s1[k]);
+        const float r2 = (a.abl & 2) ? s2[k] : srf_dpp_wave_sum(s2[k]);
         if (lane == 63) {
-          atomicAdd(&mrow[k * 5 + 0], (double)r1);
-          atomicAdd(&mrow[k * 5 + 1], (double)r2);
+          if (a.abl & 1) {
+            mrow[k * 5 + 0] = (double)r1;
+            mrow[k * 5 + 1] = (double)r2;
+          } else {
+            atomicAdd(&mrow[k * 5 + 0], (double)r1);
+            atomicAdd(&mrow[k * 5 + 1], (double)r2);
+          }
         }
       }
     }
@@ -369,6 +376,7 @@ bool srf_pyramid_reg_supported(int L, int D) {
 // moments / finalize / merge launches are driven by srf_pyramid() in srf_pyramid.hip
 int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st) {
   const int CH = a.D <= 5 ? 16 : 32;
+  a.abl = (srf_debug_flags() >> 12) & 3;
   const int nchunks = a.L / CH;
   a.tiles = (nchunks + 59) / 60;
   a.own = (nchunks + a.tiles - 1) / a.tiles;
