@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     const int ci_ = min(max(tile_ * a.own - 2 + lane, 0), nchunks - 1);   // clamped: loads unconditional
     return reinterpret_cast<const float4*>(in_base + (size_t)row_ * L + (size_t)ci_ * CH);
   };
+  float s1[6], s2[6];
   float4 pre[CH / 4];
   {
     const float4* src = chunk_src(t_beg);
@@ -243,7 +244,12 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   srf_zero(x3);
   srf_zero(x4);
   srf_zero(x5);
-  float s1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // pass 1, persistent: a wave owns whole rows (tpw is a multiple of tiles), so the row moments are
+  // accumulated in registers over the row's tiles and written with plain stores at its last tile
+  if (!PERSIST || tile == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s1[k] = s2[k] = 0.f;
+  }
   double* mrow = a.mom + (size_t)row * D * 5;
   if (MOMENTS && own) {
     srf_acc_moments<CH>(x0, s1[0], s2[0]);
@@ -295,11 +301,12 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   if (MOMENTS) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
+      if (PERSIST && tile != a.tiles - 1) break;   // the row's last tile flushes
       if (k < D) {
         const float r1 = (a.abl & 2) ? s1[k] : srf_dpp_wave_sum(s1[k]);
         const float r2 = (a.abl & 2) ? s2[k] : srf_dpp_wave_sum(s2[k]);
         if (lane == 63) {
-          if (a.abl & 1) {
+          if (PERSIST || (a.abl & 1)) {
             mrow[k * 5 + 0] = (double)r1;
             mrow[k * 5 + 1] = (double)r2;
           } else {
@@ -398,6 +405,7 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
   long nwaves = persist ? cw : a.tasks;
   if (nwaves > a.tasks) nwaves = a.tasks;
   a.tpw = (a.tasks + nwaves - 1) / nwaves;
+  if (persist) a.tpw = (a.tpw + a.tiles - 1) / a.tiles * a.tiles;   // whole rows per wave
   nwaves = (a.tasks + a.tpw - 1) / a.tpw;
   const unsigned nb = (unsigned)((nwaves + 3) / 4);
   if (CH == 16) {
