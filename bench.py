@@ -225,7 +225,7 @@ def main():
                 model(wav)
             cnt = C.c_int(0)
             _lib.check(lib.srf_profile_end(stream, C.byref(cnt)), "srf_profile_end")
-        launches = roofline.launch_model(Bt=batch, **dims)
+        launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, **dims)
         per = {}
         name, ms = C.c_char_p(), C.c_float()
         assert cnt.value == psteps * len(launches), (cnt.value, psteps, len(launches))

@@ -351,7 +351,7 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
     if (rc) return rc;
     // depthwise pyramid + upsample/add                         :206-216
     float* merged = y1;   // the merged tensor aliases y1 (dead once every level has been produced)
-    const bool fused = p->fused_pyramid && srf_kernel_mode() == 0 && !(srf_debug_flags() & 16);
+    const bool fused = p->fused_pyramid && srf_kernel_mode() != 1 && !(srf_debug_flags() & 16);
     if (fused) {
       // two passes with every level kept on chip (srf_pyramid.hip); merged aliases y1 (allowed)
       const float *pw[SRF_MAX_DEPTH], *pb[SRF_MAX_DEPTH], *pg[SRF_MAX_DEPTH], *pbe[SRF_MAX_DEPTH];

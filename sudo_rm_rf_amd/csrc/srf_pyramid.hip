@@ -751,6 +751,7 @@ struct PyrRegArgs {
   float* merged;
   SrfNormDev in_norm;
   const float* in_mr;
+  double in_inv_count;
   const float* w[SRF_MAX_DEPTH];
   const float* bias[SRF_MAX_DEPTH];
   const float* gamma[SRF_MAX_DEPTH];
@@ -817,6 +818,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
     r.merged = merged;
     r.in_norm = a.in_norm;
     r.in_mr = a.in_mr;
+    r.in_inv_count = a.in_inv_count;
     for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
       r.w[k] = a.w[k];
       r.bias[k] = a.bias[k];
@@ -831,11 +833,13 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
     r.D = D;
     r.tasks = r.tpw = 0;
     r.tiles = r.own = r.abl = 0;
-    SRF_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * (size_t)rows * D * 5, st));
-    if (a.in_norm.sums) {
-      hipLaunchKernelGGL(srf_stats_finalize_kernel, dim3((unsigned)groups), dim3(64), 0, st, a.in_norm.sums,
-                         a.in_inv_count, const_cast<float*>(a.in_mr));
-      SRF_CHECK_LAUNCH("stats_finalize", st);
+    if (srf_debug_flags() & 128) {   // non-persistent pass 1: atomics into mom + pre-finalised statistics
+      SRF_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * (size_t)rows * D * 5, st));
+      if (a.in_norm.sums) {
+        hipLaunchKernelGGL(srf_stats_finalize_kernel, dim3((unsigned)groups), dim3(64), 0, st, a.in_norm.sums,
+                           a.in_inv_count, const_cast<float*>(a.in_mr));
+        SRF_CHECK_LAUNCH("stats_finalize", st);
+      }
     }
     int rc = srf_pyramid_reg_launch(r, true, rows, st);
     if (rc) return rc;

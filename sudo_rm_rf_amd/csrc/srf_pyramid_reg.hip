@@ -18,7 +18,8 @@ struct PyrRegArgs {
   float* d0;           // raw level-0 conv output: written by pass 1, read by pass 2
   float* merged;       // pass 2 output (may alias y1)
   SrfNormDev in_norm;  // proj_1x1 GlobLN (+PReLU)
-  const float* in_mr;  // [groups][2] pre-finalised {mean, rstd} of in_norm
+  const float* in_mr;  // [groups][2] pre-finalised {mean, rstd} of in_norm (non-persistent pass 1 only)
+  double in_inv_count; // 1 / (C * L)
   const float* w[SRF_MAX_DEPTH];
   const float* bias[SRF_MAX_DEPTH];
   const float* gamma[SRF_MAX_DEPTH];
@@ -151,6 +152,8 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     return reinterpret_cast<const float4*>(in_base + (size_t)row_ * L + (size_t)ci_ * CH);
   };
   float s1[6], s2[6];
+  long cur_g = -1;               // persistent pass 1 finalises the proj statistics itself, once per example
+  float in_mean = 0.f, in_rstd = 1.f;
   float4 pre[CH / 4];
   {
     const float4* src = chunk_src(t_beg);
@@ -190,9 +193,17 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     // ---- o = PReLU(GlobLN(y1)), then the raw level-0 conv
     float sc = 1.f, sh = 0.f;
     if (a.in_norm.sums) {
-      const float mean = a.in_mr[2 * g], rstd = a.in_mr[2 * g + 1];
-      sc = a.in_norm.gamma[c] * rstd;
-      sh = a.in_norm.beta[c] - mean * sc;
+      if (PERSIST) {
+        if (g != cur_g) {   // wave-uniform
+          srf_finalize_stats(a.in_norm.sums, g, a.in_inv_count, in_mean, in_rstd);
+          cur_g = g;
+        }
+      } else {
+        in_mean = a.in_mr[2 * g];
+        in_rstd = a.in_mr[2 * g + 1];
+      }
+      sc = a.in_norm.gamma[c] * in_rstd;
+      sh = a.in_norm.beta[c] - in_mean * sc;
     }
     const bool act = a.in_norm.prelu != nullptr;
     const float slope = act ? a.in_norm.prelu[0] : 1.f;

@@ -46,6 +46,11 @@ def pyramid_fused(C, L, D):
     return 4 * (L + 8 + ((size_a + 3) & ~3)) + 8 * 72 <= 160 * 1024 - 1024
 
 
+def pyramid_regs(L, D):
+    """Mirror of srf_pyramid_reg_supported(): register-resident pyramid kernels (no stats pre-kernel)."""
+    return (D <= 5 and L % 16 == 0 and L // 16 >= 4) or (D == 6 and L % 32 == 0 and L // 32 >= 4)
+
+
 def pyramid_tiled(L, D):
     """True when srf_pyramid() runs its stats_finalize pre-kernel: register-resident kernels
     (srf_pyramid_reg_supported) or the LDS-tiled ones (pyr_pick_tile)."""
@@ -60,7 +65,7 @@ def pyramid_tiled(L, D):
     return best != L
 
 
-def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
+def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0):
     """(family, algorithmic_bytes, flops) for every kernel launch of one srf_forward, in launch order
     (mirrors srf_api.hip).  Bytes = tensors each kernel must read + write once, fp32."""
     L = frames(T, K, D)
@@ -80,8 +85,8 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
             out.append(("gln_apply_add", f * Bt * B * L * 3, 3.0 * Bt * B * L))
         out.append(pw(nB, nC, Bg))
         dw_flops = 2.0 * 5 * Bg * nC * sum(L >> k for k in range(D))
-        if pyramid_fused(nC, L, D):
-            if pyramid_tiled(L, D):
+        if kernel_mode != 1 and pyramid_fused(nC, L, D):
+            if pyramid_tiled(L, D) and not pyramid_regs(L, D):
                 out.append(("stats_finalize", 8.0 * Bg * 130, 0.0))
             out.append(("pyramid_moments", f * Bg * nC * L, dw_flops))
             out.append(("pyramid_finalize", 8.0 * Bg * nC * D * 5, 0.0))
