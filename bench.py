@@ -105,6 +105,31 @@ def cpu_baseline(variant, kw, T, fs, batch, repeats, budget_s=45.0):
                       % (batch, batch, repeats, sorted(tried))}
 
 
+def pmc_traffic(kernel_family, workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in their own runs of this same command -- tools/gpu_round.sh -- and stored
+    under profiles/; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    path = os.path.join(ROOT, "profiles", "r01_cfg2_bs32_pmc_hbm_traffic.csv")
+    if workload != "cfg2_improved_u16" or not os.path.exists(path):
+        return {"traffic": None}
+    key = {"pw_conv_bf16x3_w8": "srf_pw_bf16x3_w8_kernel", "pw_conv_mfma": "srf_pw_mfma_kernel",
+           "pyramid_moments": "srf_pyramid_reg_kernel<true", "pyramid_merge": "srf_pyramid_reg_kernel<false"
+           }.get(kernel_family, kernel_family)
+    fetch, write = {}, {}
+    import csv
+    rows = [r for r in csv.reader(l for l in open(path) if not l.startswith("#"))][1:]
+    for r in rows:
+        counter, kname, launches, mb = r[0], ",".join(r[1:-3]), int(r[-3]), float(r[-1])
+        if key in kname:
+            (fetch if counter == "FETCH_SIZE" else write)[kname] = (launches, mb)
+    if not fetch or not write:
+        return {"traffic": None}
+    f = sum(l * m for l, m in fetch.values()) / sum(l for l, _ in fetch.values())
+    w = sum(l * m for l, m in write.values()) / sum(l for l, _ in write.values())
+    return {"traffic": (f + w) * 1024 * 1024, "traffic_unit": "bytes/launch (HBM read + write, PMC)",
+            "traffic_source": "profiles/r01_cfg2_bs32_pmc_hbm_traffic.csv"}
+
+
 def cpu_baseline_subprocess(args):
     """Run the CPU leg in a child process under a hard wall-clock limit so that a slow host can never
     take the GPU result down with it."""
@@ -130,19 +155,11 @@ def main():
         return
     import torch
     import torch.distributed as dist
+    from sudo_rm_rf_amd import distributed as D
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rank, world, dev = D.init_from_env()        # one process per GPU, RCCL ("nccl") when WORLD_SIZE > 1
     n_gpus = world
     if args.gpus != n_gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d (launch through torch.distributed.run for N>1)" %
@@ -165,10 +182,7 @@ def main():
     wav = ((wav - wav.mean(-1, keepdim=True)) / (wav.std(-1, keepdim=True) + 1e-9)).to(dev)
 
     def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        D.barrier(dev)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -179,10 +193,7 @@ def main():
             out = model(wav)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.max_over_ranks(dt, dev)
     assert out.shape == (batch, kw["num_sources"], T) and bool(torch.isfinite(out).all())
     ms_per_step = 1e3 * dt / args.steps
     value = n_gpus * batch * (T / fs) * args.steps / dt
@@ -255,6 +266,7 @@ def main():
         else:
             rl = {"kernel": dom, "bound": "hbm", "achieved": kd["algorithmic_GBps"], "peak": roofline.HBM_PEAK_GBS,
                   "unit": "GB/s", "frac": kd["algorithmic_GBps"] / roofline.HBM_PEAK_GBS, "traffic": None}
+        rl.update(pmc_traffic(dom, args.workload))
         rl["avg_launch_us"] = kd["avg_launch_us"]
         rl["share_of_forward"] = kd["ms_per_forward"] / sum(v["ms_per_forward"] for v in kernels.values())
         result["roofline"] = rl

@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt
 // ---------------------------------------------------------------------------------------------
 // ABL (ablation, diagnostics only; results are wrong when != 0): 1 = no A loads, 2 = no B loads,
 // 4 = no MFMAs, 8 = no conversion / LDS stores
-// SCHED: conversion of tile t+1 and MFMAs of tile t in one basic block with MFMA/VALU interleave hints
-template <int PRO, int ABL = 0, bool SCHED = false>
+// (An instruction-interleave variant -- unconditional store + sched_group_barrier(MFMA 1 / VALU 7) -- was
+// measured: 131 us vs 151 us on proj_1x1 but slower on the prologue variants and miscompiled for PRO 0;
+// dropped.)
+template <int PRO, int ABL = 0>
 __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int nMt, int nLt, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
 
@@ -312,21 +314,9 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
     }
   };
   auto step = [&](Regs& nx, int kt) {
-    if (SCHED) {
-      // unconditional store (the surplus one lands in the stage nobody reads any more) -> one basic block
-      lds_store(nx, (kt + 1) & 1, min(kt + 1, nk_ - 1) * X3_BK);
-      gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
-      mma_tile(kt & 1);
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // 7 VALU
-      }
-    } else {
-      if (!(ABL & 8) && kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
-      gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
-      if (!(ABL & 4)) mma_tile(kt & 1);
-    }
+    if (!(ABL & 8) && kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
+    gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
+    if (!(ABL & 4)) mma_tile(kt & 1);
     __syncthreads();
   };
 
@@ -542,16 +532,6 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
         default: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 15>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
       }
       SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8_ablated", st);
-      return SRF_OK;
-    }
-    if (srf_debug_flags() & 256) {   // A/B: instruction-interleave hints
-      switch (pro) {
-        case 0: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 0, true>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 1: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<1, 0, true>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 2: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<2, 0, true>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        default: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<3, 0, true>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-      }
-      SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8", st);
       return SRF_OK;
     }
     switch (pro) {

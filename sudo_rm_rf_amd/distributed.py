@@ -1,0 +1,79 @@
+"""Batch-sharded multi-GPU execution of the forward path.
+
+Every reduction on the path (GlobLN, TAC group mean) is inside one example, so the path shards over
+ranks by batch with NO data-path collective: one process per GPU (torch.distributed.run), each rank runs
+its own examples.  The reference's only parallelism is single-process `torch.nn.DataParallel`
+(run_improved_sudormrf.py:118), which scatters the batch the same way.  `torch.distributed` (backend
+"nccl" = RCCL on ROCm, "gloo" on CPU for tests) is used for rendezvous, barriers, the max-over-ranks
+timing reduction and the optional output all-gather only.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    """(rank, world_size, local_rank) from the torchrun environment (1 process -> (0, 1, 0))."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group when WORLD_SIZE > 1.  Returns (rank, world_size, device)."""
+    rank, ws, local = world()
+    use_cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(local)
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = backend or ("nccl" if use_cuda else "gloo")
+        kw = {"device_id": device} if (use_cuda and backend == "nccl") else {}
+        dist.init_process_group(backend, rank=rank, world_size=ws, **kw)
+    return rank, ws, device
+
+
+def shard_slice(global_batch, rank, world_size):
+    """Contiguous equal shard [lo, hi) of the batch for `rank` (the reference's DataParallel scatter on
+    dim 0).  Equal shards are required so that weak-scaling numbers compare like with like."""
+    if global_batch % world_size:
+        raise ValueError("global batch %d is not divisible by world size %d" % (global_batch, world_size))
+    per = global_batch // world_size
+    return rank * per, (rank + 1) * per
+
+
+def barrier(device=None):
+    """Device-synchronising barrier used to bracket timed regions."""
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(seconds, device=None):
+    """The slowest rank's time (what a whole-job throughput must be computed from)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(seconds)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def separate_sharded(model, mixtures, gather=False):
+    """Run `model` on this rank's shard of `mixtures` [global_batch, ch, T] (every rank passes the same
+    global tensor or at least its own rows).  Returns the local estimates, or with gather=True the
+    all-gathered [global_batch, S, T] tensor (the only collective; not needed for throughput)."""
+    rank, ws, _ = world()
+    if not dist.is_initialized() or ws == 1:
+        return model(mixtures)
+    lo, hi = shard_slice(mixtures.shape[0], rank, ws)
+    local = model(mixtures[lo:hi])
+    if not gather:
+        return local
+    parts = [torch.empty_like(local) for _ in range(ws)]
+    dist.all_gather(parts, local.contiguous())
+    return torch.cat(parts, 0)

@@ -1,0 +1,84 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the batch sharding, the barrier, the
+max-over-ranks timing reduction and the output all-gather used by bench.py / separate_sharded."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from sudo_rm_rf_amd import distributed as D
+    from oracle import torch_oracle
+    from oracle.schema import ModelConfig
+    from oracle.weights import make_mixture, make_state_dict
+    torch.set_num_threads(1)
+    r, ws, dev = D.init_from_env(backend="gloo")
+    assert (r, ws) == (rank, world) and dev.type == "cpu"
+    # sharding covers the batch exactly once
+    lo, hi = D.shard_slice(8, r, ws)
+    assert hi - lo == 4 and lo == 4 * r
+    # timing reduction: slowest rank wins
+    t = D.max_over_ranks(1.0 + rank)
+    assert t == pytest.approx(2.0)
+    D.barrier(dev)
+    # a stand-in "model" (the CPU oracle): sharded + gathered == unsharded, examples are independent
+    cfg = ModelConfig("improved", 16, 32, 1, 3, 21, 16, 2)
+    sd = torch_oracle.to_torch(make_state_dict(cfg, 5))
+    wav = torch.from_numpy(make_mixture(4, 640, 6))
+    model = lambda x: torch_oracle.forward(cfg, sd, x)
+    with torch.no_grad():
+        full = model(wav)
+        local = D.separate_sharded(model, wav)
+        gathered = D.separate_sharded(model, wav, gather=True)
+    assert local.shape[0] == 2
+    q.put((rank, float((gathered - full).abs().max()), float((local - full[2 * rank:2 * rank + 2]).abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    for _, e_gather, e_local in res:
+        assert e_gather < 1e-6 and e_local < 1e-6
+
+
+def test_shard_slice_rejects_uneven():
+    from sudo_rm_rf_amd.distributed import shard_slice
+    with pytest.raises(ValueError):
+        shard_slice(10, 0, 4)
+    assert [shard_slice(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+
+
+def test_single_process_is_a_no_op():
+    from sudo_rm_rf_amd import distributed as D
+    assert D.max_over_ranks(0.25) == 0.25
+    D.barrier(torch.device("cpu"))
+    x = torch.randn(3, 1, 10)
+    assert torch.equal(D.separate_sharded(lambda t: t * 2, x), x * 2)
