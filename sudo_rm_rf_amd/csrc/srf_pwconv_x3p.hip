@@ -1,30 +1,18 @@
-// K2 (main path) -- split-precision MFMA GEMM with PRE-PACKED weights.
+// K2 -- split-precision MFMA GEMM with PRE-PACKED weights (8-wave 128x128x32 tile).
 //
-// Same arithmetic as srf_pwconv_bf16x3.hip (x = bf16 hi + bf16 lo, three v_mfma_f32_32x32x16_bf16 per
-// product block, fp32 accumulate; whole-model error vs the reference <= 4e-6, bar 1e-4) but organised
-// around what the PMC counters of that kernel showed (SQ_VALU_MFMA_BUSY 21 %, 200 VALU instructions
-// per 24 MFMAs per wave, the split/convert work repeated for every 128-row M tile):
-//   * weights are split and laid out ONCE per forward by srf_pack_pw_weights (bf16 hi|lo images in
-//     exactly the LDS row order), so the A operand is a plain 16-B global->LDS copy: no VALU;
-//   * block tile 256(M) x 128(time) x 32(K), 8 wavefronts (4 along M x 2 along time, 64x64 each):
-//     the activation tile is converted once per 256 output rows (half / quarter of the VALU work);
-//   * two register sets, loads issued two k-tiles ahead, all loads unconditional (clamped) so the
-//     compiler's vmcnt bookkeeping stays exact;
-//   * conversion of tile t+1 and the MFMAs of tile t sit in ONE basic block with
-//     sched_group_barrier hints so the matrix pipe runs under the VALU work of the same wave (the 8
-//     waves of the single resident block move in lock-step, so there is no other wave to hide it).
-// LDS: A hi|lo 2 x 256 x 80 B + B hi|lo 2 x 128 x 80 B = 60 KB per stage, 2 stages = 120 KB, 1 block/CU.
+// Same arithmetic, tile and pipeline as srf_pw_bf16x3_w8_kernel (srf_pwconv_bf16x3.hip), but the weights
+// are split into bf16 hi|lo and laid out tile-by-tile ONCE per forward (srf_pack_pw_weights, one launch
+// for all 1x1 convolutions of the model), so the A operand is a plain 16-B global->LDS copy: the
+// per-k-tile VALU work of a wave drops from ~90 to ~55 instructions and there is no row mask.
+// (A first packed variant with a 256x128 tile / one block per CU measured 220 us vs 152 us and was
+// dropped: lock-step waves cannot hide each other's conversion phase.)
 #include "srf_pw.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int P_BM = 256, P_BN = 128, P_BK = 32;
-constexpr int P_PITCH = 80;                     // LDS row pitch in bytes (64 B data + 16 B pad)
-constexpr int P_AIMG = P_BM * P_PITCH;          // 20480
-constexpr int P_BIMG = P_BN * P_PITCH;          // 10240
-constexpr int P_STAGE = 2 * P_AIMG + 2 * P_BIMG;  // 61440
-// packed weight image of one (m-tile, k-tile): [part hi|lo][256 rows][32 bf16] = 2 * 256 * 64 B
-constexpr int P_WTILE_BYTES = 2 * P_BM * 64;    // 32768
+constexpr int P_BM = 128, P_BN = 128, P_BK = 32;
+// packed weight image of one (m-tile, k-tile): [part hi|lo][128 rows][32 bf16] = 2 * 128 * 64 B
+constexpr int P_WTILE_BYTES = 2 * P_BM * 64;    // 16384
 
 // ---------------------------------------------------------------------------------------------
 // weight packing: W[Cout][Cin] fp32 -> bf16 hi/lo tiles, rows >= Cout zero-filled
@@ -71,7 +59,7 @@ size_t srf_x3p_packed_bytes(int Cout, int Cin) {
 }
 
 bool srf_x3p_supported(int Cin, int Cout, int L) {
-  return (Cin % 64 == 0) && Cin >= 64 && (L % 4 == 0) && Cout >= 192;
+  return (Cin % 64 == 0) && Cin >= 64 && (L % 4 == 0) && Cout >= 64;
 }
 
 // Packs up to SRF_MAX_PACK weight matrices in ONE launch.
@@ -93,6 +81,8 @@ int srf_x3p_pack_launch(const float* const* w, char* const* dst, const int* Cout
 // ---------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ void srf_split8p(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -102,11 +92,15 @@ __device__ __forceinline__ void srf_split8p(const float (&v)[8], bf16x8& hi, bf1
   }
 }
 
+constexpr int P_PITCH_B = 80;
+constexpr int P_IMG = P_BM * P_PITCH_B;     // one [128][32] bf16 image, 80-B row pitch
+constexpr int P_STAGE_B = 4 * P_IMG;        // A_hi, A_lo, B_hi, B_lo
+
 // PRO: 0 = identity, 1 = GlobLN, 2 = GlobLN + PReLU, 3 = PReLU only
-template <int PRO, bool SCHED>
-__global__ __launch_bounds__(512, 2) void srf_pw_x3p_kernel(PwArgs a, const char* __restrict__ wpack, int nMt,
+template <int PRO>
+__global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char* __restrict__ wpack, int nMt,
                                                             int nLt, int total) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * P_STAGE];   // 120 KB
+  __shared__ __attribute__((aligned(16))) char smem[2 * P_STAGE_B];   // exactly 80 KB -> 2 blocks / CU
 
   const int v = srf_xcd_remap(blockIdx.x, total);
   const int mt = v % nMt;
@@ -115,47 +109,43 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3p_kernel(PwArgs a, const char
   const int m0 = mt * P_BM, l0 = lt * P_BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves, 32 x 64 each
 
   float mean = 0.f, rstd = 1.f, slope = 1.f;
   if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
   if (PRO == 2 || PRO == 3) slope = a.nrm.prelu[0];
 
   const int Cin = a.Cin, L = a.L;
-  const int nk = Cin / P_BK;  // even: host checks Cin % 64 == 0
+  const int nk = Cin / P_BK;   // even (host checks Cin % 64 == 0)
   const float* xb = a.x + (size_t)b * Cin * L;
 
-  // ---- staging assignment
-  // A: packed tile (mt, kt) = 2048 x 16-B pieces in [part][row][4] order; thread -> piece tid + 512*i
+  // A: packed tile (mt, kt) = 1024 x 16-B pieces in [part][row][4] order; thread -> pieces tid, tid + 512
+  //    piece p: part = p >> 9, row = (p >> 2) & 127, chunk = p & 3  ->  i = 0: hi image, i = 1: lo image
   const char* a_src = wpack + (size_t)mt * nk * P_WTILE_BYTES + tid * 16;
-  //    LDS offset of piece p = tid + 512*i: part = p >> 10, row = (p >> 2) & 255, chunk = p & 3
-  const int a_lds = ((tid >> 2) & 255) * P_PITCH + (tid & 3) * 16;   // (+ 128 rows for odd i, + image for part)
-  // B: thread -> time step n = tid & 127, k-group kg = tid >> 7 (wave-uniform): 8 k rows x 1 time step
-  const int b_n = tid & 127;
-  const int b_kg = (wave >> 1) * 8;
+  const int a_lds = (tid >> 2) * P_PITCH_B + (tid & 3) * 16;
+  // B: time step n = tid & 127, k-group kg = tid >> 7 (wave-uniform), 8 k rows x 1 time step
+  const int b_n = tid & 127, b_kg = (wave >> 1) * 8;
   const bool b_ok = (l0 + b_n) < L;
-  const float* b_src = xb + (size_t)b_kg * L + (b_ok ? (l0 + b_n) : 0);   // clamped: never stored if !ok
-  const int b_lds = b_n * P_PITCH + b_kg * 2;
+  const float* b_src = xb + (size_t)b_kg * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
+  const int b_lds = b_n * P_PITCH_B + b_kg * 2;
 
   struct Regs {
-    uint4 a[4];
+    uint4 a[2];
     float b[8];
   };
   Regs r0, r1;
   auto gload = [&](Regs& r, int kt) {
     const char* ap = a_src + (size_t)kt * P_WTILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r.a[i] = *reinterpret_cast<const uint4*>(ap + i * 8192);
+    r.a[0] = *reinterpret_cast<const uint4*>(ap);
+    r.a[1] = *reinterpret_cast<const uint4*>(ap + 8192);
     const float* bp = b_src + (size_t)kt * P_BK * L;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r.b[j] = bp[(size_t)j * L];
   };
   auto lds_store = [&](const Regs& r, int stage, int kt) {
-    char* base = smem + stage * P_STAGE;
-    // pieces i = 0..3: p = tid + 512 i -> part = i >> 1, row = (tid >> 2) + 128 * (i & 1)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(base + (i >> 1) * P_AIMG + (i & 1) * 128 * P_PITCH + a_lds) = r.a[i];
+    char* base = smem + stage * P_STAGE_B;
+    *reinterpret_cast<uint4*>(base + 0 * P_IMG + a_lds) = r.a[0];
+    *reinterpret_cast<uint4*>(base + 1 * P_IMG + a_lds) = r.a[1];
     float vb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -170,59 +160,37 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3p_kernel(PwArgs a, const char
     }
     bf16x8 hi, lo;
     srf_split8p(vb, hi, lo);
-    *reinterpret_cast<bf16x8*>(base + 2 * P_AIMG + b_lds) = hi;
-    *reinterpret_cast<bf16x8*>(base + 2 * P_AIMG + P_BIMG + b_lds) = lo;
+    *reinterpret_cast<bf16x8*>(base + 2 * P_IMG + b_lds) = hi;
+    *reinterpret_cast<bf16x8*>(base + 3 * P_IMG + b_lds) = lo;
   };
 
-  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-  const int frag = (lane & 31) * P_PITCH + (lane >> 5) * 16;
-  const int a_row0 = (wm * 64) * P_PITCH + frag, a_row1 = a_row0 + 32 * P_PITCH;
-  const int b_row0 = (wn * 64) * P_PITCH + frag, b_row1 = b_row0 + 32 * P_PITCH;
+  f32x16 acc0 = {0}, acc1 = {0};
+  const int frag = (lane & 31) * P_PITCH_B + (lane >> 5) * 16;
+  const int a_row = (wm * 32) * P_PITCH_B + frag;
+  const int b_row0 = (wn * 64) * P_PITCH_B + frag, b_row1 = b_row0 + 32 * P_PITCH_B;
   auto mma_tile = [&](int stage) {
-    const char* base = smem + stage * P_STAGE;
-    const char* bb = base + 2 * P_AIMG;
+    const char* base = smem + stage * P_STAGE_B;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ko = ks * 32;
-      const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(base + a_row0 + ko);
-      const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(base + a_row1 + ko);
-      const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(base + P_AIMG + a_row0 + ko);
-      const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(base + P_AIMG + a_row1 + ko);
-      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(bb + b_row0 + ko);
-      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(bb + b_row1 + ko);
-      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(bb + P_BIMG + b_row0 + ko);
-      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(bb + P_BIMG + b_row1 + ko);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + 0 * P_IMG + a_row + ko);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + 1 * P_IMG + a_row + ko);
+      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * P_IMG + b_row0 + ko);
+      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * P_IMG + b_row1 + ko);
+      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * P_IMG + b_row0 + ko);
+      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * P_IMG + b_row1 + ko);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
     }
   };
-  // One pipeline step for tile kt (stage kt&1).  `nx` holds tile kt+1 (loaded two steps ago): it is
-  // converted/stored into the other stage, then re-armed with tile kt+3.  Everything is unconditional
-  // (indices clamped; a surplus store lands in the stage nobody reads any more) so that the step is ONE
-  // basic block the scheduler can interleave: MFMA pipe under the VALU/LDS work of the same wave.
   auto step = [&](Regs& nx, int kt) {
-    lds_store(nx, (kt + 1) & 1, min(kt + 1, nk - 1));
+    if (kt + 1 < nk) lds_store(nx, (kt + 1) & 1, kt + 1);
     gload(nx, min(kt + 3, nk - 1));
     mma_tile(kt & 1);
-    if (SCHED) {
-#pragma unroll
-      for (int i = 0; i < 24; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
-        if (i % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 DS write
-        if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
-      }
-    }
     __syncthreads();
   };
 
@@ -236,15 +204,9 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3p_kernel(PwArgs a, const char
     step(r0, kt + 1);
   }
 
-  // ---- epilogue: per-wave LDS strips (8 waves x 2 strips x 32 x 68 floats = 136 KB?  no: one strip
-  // per wave used twice = 8 x 8704 B = 68 KB, inside the dead operand stages)
   float s = 0.f, q = 0.f;
-  const int mb = m0 + wm * 64, lb = l0 + wn * 64;
   float* strip = reinterpret_cast<float*>(smem) + wave * (32 * SRF_EPI_PITCH);
-  srf_pw_epilogue_strip(a, acc00, acc01, strip, b, mb, lb, lane, s, q);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  srf_pw_epilogue_strip(a, acc10, acc11, strip, b, mb + 32, lb, lane, s, q);
+  srf_pw_epilogue_strip(a, acc0, acc1, strip, b, m0 + wm * 32, l0 + wn * 64, lane, s, q);
   __syncthreads();
   if (a.out_sums)
     srf_block_stats_atomic<8>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
@@ -256,20 +218,12 @@ int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   const long total = (long)a.Bt * nMt * nLt;
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
   dim3 grid((unsigned)total), block(512);
-#define X3P_LAUNCH(P, S) \
-  hipLaunchKernelGGL((srf_pw_x3p_kernel<P, S>), grid, block, 0, st, a, wpack, nMt, nLt, (int)total)
-  const bool sched = (srf_debug_flags() & 1) == 0;
-  switch (pro * 2 + (sched ? 1 : 0)) {
-    case 0: X3P_LAUNCH(0, false); break;
-    case 1: X3P_LAUNCH(0, true); break;
-    case 2: X3P_LAUNCH(1, false); break;
-    case 3: X3P_LAUNCH(1, true); break;
-    case 4: X3P_LAUNCH(2, false); break;
-    case 5: X3P_LAUNCH(2, true); break;
-    case 6: X3P_LAUNCH(3, false); break;
-    default: X3P_LAUNCH(3, true); break;
+  switch (pro) {
+    case 0: hipLaunchKernelGGL(srf_pw_x3p_kernel<0>, grid, block, 0, st, a, wpack, nMt, nLt, (int)total); break;
+    case 1: hipLaunchKernelGGL(srf_pw_x3p_kernel<1>, grid, block, 0, st, a, wpack, nMt, nLt, (int)total); break;
+    case 2: hipLaunchKernelGGL(srf_pw_x3p_kernel<2>, grid, block, 0, st, a, wpack, nMt, nLt, (int)total); break;
+    default: hipLaunchKernelGGL(srf_pw_x3p_kernel<3>, grid, block, 0, st, a, wpack, nMt, nLt, (int)total); break;
   }
-#undef X3P_LAUNCH
   SRF_CHECK_LAUNCH("pw_conv_x3p", st);
   return SRF_OK;
 }

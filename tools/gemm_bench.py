@@ -18,7 +18,7 @@ SHAPES = {  # name: (Bt, Cin, Cout, L, prologue, residual, stats, mask)
 
 
 def main():
-    modes = sys.argv[1:] or ["2", "0u", "0s"]   # 0u 8-wave (default), 0w wave-specialised, 0v 4-wave (all unpacked)
+    modes = sys.argv[1:] or ["2", "0u", "0"]   # 0u on-the-fly weights (8-wave), 0 pre-packed weights   # 0u 8-wave (default), 0w wave-specialised, 0v 4-wave (all unpacked)
     out = {}
     for name, (Bt, Cin, Cout, L, pro, res, stats, mask) in SHAPES.items():
         g = torch.Generator(device="cpu").manual_seed(0)
