@@ -130,22 +130,22 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
   const int b_lds = b_n * P_PITCH_B + b_kg * 2;
 
   struct Regs {
-    uint4 a[2];
+    uint4 a0, a1;   // (named members: an array of uint4 here ends up in scratch memory)
     float b[8];
   };
   Regs r0, r1;
   auto gload = [&](Regs& r, int kt) {
     const char* ap = a_src + (size_t)kt * P_WTILE_BYTES;
-    r.a[0] = *reinterpret_cast<const uint4*>(ap);
-    r.a[1] = *reinterpret_cast<const uint4*>(ap + 8192);
+    r.a0 = *reinterpret_cast<const uint4*>(ap);
+    r.a1 = *reinterpret_cast<const uint4*>(ap + 8192);
     const float* bp = b_src + (size_t)kt * P_BK * L;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r.b[j] = bp[(size_t)j * L];
   };
   auto lds_store = [&](const Regs& r, int stage, int kt) {
     char* base = smem + stage * P_STAGE_B;
-    *reinterpret_cast<uint4*>(base + 0 * P_IMG + a_lds) = r.a[0];
-    *reinterpret_cast<uint4*>(base + 1 * P_IMG + a_lds) = r.a[1];
+    *reinterpret_cast<uint4*>(base + 0 * P_IMG + a_lds) = r.a0;
+    *reinterpret_cast<uint4*>(base + 1 * P_IMG + a_lds) = r.a1;
     float vb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
