@@ -81,7 +81,7 @@ int srf_x3p_pack_launch(const float* const* w, char* const* dst, const int* Cout
 // ---------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // first-class 16-B value (HIP uint4 is a struct)
 
 __device__ __forceinline__ void srf_split8p(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -130,22 +130,22 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
   const int b_lds = b_n * P_PITCH_B + b_kg * 2;
 
   struct Regs {
-    uint4 a0, a1;   // (named members: an array of uint4 here ends up in scratch memory)
+    u32x4 a0, a1;   // (clang ext-vectors: HIP's uint4 struct ended up in scratch memory here)
     float b[8];
   };
   Regs r0, r1;
   auto gload = [&](Regs& r, int kt) {
     const char* ap = a_src + (size_t)kt * P_WTILE_BYTES;
-    r.a0 = *reinterpret_cast<const uint4*>(ap);
-    r.a1 = *reinterpret_cast<const uint4*>(ap + 8192);
+    r.a0 = *reinterpret_cast<const u32x4*>(ap);
+    r.a1 = *reinterpret_cast<const u32x4*>(ap + 8192);
     const float* bp = b_src + (size_t)kt * P_BK * L;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r.b[j] = bp[(size_t)j * L];
   };
   auto lds_store = [&](const Regs& r, int stage, int kt) {
     char* base = smem + stage * P_STAGE_B;
-    *reinterpret_cast<uint4*>(base + 0 * P_IMG + a_lds) = r.a0;
-    *reinterpret_cast<uint4*>(base + 1 * P_IMG + a_lds) = r.a1;
+    *reinterpret_cast<u32x4*>(base + 0 * P_IMG + a_lds) = r.a0;
+    *reinterpret_cast<u32x4*>(base + 1 * P_IMG + a_lds) = r.a1;
     float vb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
