@@ -342,6 +342,141 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
                               reinterpret_cast<double*>(smem));
 }
 
+// 8-wave kernel with a deeper activation prefetch (see RA/RB below); used when Cin % 128 == 0.
+template <int PRO>
+__global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8d_kernel(PwArgs a, int nMt, int nLt, int total) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
+
+  const int v = srf_xcd_remap(blockIdx.x, total);
+  const int mt = v % nMt;
+  const int lt = (v / nMt) % nLt;
+  const long b = v / (nMt * nLt);
+  const int m0 = mt * X3_BM, l0 = lt * X3_BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves, 32 x 64 each
+
+  float mean = 0.f, rstd = 1.f, slope = 1.f;
+  if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
+  if (PRO == 2 || PRO == 3) slope = a.nrm.prelu[0];
+
+  const int Cin = a.Cin, L = a.L, Cout = a.Cout;
+  const int nk_ = Cin / X3_BK;   // even (host checks Cin % 64 == 0)
+  const float* xb = a.x + (size_t)b * Cin * L;
+
+  // A (weights [m][k]): thread -> row m = tid>>2, 8-k packet pk = tid&3 (2 float4 = 32 B; a wavefront
+  // covers 16 rows x 128 B = whole cache lines)
+  const int a_m = tid >> 2, a_pk = tid & 3;
+  const bool a_ok = (m0 + a_m) < Cout;
+  const float* a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_pk * 8;
+  const float a_msk = a_ok ? 1.f : 0.f;
+  const int a_lds = a_m * X3_PITCH + a_pk * 16;
+  // B (X_b [k][time]): thread -> time step n = tid&127, k-group kg = tid>>7 (wave-uniform), 8 k rows
+  const int b_n = tid & 127, b_kg = (wave >> 1) * 8;
+  const bool b_ok = (l0 + b_n) < L;
+  const float* b_src = xb + (size_t)b_kg * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
+  const int b_lds = b_n * X3_PITCH + b_kg * 2;
+
+  // A (weights, L2-resident) is prefetched 2 k-tiles ahead, B (activations, first touch comes from
+  // HBM) 4 k-tiles ahead: separate register rings (2 x 8 + 4 x 8 VGPRs)
+  struct RA {
+    float4 a[2];
+  };
+  struct RB {
+    float b[8];
+  };
+  RA ra0, ra1;
+  RB rb0, rb1, rb2, rb3;
+  auto gload_a = [&](RA& r, int k0) {
+    r.a[0] = *reinterpret_cast<const float4*>(a_src + k0);
+    r.a[1] = *reinterpret_cast<const float4*>(a_src + k0 + 4);
+  };
+  auto gload_b = [&](RB& r, int k0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.b[j] = b_src[(size_t)(k0 + j) * L];
+  };
+  auto lds_store = [&](const RA& ra, const RB& rb, int stage, int k0) {
+    char* base = smem + stage * X3_STAGE;
+    const float va[8] = {ra.a[0].x * a_msk, ra.a[0].y * a_msk, ra.a[0].z * a_msk, ra.a[0].w * a_msk,
+                         ra.a[1].x * a_msk, ra.a[1].y * a_msk, ra.a[1].z * a_msk, ra.a[1].w * a_msk};
+    bf16x8 hi, lo;
+    srf_split8(va, hi, lo);
+    *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + a_lds) = hi;
+    *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + a_lds) = lo;
+    float vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x0 = rb.b[j];
+      if (PRO == 1 || PRO == 2) {
+        const int k = k0 + b_kg + j;
+        const float sc = a.nrm.gamma[k] * rstd;
+        x0 = fmaf(x0, sc, a.nrm.beta[k] - mean * sc);
+      }
+      if (PRO == 2 || PRO == 3) x0 = srf_prelu(x0, slope);
+      vb[j] = x0;
+    }
+    srf_split8(vb, hi, lo);
+    *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + b_lds) = hi;
+    *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + b_lds) = lo;
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  const int frag = (lane & 31) * X3_PITCH + (lane >> 5) * 16;
+  const int a_row = (wm * 32) * X3_PITCH + frag;
+  const int b_row0 = (wn * 64) * X3_PITCH + frag, b_row1 = b_row0 + 32 * X3_PITCH;
+  auto mma_tile = [&](int stage) {
+    const char* base = smem + stage * X3_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ko = ks * 32;
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row + ko);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row + ko);
+      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row0 + ko);
+      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
+      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
+      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
+    }
+  };
+  auto step = [&](RA& na, RB& nb, int kt) {   // na/nb hold tile kt+1
+    if (kt + 1 < nk_) lds_store(na, nb, (kt + 1) & 1, (kt + 1) * X3_BK);
+    gload_a(na, min(kt + 3, nk_ - 1) * X3_BK);
+    gload_b(nb, min(kt + 5, nk_ - 1) * X3_BK);
+    mma_tile(kt & 1);
+    __syncthreads();
+  };
+
+  gload_a(ra0, 0);
+  gload_b(rb0, 0);
+  gload_a(ra1, X3_BK);
+  gload_b(rb1, X3_BK);
+  gload_b(rb2, min(2, nk_ - 1) * X3_BK);
+  gload_b(rb3, min(3, nk_ - 1) * X3_BK);
+  lds_store(ra0, rb0, 0, 0);
+  gload_a(ra0, min(2, nk_ - 1) * X3_BK);
+  gload_b(rb0, min(4, nk_ - 1) * X3_BK);
+  __syncthreads();
+  for (int kt = 0; kt < nk_; kt += 4) {   // host guarantees nk % 4 == 0
+    step(ra1, rb1, kt);
+    step(ra0, rb2, kt + 1);
+    step(ra1, rb3, kt + 2);
+    step(ra0, rb0, kt + 3);
+  }
+
+  float s = 0.f, q = 0.f;
+  float* strip = reinterpret_cast<float*>(smem) + wave * (32 * SRF_EPI_PITCH);
+  srf_pw_epilogue_strip(a, acc0, acc1, strip, b, m0 + wm * 32, l0 + wn * 64, lane, s, q);
+  __syncthreads();
+  if (a.out_sums)
+    srf_block_stats_atomic<8>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
+                              reinterpret_cast<double*>(smem));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave-specialised variant (debug flag 4; measured 165 us vs 152 us for the symmetric 8-wave kernel on
 // the proj_1x1 shape -- kept for A/B): the ablation of the kernels above showed time ~ SUM of
@@ -532,6 +667,16 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
         default: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 15>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
       }
       SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8_ablated", st);
+      return SRF_OK;
+    }
+    if ((a.Cin % 128) == 0 && !(srf_debug_flags() & 512)) {   // deeper activation prefetch
+      switch (pro) {
+        case 0: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<0>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        case 1: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<1>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        case 2: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<2>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        default: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<3>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+      }
+      SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8", st);
       return SRF_OK;
     }
     switch (pro) {
