@@ -74,7 +74,7 @@ __device__ __forceinline__ void srf_pw_epilogue_strip(const PwArgs& a, const f32
       v.z += rv.z;
       v.w += rv.w;
     }
-    if (a.epi_mask) {
+    if (a.epi_mask & 1) {
       const float4 e = *reinterpret_cast<const float4*>(a.mul + ((size_t)b * mulC + (mc % mulC)) * a.L + lc);
       v.x = fmaxf(v.x, 0.f) * e.x;
       v.y = fmaxf(v.y, 0.f) * e.y;

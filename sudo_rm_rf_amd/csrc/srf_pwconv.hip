@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void srf_pw_generic_kernel(PwArgs a) {
       const size_t idx = ((size_t)b * a.Cout + m) * a.L + l;
       float v = acc[i] + a.bias[m];
       if (a.residual) v += a.residual[idx];
-      if (a.epi_mask)
+      if (a.epi_mask & 1)
         v = fmaxf(v, 0.f) * a.mul[((size_t)b * a.mul_channels + (m % a.mul_channels)) * a.L + l];
       a.y[idx] = v;
       ds += (double)v;
@@ -256,6 +256,8 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
   a.Bt = Bt;
   a.mul_channels = mul_channels > 0 ? mul_channels : 1;
   a.epi_mask = epilogue_mask ? 1 : 0;
+  // bits 1..: start-up stagger of the split-bf16 kernel (debug flags bits 20..23 = number of s_sleep(127))
+  if ((srf_debug_flags() >> 20) & 15) a.epi_mask |= 2 | (((srf_debug_flags() >> 20) & 15) << 2);
   if (a.nrm.sums) SRF_CHECK_ARG(a.nrm.gamma && a.nrm.beta, "srf_pw_conv: norm without gamma/beta");
   hipStream_t st = (hipStream_t)stream;
 

@@ -215,6 +215,12 @@ template <int PRO, int ABL = 0>
 __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int nMt, int nLt, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
 
+  // Stagger: all resident blocks start together and have identical durations, so the whole chip runs
+  // its main loops (HBM nearly idle) and then its epilogues (a 6 TB/s write burst, matrix pipes idle)
+  // in lock-step.  Delaying every other group of blocks by about half a block time once de-phases them.
+  if ((a.epi_mask & 2) && ((blockIdx.x >> 3) & 1)) {
+    for (int i = 0; i < (a.epi_mask >> 2); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int v = srf_xcd_remap(blockIdx.x, total);
   const int mt = v % nMt;
   const int lt = (v / nMt) % nLt;
@@ -655,7 +661,7 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
   }
   if ((srf_debug_flags() & 2) == 0) {   // default: 8-wave variant (flag 2: 4-wave variant)
     dim3 grid8((unsigned)total), block8(512);
-    const int abl = (srf_debug_flags() >> 8) & 15;   // diagnostics: ablated pipelines (PRO 0 only)
+    const int abl = (srf_debug_flags() >> 16) & 15;   // diagnostics: ablated pipelines (PRO 0 only)
     if (abl && pro == 0) {
       switch (abl) {
         case 1: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 1>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
@@ -669,7 +675,7 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
       SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8_ablated", st);
       return SRF_OK;
     }
-    if ((a.Cin % 128) == 0 && !(srf_debug_flags() & 512)) {   // deeper activation prefetch
+    if ((a.Cin % 128) == 0 && (srf_debug_flags() & 1024)) {   // deeper activation prefetch: measured no gain
       switch (pro) {
         case 0: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<0>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
         case 1: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<1>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;

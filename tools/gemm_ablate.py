@@ -14,7 +14,7 @@ _o.pack_pw_weight = lambda w_: None
 names = {0: "full", 1: "no A loads", 2: "no B loads", 3: "no loads", 4: "no MFMA", 8: "no convert/store",
          12: "no MFMA, no convert", 15: "barriers + epilogue only"}
 for abl, nm in names.items():
-    ops.set_debug_flags(abl << 8)
+    ops.set_debug_flags(abl << 16)
     ops.pw_conv(x, w, bias); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
