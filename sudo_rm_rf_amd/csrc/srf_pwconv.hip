@@ -207,6 +207,8 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st);
 int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
 size_t srf_x3p_packed_bytes(int Cout, int Cin);
 bool srf_x3p_supported(int Cin, int Cout, int L);
+int srf_pw_small_launch(const PwArgs& a, hipStream_t st);
+bool srf_pw_small_supported(int Cin, int Cout, int L);
 int srf_x3p_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n,
                         hipStream_t st);
 
@@ -256,8 +258,6 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
   a.Bt = Bt;
   a.mul_channels = mul_channels > 0 ? mul_channels : 1;
   a.epi_mask = epilogue_mask ? 1 : 0;
-  // bits 1..: start-up stagger of the split-bf16 kernel (debug flags bits 20..23 = number of s_sleep(127))
-  if ((srf_debug_flags() >> 20) & 15) a.epi_mask |= 2 | (((srf_debug_flags() >> 20) & 15) << 2);
   if (a.nrm.sums) SRF_CHECK_ARG(a.nrm.gamma && a.nrm.beta, "srf_pw_conv: norm without gamma/beta");
   hipStream_t st = (hipStream_t)stream;
 
@@ -265,6 +265,10 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
   const bool mfma_ok = mode != 1 && (Cin % PW_BK == 0) && (L % 4 == 0) && Cout >= 32 && Cin >= 32 &&
                        srf_aligned16(x) && srf_aligned16(w);
   const int pro_sel = a.nrm.sums ? (a.nrm.prelu ? 2 : 1) : (a.nrm.prelu ? 3 : 0);
+  // GroupComm's per-group convs (<= 32 -> <= 64 channels): register-resident streaming kernel
+  if (mode != 1 && !(a.epi_mask & 1) && srf_pw_small_supported(Cin, Cout, L) && srf_aligned16(x) &&
+      srf_aligned16(y) && (!residual || srf_aligned16(residual)))
+    return srf_pw_small_launch(a, st);
   if (mfma_ok && mode == 0 && w_packed && srf_x3p_supported(Cin, Cout, L) && srf_aligned16(w_packed))
     return srf_pw_x3p_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
   if (mfma_ok && mode == 0 && (Cin % 64 == 0)) return srf_pw_bf16x3_launch(a, pro_sel, st);

@@ -215,12 +215,6 @@ template <int PRO, int ABL = 0>
 __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int nMt, int nLt, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
 
-  // Stagger: all resident blocks start together and have identical durations, so the whole chip runs
-  // its main loops (HBM nearly idle) and then its epilogues (a 6 TB/s write burst, matrix pipes idle)
-  // in lock-step.  Delaying every other group of blocks by about half a block time once de-phases them.
-  if ((a.epi_mask & 2) && ((blockIdx.x >> 3) & 1)) {
-    for (int i = 0; i < (a.epi_mask >> 2); ++i) __builtin_amdgcn_s_sleep(127);
-  }
   const int v = srf_xcd_remap(blockIdx.x, total);
   const int mt = v % nMt;
   const int lt = (v / nMt) % nLt;

@@ -100,6 +100,189 @@ __global__ __launch_bounds__(128) void srf_tac_kernel(TacArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Group-per-lane kernel (G in {2,4,8,16}, n <= 16).  lane = c*G + g: a wavefront holds 64/G time steps
+// x all G groups, so the mean over groups is a butterfly of DPP row operations (VALU only, no LDS, no
+// barrier), z_g stays in registers between the two sweeps (no recompute), the H x H "mean" layer is
+// SPLIT over the G lanes of a column (lane g owns ceil(H/G) hidden units; its slice of Wm / Wo[:, H:]
+// comes from an LDS copy staged once per block) and the per-column vector r is all-reduced the same way.
+// Per (column, group): n*H + H*n MACs with wave-uniform scalar weights + ~H^2/G with per-lane weights,
+// against 3*n*H + (H^2 + H*n)/G... for the column-per-lane kernel above, which also ran at 1.6
+// wavefronts per SIMD on the headline shape (B*L = 102400 columns).
+// Global accesses are (64/G)*4-byte segments per group row; neighbouring wavefronts of the block use the
+// rest of each cache line.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float srf_dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+// sum over the aligned group of G lanes, result in every lane (bitwise identical across the group)
+template <int G>
+__device__ __forceinline__ float srf_group_allsum(float v) {
+  if (G >= 2) v += srf_dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (G >= 4) v += srf_dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (G >= 8) v += srf_dpp_mov<0x141>(v);   // row_half_mirror
+  if (G >= 16) v += srf_dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
+template <int NN, int G>
+__global__ __launch_bounds__(256) void srf_tac_lanes_kernel(
+    TacArgs a, int tiles_per_block,
+    // the weights again as noalias kernel arguments: only then does the compiler know the stores to q
+    // cannot clobber them and fetch them with scalar loads (s_load -> SGPR operands) instead of per-lane
+    // VMEM loads (measured in the ISA: 431 global_load + 654 v_mov per tile without this)
+    const float* __restrict__ wi, const float* __restrict__ bi, const float* __restrict__ wo,
+    const float* __restrict__ bo) {
+  constexpr int HH = 3 * NN, CW = 64 / G, JPL = (HH + G - 1) / G;
+  constexpr int PM = HH + 4, PO = NN + 4;   // LDS row pitches (floats), 16-B aligned rows
+  __shared__ __attribute__((aligned(16))) float s_wm[HH * PM];   // Wm[j][i]
+  __shared__ __attribute__((aligned(16))) float s_wq[HH * PO];   // Wo[i][H + j] stored as [j][i]
+  __shared__ float s_bm[HH];
+  __shared__ float s_red[4][G][2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane & (G - 1), c = lane / G;
+  const long b = blockIdx.y;
+  const int L = a.L;
+  for (int e = tid; e < HH * HH; e += 256) s_wm[(e / HH) * PM + (e % HH)] = a.wm[e];
+  for (int e = tid; e < HH * NN; e += 256) {
+    const int j = e / NN, i = e % NN;
+    s_wq[j * PO + i] = a.wo[i * 2 * HH + HH + j];
+  }
+  for (int e = tid; e < HH; e += 256) s_bm[e] = a.bm[e];
+  __syncthreads();
+
+  const float ai = a.ai[0], am = a.am[0], ao = a.ao[0];
+  const float* xb = a.x + ((size_t)b * G + g) * NN * L;
+  float* qb = a.q + ((size_t)b * G + g) * NN * L;
+  float ss = 0.f, sq = 0.f;
+
+  for (int it = 0; it < tiles_per_block; ++it) {
+    const int l0 = ((blockIdx.x * tiles_per_block + it) * 4 + wave) * CW;   // wave-uniform
+    if (l0 >= L) break;
+    const int l = l0 + c;
+    const bool valid = l < L;
+    const int lc = valid ? l : L - 1;
+
+    float x[NN];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) x[i] = xb[(size_t)i * L + lc];
+
+    // z_g = PReLU(Wi x_g + bi); zbar = mean_g z_g is consumed on the fly by this lane's JPL rows of Wm
+    float z[HH], qacc[JPL];
+#pragma unroll
+    for (int t = 0; t < JPL; ++t) qacc[t] = 0.f;
+    const int jrow = g * JPL;
+#pragma unroll
+    for (int j = 0; j < HH; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) t = fmaf(wi[j * NN + i], x[i], t);
+      z[j] = srf_prelu(t + bi[j], ai);
+      const float zb = srf_group_allsum<G>(z[j]) * (1.f / (float)G);
+#pragma unroll
+      for (int t2 = 0; t2 < JPL; ++t2) {
+        const int jr = jrow + t2 < HH ? jrow + t2 : HH - 1;
+        qacc[t2] = fmaf(s_wm[jr * PM + j], zb, qacc[t2]);
+      }
+    }
+
+    // this lane's slice of q = PReLU(Wm zbar + bm) and of r = Wo[:, H:2H] q
+    float r[NN];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) r[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < JPL; ++t) {
+      const bool jm = jrow + t < HH;
+      const int jc = jm ? jrow + t : HH - 1;
+      float qv = srf_prelu(qacc[t] + s_bm[jc], am);
+      qv = jm ? qv : 0.f;
+      const float* wq = s_wq + jc * PO;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) r[i] = fmaf(wq[i], qv, r[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NN; ++i) r[i] = srf_group_allsum<G>(r[i]);
+
+    // o_g = PReLU(Wo[:, :H] z_g + r + bo)
+#pragma unroll
+    for (int i = 0; i < NN; ++i) {
+      float o = 0.f;
+#pragma unroll
+      for (int j = 0; j < HH; ++j) o = fmaf(wo[i * 2 * HH + j], z[j], o);
+      const float v = srf_prelu((o + r[i]) + bo[i], ao);
+      if (valid) {
+        qb[(size_t)i * L + l] = v;
+        ss += v;
+        sq = fmaf(v, v, sq);
+      }
+    }
+  }
+
+  if (a.out_sums) {
+    // lanes that share g: c = 0..CW-1 -> xor over the lane bits above log2(G)
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+      ss += __shfl_xor(ss, o, 64);
+      sq += __shfl_xor(sq, o, 64);
+    }
+    if (lane < G) {
+      s_red[wave][lane][0] = ss;
+      s_red[wave][lane][1] = sq;
+    }
+    __syncthreads();
+    if (tid < G) {
+      double ds = 0.0, dq = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        ds += (double)s_red[w][tid][0];
+        dq += (double)s_red[w][tid][1];
+      }
+      double* dst = srf_stat_slot(a.out_sums, b * G + tid, blockIdx.x);
+      atomicAdd(dst, ds);
+      atomicAdd(dst + 1, dq);
+    }
+  }
+}
+
+template <int NN, int G>
+static void srf_tac_lanes_go(const TacArgs& a, int Bt, hipStream_t st) {
+  constexpr int CW = 64 / G;
+  const int tiles = (a.L + 4 * CW - 1) / (4 * CW);   // block-tiles (4 wavefronts x CW columns) per row
+  // enough blocks to keep >= ~8 per CU in flight, otherwise fold tiles into one block (fewer atomics,
+  // weight staging amortised)
+  int tpb = 1;
+  while (tpb < 8 && (long)Bt * (tiles / (tpb * 2)) >= 8 * 256) tpb *= 2;
+  if (srf_debug_flags() & (1 << 25)) tpb = 1;
+  if (srf_debug_flags() & (1 << 26)) tpb = 4;
+  dim3 grid((tiles + tpb - 1) / tpb, Bt), block(256);
+  hipLaunchKernelGGL((srf_tac_lanes_kernel<NN, G>), grid, block, 0, st, a, tpb, a.wi, a.bi, a.wo, a.bo);
+}
+
+template <int NN>
+static bool srf_tac_lanes_g(const TacArgs& a, int Bt, hipStream_t st) {
+  switch (a.G) {
+    case 2: srf_tac_lanes_go<NN, 2>(a, Bt, st); return true;
+    case 4: srf_tac_lanes_go<NN, 4>(a, Bt, st); return true;
+    case 8: srf_tac_lanes_go<NN, 8>(a, Bt, st); return true;
+    case 16: srf_tac_lanes_go<NN, 16>(a, Bt, st); return true;
+    default: return false;
+  }
+}
+
+static bool srf_tac_lanes_launch(const TacArgs& a, int n, int Bt, hipStream_t st) {
+  switch (n) {
+    case 2: return srf_tac_lanes_g<2>(a, Bt, st);
+    case 4: return srf_tac_lanes_g<4>(a, Bt, st);
+    case 8: return srf_tac_lanes_g<8>(a, Bt, st);
+    case 16: return srf_tac_lanes_g<16>(a, Bt, st);
+    default: return false;
+  }
+}
+
 extern "C" int srf_tac(const float* x, float* q, const float* const* params, int Bt, int G, int n, int H,
                        int L, double* out_sums, void* stream) {
   SRF_CHECK_ARG(x && q && params, "srf_tac: null pointer");
@@ -123,6 +306,10 @@ extern "C" int srf_tac(const float* x, float* q, const float* const* params, int
   a.L = L;
   dim3 grid((L + 127) / 128, Bt), block(128);
   hipStream_t st = (hipStream_t)stream;
+  if (srf_kernel_mode() != 1 && !(srf_debug_flags() & (1 << 24)) && srf_tac_lanes_launch(a, n, Bt, st)) {
+    SRF_CHECK_LAUNCH("tac", st);
+    return SRF_OK;
+  }
   switch (n) {
     case 2: hipLaunchKernelGGL(srf_tac_kernel<2>, grid, block, 0, st, a); break;
     case 4: hipLaunchKernelGGL(srf_tac_kernel<4>, grid, block, 0, st, a); break;

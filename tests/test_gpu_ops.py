@@ -105,7 +105,11 @@ PW_SHAPES = [  # Bt, Cin, Cout, L
     (2, 512, 256, 800),    # res_conv-like
     (1, 64, 42, 200),      # partial M tile (decoder frame GEMM shape), partial N tile
     (3, 48, 160, 132),     # nothing a multiple of the tile
-    (4, 16, 32, 404),      # GroupComm per-group shape (generic kernel)
+    (4, 16, 32, 404),      # GroupComm per-group shapes (register-resident streaming kernel)
+    (3, 32, 16, 1000),
+    (2, 8, 64, 64),
+    (2, 32, 64, 260),
+    (2, 16, 32, 402),      # same channels, L % 4 != 0 -> generic kernel
     (2, 24, 20, 50),       # generic: Cin not multiple of 16, L not multiple of 4
 ]
 
@@ -260,8 +264,20 @@ def test_decoder(mode, Bt, Ci, Co, K, L, T):
     check(got, want, 3e-5, "decoder")
 
 
-@pytest.mark.parametrize("Bt,G,n,L", [(2, 16, 16, 300), (1, 4, 8, 77), (2, 8, 4, 130), (1, 2, 32, 64)])
-def test_tac(Bt, G, n, L):
+@pytest.mark.parametrize("flags", [0, 1 << 26, 1 << 24], ids=["lanes", "lanes-4tiles", "columns"])
+@pytest.mark.parametrize("Bt,G,n,L", [(2, 16, 16, 300), (1, 4, 8, 77), (2, 8, 4, 130), (1, 2, 32, 64),
+                                      (3, 16, 16, 1601), (2, 4, 4, 100), (2, 2, 2, 70), (1, 8, 16, 50),
+                                      (2, 16, 8, 64), (1, 16, 2, 33), (1, 3, 4, 40)])
+def test_tac(Bt, G, n, L, flags):
+    from sudo_rm_rf_amd import ops
+    ops.set_debug_flags(flags)
+    try:
+        _tac_case(Bt, G, n, L)
+    finally:
+        ops.set_debug_flags(0)
+
+
+def _tac_case(Bt, G, n, L):
     from sudo_rm_rf_amd import ops
     H = 3 * n
     x = rnd(Bt, G, n, L, seed=80)
