@@ -112,7 +112,8 @@ def pmc_traffic(kernel_family, workload):
     path = os.path.join(ROOT, "profiles", "r01_cfg2_bs32_pmc_hbm_traffic.csv")
     if workload != "cfg2_improved_u16" or not os.path.exists(path):
         return {"traffic": None}
-    key = {"pw_conv_bf16x3_w8": "srf_pw_bf16x3_w8_kernel", "pw_conv_mfma": "srf_pw_mfma_kernel",
+    key = {"pw_conv_bf16x3_w8": "srf_pw_bf16x3_w8_kernel", "pw_conv_bf16x3_p8": "srf_pw_bf16x3_p8_kernel",
+           "pw_conv_mfma": "srf_pw_mfma_kernel",
            "pyramid_moments": "srf_pyramid_reg_kernel<true", "pyramid_merge": "srf_pyramid_reg_kernel<false"
            }.get(kernel_family, kernel_family)
     fetch, write = {}, {}

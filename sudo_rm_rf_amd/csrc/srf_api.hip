@@ -350,10 +350,12 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
                             0, nullptr, 0, stream);
     if (rc) return rc;
     // depthwise pyramid + upsample/add                         :206-216
-    float* merged = y1;   // the merged tensor aliases y1 (dead once every level has been produced)
+    // unfused path: the merged tensor aliases y1 (dead once every level has been produced); fused path:
+    // its own buffer (the otherwise unused level-0 buffer), because pass 2 re-reads y1 with halos
     const bool fused = p->fused_pyramid && srf_kernel_mode() != 1 && !(srf_debug_flags() & 16);
+    float* merged = fused ? fptr(p->off_lv[0]) : y1;
     if (fused) {
-      // two passes with every level kept on chip (srf_pyramid.hip); merged aliases y1 (allowed)
+      // two passes with every level kept on chip (srf_pyramid.hip)
       const float *pw[SRF_MAX_DEPTH], *pb[SRF_MAX_DEPTH], *pg[SRF_MAX_DEPTH], *pbe[SRF_MAX_DEPTH];
       for (int k = 0; k < D; ++k) {
         const float* const* Pk = Pu + 5 + 4 * k;

@@ -215,6 +215,12 @@ template <int PRO, int ABL = 0>
 __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int nMt, int nLt, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
 
+  // first-round blocks only: de-phase the chip (see the persistent kernel below); epi_mask bits 8..
+  if ((a.epi_mask >> 8) && blockIdx.x < 512) {
+    const int units = (a.epi_mask >> 8) & 15, four = (a.epi_mask >> 12) & 1;
+    const int phase = four ? ((blockIdx.x >> 3) & 3) : 2 * ((blockIdx.x >> 3) & 1);
+    for (int i = 0; i < units * phase; ++i) __builtin_amdgcn_s_sleep(64);   // ~4K cycles each
+  }
   const int v = srf_xcd_remap(blockIdx.x, total);
   const int mt = v % nMt;
   const int lt = (v / nMt) % nLt;
@@ -223,6 +229,23 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves, 32 x 64 each
+
+  // ABL & 16: in-kernel timeline (diagnostics).  Lane i of every wavefront keeps the i-th s_memtime
+  // stamp; the 64 stamps go to the buffer passed in a.mul.  Per k-tile: after the barrier, after the
+  // prefetched operands have landed, after split + LDS stores, after LDS reads + MFMA issue.
+  unsigned tsv = 0;
+  int tsi = 0;
+  const unsigned rt0 = (ABL & 16) ? (unsigned)__builtin_amdgcn_s_memrealtime() : 0u;   // constant 100 MHz
+  auto stamp = [&]() {
+    if (ABL & 16) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+      tsv = (lane == tsi) ? t : tsv;
+      ++tsi;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stamp();
 
   float mean = 0.f, rstd = 1.f, slope = 1.f;
   if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
@@ -271,8 +294,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
                          r.a[1].x * a_msk, r.a[1].y * a_msk, r.a[1].z * a_msk, r.a[1].w * a_msk};
     bf16x8 hi, lo;
     srf_split8(va, hi, lo);
-    *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + a_lds) = hi;
-    *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + a_lds) = lo;
     float vb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -285,9 +306,16 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
       if (PRO == 2 || PRO == 3) x0 = srf_prelu(x0, slope);
       vb[j] = x0;
     }
-    srf_split8(vb, hi, lo);
-    *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + b_lds) = hi;
-    *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + b_lds) = lo;
+    bf16x8 hib, lob;
+    srf_split8(vb, hib, lob);
+    if (ABL & 16) {
+      asm volatile("" ::"v"(hi), "v"(lo), "v"(hib), "v"(lob));
+      stamp();
+    }
+    *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + a_lds) = hi;
+    *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + a_lds) = lo;
+    *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + b_lds) = hib;
+    *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + b_lds) = lob;
   };
 
   f32x16 acc0 = {0}, acc1 = {0};
@@ -305,6 +333,10 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
       const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
       const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
       const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
+      if ((ABL & 16) && ks == 0) {
+        asm volatile("" ::"v"(ah), "v"(al), "v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
+        stamp();
+      }
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
@@ -314,9 +346,18 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
     }
   };
   auto step = [&](Regs& nx, int kt) {
+    stamp();
+    if (ABL & 16) {
+      asm volatile("" ::"v"(nx.a[0].x), "v"(nx.a[0].w), "v"(nx.a[1].x), "v"(nx.a[1].w), "v"(nx.b[0]), "v"(nx.b[1]),
+                   "v"(nx.b[2]), "v"(nx.b[3]), "v"(nx.b[4]), "v"(nx.b[5]), "v"(nx.b[6]), "v"(nx.b[7]));
+      stamp();
+    }
     if (!(ABL & 8) && kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
+    stamp();
     gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
+    stamp();
     if (!(ABL & 4)) mma_tile(kt & 1);
+    stamp();
     __syncthreads();
   };
 
@@ -325,21 +366,32 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
   lds_store(r0, 0, 0);
   gload(r0, min(2, nk_ - 1) * X3_BK);
   __syncthreads();
+  stamp();
   for (int kt = 0; kt < nk_; kt += 2) {
     step(r1, kt);
     step(r0, kt + 1);
   }
+  stamp();
   if (ABL) {   // keep everything the ablated pipeline produced alive
     asm volatile("" ::"v"(r0.a[0].x), "v"(r1.a[0].x), "v"(r0.b[0]), "v"(r1.b[0]), "v"(r0.a[1].w), "v"(r1.b[7]));
   }
 
   float s = 0.f, q = 0.f;
   float* strip = reinterpret_cast<float*>(smem) + wave * (32 * SRF_EPI_PITCH);
-  srf_pw_epilogue_strip(a, acc0, acc1, strip, b, m0 + wm * 32, l0 + wn * 64, lane, s, q);
+  srf_pw_epilogue_strip(a, acc0, acc1, strip, b, m0 + wm * 32, (ABL & 32) ? a.L : l0 + wn * 64, lane, s, q);
   __syncthreads();
   if (a.out_sums)
     srf_block_stats_atomic<8>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
                               reinterpret_cast<double*>(smem));
+  if (ABL & 16) {
+    stamp();
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+    const unsigned rt1 = (unsigned)__builtin_amdgcn_s_memrealtime();
+    tsv = lane == 62 ? hw : (lane == 63 ? xcc : tsv);
+    tsv = lane == 60 ? rt0 : (lane == 61 ? rt1 : tsv);
+    reinterpret_cast<unsigned*>(const_cast<float*>(a.mul))[((size_t)blockIdx.x * 8 + wave) * 64 + lane] = tsv;
+  }
 }
 
 // 8-wave kernel with a deeper activation prefetch (see RA/RB below); used when Cin % 128 == 0.
@@ -638,6 +690,248 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_ws_kernel(PwArgs a, int 
                               reinterpret_cast<double*>(smem));
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Persistent 8-wave kernel.  In-kernel timeline of the kernel above (tools/gemm_timeline.py, proj_1x1):
+// a block spends ~14 % of its life in the prologue (first operands from HBM), ~60 % in the k-loop and
+// ~26 % in the epilogue, where every resident block of the chip writes its 64 KB at the same moment
+// (the launch without its stores runs in 120 us instead of 161 us).  Here 2 blocks per CU stay
+// resident and walk over tiles: the operand pipeline (global loads 2-3 k-tiles ahead, split + LDS
+// store 1 ahead) runs straight across tile boundaries, so the next tile's first operands arrive under
+// the current tile's MFMAs, and the epilogue's global stores are issued and left in flight while the
+// next tile's k-loop runs.  The epilogue strip lives in the LDS stage the last k-tile has just freed
+// (two 32x32 halves per wavefront, 36.9 KB), the other stage already holds the next tile's k-tile 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int SRF_EPI_PITCH_H = 36;
+
+// one 32x32 accumulator tile -> rows x 128 B float4 stores (see srf_pw_epilogue_strip)
+__device__ __forceinline__ void srf_pw_epilogue_half(const PwArgs& a, const f32x16& acc, float* strip, long b,
+                                                     int m_base, int l_base, int lane, float& s, float& q) {
+  const int col = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+    strip[row * SRF_EPI_PITCH_H + col] = acc[r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int c4 = (lane & 7) * 4;
+  const int l = l_base + c4;
+  const bool l_ok = l < a.L;
+  const size_t lc = l_ok ? l : 0;
+  const int mulC = a.mul_channels;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 8 + (lane >> 3);
+    const int m = m_base + row;
+    const bool ok = l_ok && m < a.Cout;
+    const int mc = m < a.Cout ? m : 0;
+    float4 v = *reinterpret_cast<const float4*>(strip + row * SRF_EPI_PITCH_H + c4);
+    const float bs = a.bias[mc];
+    v.x += bs;
+    v.y += bs;
+    v.z += bs;
+    v.w += bs;
+    const size_t idx = ((size_t)b * a.Cout + mc) * a.L + lc;
+    if (a.residual) {
+      const float4 rv = *reinterpret_cast<const float4*>(a.residual + idx);
+      v.x += rv.x;
+      v.y += rv.y;
+      v.z += rv.z;
+      v.w += rv.w;
+    }
+    if (a.epi_mask & 1) {
+      const float4 e = *reinterpret_cast<const float4*>(a.mul + ((size_t)b * mulC + (mc % mulC)) * a.L + lc);
+      v.x = fmaxf(v.x, 0.f) * e.x;
+      v.y = fmaxf(v.y, 0.f) * e.y;
+      v.z = fmaxf(v.z, 0.f) * e.z;
+      v.w = fmaxf(v.w, 0.f) * e.w;
+    }
+    if (ok) {
+      *reinterpret_cast<float4*>(a.y + idx) = v;
+      s += (v.x + v.y) + (v.z + v.w);
+      q = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, q))));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int PRO>
+__global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int nMt, int nLt, int total) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves, 32 x 64 each
+  const int Cin = a.Cin, L = a.L, Cout = a.Cout;
+  const int nk_ = Cin / X3_BK;   // even (host checks Cin % 64 == 0)
+  const int nblk = gridDim.x;
+  const int ntile = (total - (int)blockIdx.x + nblk - 1) / nblk;   // >= 1 (host: grid <= total)
+  const int nsteps = ntile * nk_;
+  const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
+  // experiment (epi_mask bits 8..): delay every other block once, by roughly half a tile, so that the
+  // chip's epilogue write bursts stop coinciding
+  {
+    const int units = (a.epi_mask >> 8) & 15, four = (a.epi_mask >> 12) & 1;
+    const int phase = four ? ((blockIdx.x >> 3) & 3) : 2 * ((blockIdx.x >> 3) & 1);
+    for (int i = 0; i < units * phase; ++i) __builtin_amdgcn_s_sleep(64);   // ~4K cycles each
+  }
+
+  // tile i of this block -> virtual tile id (XCD-contiguous runs, see srf_xcd_remap; nblk % 8 == 0 keeps
+  // every tile of a block on the block's own XCD)
+  auto tile_of = [&](int i, int& m0, int& l0, long& b) {
+    const int v = srf_xcd_remap(blockIdx.x + i * nblk, total);
+    m0 = (v % nMt) * X3_BM;
+    l0 = ((v / nMt) % nLt) * X3_BN;
+    b = v / (nMt * nLt);
+    return v;
+  };
+
+  const int a_m = tid >> 2, a_pk = tid & 3;
+  const int a_lds = a_m * X3_PITCH + a_pk * 16;
+  const int b_n = tid & 127, b_kg = (wave >> 1) * 8;
+  const int b_lds = b_n * X3_PITCH + b_kg * 2;
+
+  // ---- load cursor: (tile, k offset) of the next k-tile to fetch
+  int ld_i = 0, ld_k = 0;
+  const float* a_src;
+  const float* b_src;
+  auto ld_tile = [&](int i) {
+    int m0, l0;
+    long b;
+    tile_of(i, m0, l0, b);
+    const bool a_ok = (m0 + a_m) < Cout;
+    a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_pk * 8;
+    const bool b_ok = (l0 + b_n) < L;
+    b_src = a.x + ((size_t)b * Cin + b_kg) * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
+  };
+  ld_tile(0);
+  struct Regs {
+    float4 a[2];
+    float b[8];
+  };
+  auto gload = [&](Regs& r) {
+    r.a[0] = *reinterpret_cast<const float4*>(a_src + ld_k);
+    r.a[1] = *reinterpret_cast<const float4*>(a_src + ld_k + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.b[j] = b_src[(size_t)(ld_k + j) * L];
+    ld_k += X3_BK;
+    if (ld_k == Cin) {   // wave-uniform; past the last tile the cursor re-reads that tile (harmless)
+      ld_k = 0;
+      if (ld_i + 1 < ntile) ld_tile(++ld_i);
+    }
+  };
+
+  // ---- convert cursor: (tile, k offset) of the next k-tile to split into LDS
+  int cv_i = 0, cv_k = 0;
+  float a_msk = 0.f, mean = 0.f, rstd = 1.f;
+  auto cv_tile = [&](int i) {
+    int m0, l0;
+    long b;
+    tile_of(i, m0, l0, b);
+    a_msk = (m0 + a_m) < Cout ? 1.f : 0.f;
+    if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
+  };
+  cv_tile(0);
+  auto lds_store = [&](const Regs& r, int stage) {
+    char* base = smem + stage * X3_STAGE;
+    const float va[8] = {r.a[0].x * a_msk, r.a[0].y * a_msk, r.a[0].z * a_msk, r.a[0].w * a_msk,
+                         r.a[1].x * a_msk, r.a[1].y * a_msk, r.a[1].z * a_msk, r.a[1].w * a_msk};
+    bf16x8 hi, lo;
+    srf_split8(va, hi, lo);
+    *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + a_lds) = hi;
+    *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + a_lds) = lo;
+    float vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x0 = r.b[j];
+      if (PRO == 1 || PRO == 2) {
+        const int k = cv_k + b_kg + j;
+        const float sc = a.nrm.gamma[k] * rstd;
+        x0 = fmaf(x0, sc, a.nrm.beta[k] - mean * sc);
+      }
+      if (PRO == 2 || PRO == 3) x0 = srf_prelu(x0, slope);
+      vb[j] = x0;
+    }
+    srf_split8(vb, hi, lo);
+    *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + b_lds) = hi;
+    *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + b_lds) = lo;
+    cv_k += X3_BK;
+    if (cv_k == Cin) {
+      cv_k = 0;
+      if (cv_i + 1 < ntile) cv_tile(++cv_i);
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  const int frag = (lane & 31) * X3_PITCH + (lane >> 5) * 16;
+  const int a_row = (wm * 32) * X3_PITCH + frag;
+  const int b_row0 = (wn * 64) * X3_PITCH + frag, b_row1 = b_row0 + 32 * X3_PITCH;
+  auto mma_tile = [&](int stage) {
+    const char* base = smem + stage * X3_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ko = ks * 32;
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row + ko);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row + ko);
+      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row0 + ko);
+      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
+      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
+      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
+    }
+  };
+  auto step = [&](Regs& nx, int g) {
+    if (g + 1 < nsteps) lds_store(nx, (g + 1) & 1);
+    gload(nx);
+    mma_tile(g & 1);
+    __syncthreads();
+  };
+
+  Regs r0, r1;
+  gload(r0);
+  gload(r1);
+  lds_store(r0, 0);
+  gload(r0);
+  __syncthreads();
+  float* strip = reinterpret_cast<float*>(smem + X3_STAGE) + wave * (32 * SRF_EPI_PITCH_H);   // stage 1
+  int g = 0;
+  for (int i = 0; i < ntile; ++i) {
+    for (int kt = 0; kt < nk_; kt += 2) {
+      step(r1, g);
+      step(r0, g + 1);
+      g += 2;
+    }
+    // the tile's last k-tile sat in stage 1, which every wave has finished reading (barrier above);
+    // stage 0 already holds the next tile's first k-tile
+    int m0, l0;
+    long b;
+    const int v = tile_of(i, m0, l0, b);
+    float s = 0.f, q = 0.f;
+    srf_pw_epilogue_half(a, acc0, strip, b, m0 + wm * 32, l0 + wn * 64, lane, s, q);
+    srf_pw_epilogue_half(a, acc1, strip, b, m0 + wm * 32, l0 + wn * 64 + 32, lane, s, q);
+    if (a.out_sums) {
+      const double ds = srf_wave_sum((double)s), dq = srf_wave_sum((double)q);
+      if (lane == 0) {
+        double* dst = srf_stat_slot(a.out_sums, b, (long)v * 8 + wave);
+        atomicAdd(dst, ds);
+        atomicAdd(dst + 1, dq);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    __syncthreads();   // strip reads done before the next step's split overwrites stage 1
+  }
+}
+
 int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
   const int nMt = (a.Cout + X3_BM - 1) / X3_BM, nLt = (a.L + X3_BN - 1) / X3_BN;
   const long total = (long)a.Bt * nMt * nLt;
@@ -656,6 +950,34 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
   if ((srf_debug_flags() & 2) == 0) {   // default: 8-wave variant (flag 2: 4-wave variant)
     dim3 grid8((unsigned)total), block8(512);
     const int abl = (srf_debug_flags() >> 16) & 15;   // diagnostics: ablated pipelines (PRO 0 only)
+    // Persistent blocks (2 per CU) whenever every block gets >= 3 tiles; fewer tiles and the idle slots
+    // of the last round cost more than the pipelining across tiles gains (decoder frame GEMM: 800 tiles).
+    // Debug flag 2048 forces the one-tile-per-block kernel.
+    static int cached_cus = 0;
+    if (!cached_cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      cached_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                       ? prop.multiProcessorCount : 256;
+    }
+    long nb = 2L * cached_cus;
+    nb -= nb % 8;
+    if (!abl && !(srf_debug_flags() & 2048) && nb >= 8 && total >= 3 * nb) {
+      dim3 gridp((unsigned)nb);
+      PwArgs ap = a;
+      // start-up stagger: 4 phases x ~4K cycles (flags bits 20..23 override the unit count, 15 = none;
+      // bit 12 selects 2 phases)
+      const int su = (srf_debug_flags() >> 20) & 15;
+      ap.epi_mask |= ((su == 15 ? 0 : (su ? su : 1)) << 8) | ((((srf_debug_flags() >> 12) & 1) ^ 1) << 12);
+      switch (pro) {
+        case 0: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<0>, gridp, block8, 0, st, ap, nMt, nLt, (int)total); break;
+        case 1: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<1>, gridp, block8, 0, st, ap, nMt, nLt, (int)total); break;
+        case 2: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<2>, gridp, block8, 0, st, ap, nMt, nLt, (int)total); break;
+        default: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<3>, gridp, block8, 0, st, ap, nMt, nLt, (int)total); break;
+      }
+      SRF_CHECK_LAUNCH("pw_conv_bf16x3_p8", st);
+      return SRF_OK;
+    }
     if (abl && pro == 0) {
       switch (abl) {
         case 1: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 1>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
@@ -664,6 +986,13 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
         case 4: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 4>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
         case 8: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 8>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
         case 12: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 12>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+        case 10:  // no epilogue stores (everything else intact)
+          hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 32>), grid8, block8, 0, st, a, nMt, nLt, (int)total);
+          break;
+        case 9:   // (flag value 9 is not an ablation: in-kernel timeline into the buffer passed as `mul`)
+          SRF_CHECK_ARG(a.mul != nullptr && a.Cin <= 256, "srf_pw_conv: timeline needs a buffer in mul, Cin <= 256");
+          hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 16>), grid8, block8, 0, st, a, nMt, nLt, (int)total);
+          break;
         default: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 15>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
       }
       SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8_ablated", st);
@@ -679,11 +1008,13 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
       SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8", st);
       return SRF_OK;
     }
+    PwArgs aw = a;
+    aw.epi_mask |= (((srf_debug_flags() >> 20) & 15) << 8) | (((srf_debug_flags() >> 12) & 1) << 12);
     switch (pro) {
-      case 0: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<0>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-      case 1: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<1>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-      case 2: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<2>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-      default: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<3>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
+      case 0: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<0>, grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+      case 1: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<1>, grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+      case 2: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<2>, grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+      default: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<3>, grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
     }
     SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8", st);
     return SRF_OK;

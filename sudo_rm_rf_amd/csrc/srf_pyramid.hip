@@ -598,6 +598,9 @@ struct PyrFinArgs {
   const float* gamma[SRF_MAX_DEPTH];
   const float* beta[SRF_MAX_DEPTH];
   float* lvl;          // [groups][D][2]
+  const double* in_sums;   // statistics of the pyramid's input norm (may be null) -> in_mr[g] = {mean, rstd}
+  double in_inv_count;
+  float* in_mr;
   int C, L, D;
 };
 
@@ -607,6 +610,14 @@ __global__ __launch_bounds__(256) void srf_pyramid_finalize_kernel(PyrFinArgs a)
   __shared__ float bc[2];
   const long g = blockIdx.x;
   const int tid = threadIdx.x, C = a.C, D = a.D;
+  if (a.in_sums && tid < 64) {   // wavefront 0: the input norm's {mean, rstd} for pass 2
+    float m, r;
+    srf_finalize_stats(a.in_sums, g, a.in_inv_count, m, r);
+    if (tid == 0) {
+      a.in_mr[2 * g] = m;
+      a.in_mr[2 * g + 1] = r;
+    }
+  }
   double alpha[SRF_FIN_CPT], kap[SRF_FIN_CPT], g0[SRF_FIN_CPT], g1[SRF_FIN_CPT], gl[SRF_FIN_CPT];
 #pragma unroll
   for (int i = 0; i < SRF_FIN_CPT; ++i) {
@@ -808,6 +819,9 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
   a.D = D;
   f.mom = mom;
   f.lvl = lvl;
+  f.in_sums = nullptr;   // the LDS kernels get in_mr from srf_stats_finalize_kernel before pass 1
+  f.in_inv_count = a.in_inv_count;
+  f.in_mr = const_cast<float*>(a.in_mr);
   f.C = C;
   f.L = L;
   f.D = D;
@@ -841,8 +855,10 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
         SRF_CHECK_LAUNCH("stats_finalize", st);
       }
     }
+    SRF_CHECK_ARG(merged != y1, "srf_pyramid: merged must not alias y1 (pass 2 re-reads y1 with halos)");
     int rc = srf_pyramid_reg_launch(r, true, rows, st);
     if (rc) return rc;
+    if (!(srf_debug_flags() & 128)) f.in_sums = a.in_norm.sums;
     hipLaunchKernelGGL(srf_pyramid_finalize_kernel, dim3((unsigned)groups), dim3(256), 0, st, f);
     SRF_CHECK_LAUNCH("pyramid_finalize", st);
     return srf_pyramid_reg_launch(r, false, rows, st);

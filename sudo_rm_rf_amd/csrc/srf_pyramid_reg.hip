@@ -15,7 +15,7 @@
 
 struct PyrRegArgs {
   const float* y1;     // pass 1 input
-  float* d0;           // raw level-0 conv output: written by pass 1, read by pass 2
+  float* d0;           // unused by the register kernels (the LDS kernels of srf_pyramid.hip stage level 0 here)
   float* merged;       // pass 2 output (may alias y1)
   SrfNormDev in_norm;  // proj_1x1 GlobLN (+PReLU)
   const float* in_mr;  // [groups][2] pre-finalised {mean, rstd} of in_norm (non-persistent pass 1 only)
@@ -128,7 +128,9 @@ __device__ __forceinline__ void srf_pyr_edges(double* m5, const float (&v)[N], i
   if (ci == nchunks - 1) m5[4] = (double)v[N - 1];
 }
 
-// MOMENTS: pass 1 (raw cascade; writes d0 + row moments).  !MOMENTS: pass 2 (d0 -> merged).
+// MOMENTS: pass 1 (y1 -> raw cascade -> row moments; writes nothing else).  !MOMENTS: pass 2 (y1 -> level 0
+// again, normalised cascade -> merged).  Recomputing level 0 (5 MAC/elem) is cheaper than the d0 round trip
+// through HBM that an earlier version made (pass 1 measured 138 us with the d0 store, 81 us without).
 // PERSIST: wavefronts loop over a contiguous task range with next-task prefetch (measured faster for
 // pass 1, slower for pass 2 whose one-task-per-wave form keeps 8 waves per SIMD resident).
 template <bool MOMENTS, int CH, bool PERSIST = MOMENTS>
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   const long t_beg = PERSIST ? wave_id * a.tpw : wave_id;
   if (t_beg >= a.tasks) return;   // wave-uniform
   const long t_end = PERSIST ? min(t_beg + a.tpw, a.tasks) : t_beg + 1;   // exactly one trip when !PERSIST
-  const float* in_base = MOMENTS ? a.y1 : a.d0;
+  const float* in_base = a.y1;   // both passes start from y1: pass 2 recomputes level 0 instead of re-reading it
   auto chunk_src = [&](long task) {
     const long row_ = task / a.tiles;
     const int tile_ = (int)(task - row_ * a.tiles);
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   }
 
   float x0[CH];
-  if (MOMENTS) {
-    // ---- o = PReLU(GlobLN(y1)), then the raw level-0 conv
+  {
+    // ---- o = PReLU(GlobLN(y1)), then the level-0 conv (+ bias)
     float sc = 1.f, sh = 0.f;
     if (a.in_norm.sums) {
       if (PERSIST) {
@@ -223,23 +225,12 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
       o[i] = valid ? v : 0.f;
     }
     srf_conv_s1<CH>(o, x0, lc[0].w, lc[0].b);
-    if (own) {
-      float4* dst = reinterpret_cast<float4*>(a.d0 + (size_t)row * L + (size_t)ci * CH);
+    if (MOMENTS) {
 #pragma unroll
-      for (int i = 0; i < CH / 4; ++i) dst[i] = make_float4(x0[4 * i], x0[4 * i + 1], x0[4 * i + 2], x0[4 * i + 3]);
+      for (int i = 0; i < CH; ++i) x0[i] = valid ? x0[i] : 0.f;
+    } else {
+      srf_affine_mask<CH>(x0, lc[0].a, lc[0].c, valid);   // n_0 = GlobLN_0(d_0)
     }
-#pragma unroll
-    for (int i = 0; i < CH; ++i) x0[i] = valid ? x0[i] : 0.f;
-  } else {
-#pragma unroll
-    for (int i = 0; i < CH / 4; ++i) {
-      const float4 v = pre[i];
-      x0[4 * i + 0] = v.x;
-      x0[4 * i + 1] = v.y;
-      x0[4 * i + 2] = v.z;
-      x0[4 * i + 3] = v.w;
-    }
-    srf_affine_mask<CH>(x0, lc[0].a, lc[0].c, valid);
   }
 
   if (PERSIST) {  // prefetch the next task's chunk (clamped to this wave's last task: surplus loads are harmless)
