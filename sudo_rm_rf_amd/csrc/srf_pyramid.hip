@@ -770,8 +770,8 @@ struct PyrRegArgs {
   const float* lvl;
   double* mom;
   double* out_sums;
-  long tasks;
-  long tpw;
+  int rows;
+  int rpw;
   int C, L, D, tiles, own;
   int abl;
 };
@@ -845,7 +845,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
     r.C = C;
     r.L = L;
     r.D = D;
-    r.tasks = r.tpw = 0;
+    r.rows = r.rpw = 0;
     r.tiles = r.own = r.abl = 0;
     if (srf_debug_flags() & 128) {   // non-persistent pass 1: atomics into mom + pre-finalised statistics
       SRF_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * (size_t)rows * D * 5, st));

@@ -27,8 +27,8 @@ struct PyrRegArgs {
   const float* lvl;    // [groups][D][2] {mean, rstd} per level (pass 2)
   double* mom;         // [rows][D][5] (pass 1; zeroed by the host)
   double* out_sums;    // merged statistics (pass 2)
-  long tasks;          // rows * tiles
-  long tpw;            // tasks per (persistent) wavefront
+  int rows;            // groups * C
+  int rpw;             // rows per (persistent) wavefront
   int C, L, D, tiles, own;   // own = own chunks per tile
   int abl;             // diagnostics: 1 = plain stores instead of moment atomics, 2 = no wave reductions
 };
@@ -135,38 +135,56 @@ __device__ __forceinline__ void srf_pyr_edges(double* m5, const float (&v)[N], i
 // pass 1, slower for pass 2 whose one-task-per-wave form keeps 8 waves per SIMD resident).
 template <bool MOMENTS, int CH, bool PERSIST = MOMENTS>
 __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
+  __shared__ float4 pyr_strip[MOMENTS ? 1 : 4 * 60 * (CH / 4 + 1)];   // pass 2: store transposition
   const int lane = threadIdx.x & 63;
   const int L = a.L, D = a.D, C = a.C;
   const int nchunks = L / CH;
-  // Persistent wavefronts: wave w of the grid owns the contiguous task range [w*tpw, (w+1)*tpw) (tasks of
-  // one row are adjacent, so the per-row coefficients are reused) and keeps the NEXT task's input chunk
-  // in flight while it computes the current one -- without it every wave of a CU sits through the full
-  // HBM latency at the start of each task at the same time.
-  const long wave_id = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long t_beg = PERSIST ? wave_id * a.tpw : wave_id;
-  if (t_beg >= a.tasks) return;   // wave-uniform
-  const long t_end = PERSIST ? min(t_beg + a.tpw, a.tasks) : t_beg + 1;   // exactly one trip when !PERSIST
+  // Task = (row, tile).  All index arithmetic is 32-bit and division-free inside the loop: the earlier
+  // flat 64-bit task index cost ~300 scalar instructions per task in divisions and 64-bit multiplies
+  // (the scalar unit is shared by the CU's four SIMDs).
+  //  * persistent (pass 1): wave w owns the whole rows [w*rpw, (w+1)*rpw) -- the row moments stay in
+  //    registers across the row's tiles -- and keeps the NEXT task's input chunk in flight while it
+  //    computes the current one;
+  //  * one task per wave (pass 2): grid = (C, ceil(tiles/4), groups), wave = tile within the group of 4.
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int row, row_end, tile, g, c;
+  if (PERSIST) {
+    row = (blockIdx.x * 4 + wave) * a.rpw;
+    if (row >= a.rows) return;   // wave-uniform
+    row_end = min(row + a.rpw, a.rows);
+    g = row / C;
+    c = row - g * C;
+    tile = 0;
+  } else {
+    c = blockIdx.x;
+    g = blockIdx.z;
+    row = g * C + c;
+    row_end = row + 1;
+    tile = blockIdx.y * 4 + wave;
+    if (tile >= a.tiles) return;   // wave-uniform
+  }
   const float* in_base = a.y1;   // both passes start from y1: pass 2 recomputes level 0 instead of re-reading it
-  auto chunk_src = [&](long task) {
-    const long row_ = task / a.tiles;
-    const int tile_ = (int)(task - row_ * a.tiles);
+  auto chunk_src = [&](int row_, int tile_) {
     const int ci_ = min(max(tile_ * a.own - 2 + lane, 0), nchunks - 1);   // clamped: loads unconditional
-    return reinterpret_cast<const float4*>(in_base + (size_t)row_ * L + (size_t)ci_ * CH);
+    return reinterpret_cast<const float4*>(in_base + (size_t)row_ * L + ci_ * CH);
   };
   float s1[6], s2[6];
-  long cur_g = -1;               // persistent pass 1 finalises the proj statistics itself, once per example
+  int cur_g = -1;                // persistent pass 1 finalises the proj statistics itself, once per example
   float in_mean = 0.f, in_rstd = 1.f;
   float4 pre[CH / 4];
   {
-    const float4* src = chunk_src(t_beg);
+    const float4* src = chunk_src(row, tile);
 #pragma unroll
     for (int i = 0; i < CH / 4; ++i) pre[i] = src[i];
   }
-  for (long task = t_beg; task < t_end; ++task) {
-  const long row = task / a.tiles;
-  const int tile = (int)(task - row * a.tiles);
-  const int c = (int)(row % C);
-  const long g = row / C;
+  for (;;) {
+  // the task after this one (persistent only)
+  int nrow = row, ntile = tile + 1;
+  if (ntile == a.tiles) {
+    ntile = 0;
+    nrow = row + 1;
+  }
+  const bool last_task = !PERSIST || nrow >= row_end;
   const int ci = tile * a.own - 2 + lane;          // this lane's chunk index in the row
   const bool valid = ci >= 0 && ci < nchunks;      // inside the row (else: zero padding)
   const bool own = valid && lane >= 2 && lane < 2 + a.own;
@@ -233,8 +251,8 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     }
   }
 
-  if (PERSIST) {  // prefetch the next task's chunk (clamped to this wave's last task: surplus loads are harmless)
-    const float4* src = chunk_src(task + 1 < t_end ? task + 1 : task);
+  if (PERSIST) {  // prefetch the next task's chunk (the last task re-reads its own: surplus loads are harmless)
+    const float4* src = chunk_src(last_task ? row : nrow, last_task ? tile : ntile);
 #pragma unroll
     for (int i = 0; i < CH / 4; ++i) pre[i] = src[i];
   }
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   srf_zero(x3);
   srf_zero(x4);
   srf_zero(x5);
-  // pass 1, persistent: a wave owns whole rows (tpw is a multiple of tiles), so the row moments are
+  // pass 1, persistent: a wave owns whole rows, so the row moments are
   // accumulated in registers over the row's tiles and written with plain stores at its last tile
   if (!PERSIST || tile == 0) {
 #pragma unroll
@@ -355,24 +373,49 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
       ms += v;
       mq = fmaf(v, v, mq);
     }
+    // Store through a wave-private LDS strip so that every store instruction writes 1 KB of consecutive
+    // addresses (a lane's own 64/128 B at a 64/128-B lane stride measured 17-22 us slower per launch):
+    // own chunk j sits at float4 offset j*(NF+1) (odd pitch in 16-B units: conflict-free both ways).
+    constexpr int NF = CH / 4, PF = NF + 1;
+    float4* strip = pyr_strip + wave * (60 * PF);
+    const int j = lane - 2;
     if (own) {
-      float4* dst = reinterpret_cast<float4*>(a.merged + (size_t)row * L + (size_t)ci * CH);
 #pragma unroll
-      for (int i = 0; i < CH / 4; ++i)
-        dst[i] = make_float4(outv[4 * i], outv[4 * i + 1], outv[4 * i + 2], outv[4 * i + 3]);
+      for (int i = 0; i < NF; ++i)
+        strip[j * PF + i] = make_float4(outv[4 * i], outv[4 * i + 1], outv[4 * i + 2], outv[4 * i + 3]);
     } else {
       ms = 0.f;
       mq = 0.f;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const int first = tile * a.own;
+      const int cnt = min(a.own, nchunks - first);   // own chunks of this tile inside the row
+      float4* dst = reinterpret_cast<float4*>(a.merged + (size_t)row * L + first * CH);
+#pragma unroll
+      for (int it = 0; it < (60 * NF + 63) / 64; ++it) {
+        const int f = it * 64 + lane;
+        if (f < cnt * NF) dst[f] = strip[(f / NF) * PF + (f % NF)];
+      }
+    }
     if (a.out_sums) {
       const double ds = srf_wave_sum((double)ms), dq = srf_wave_sum((double)mq);
       if (lane == 0) {
-        double* dst = srf_stat_slot(a.out_sums, g, task);
+        double* dst = srf_stat_slot(a.out_sums, g, c * a.tiles + tile);
         atomicAdd(dst, ds);
         atomicAdd(dst + 1, dq);
       }
     }
   }
+  if (last_task) break;
+  if (ntile == 0 && ++c == C) {
+    c = 0;
+    ++g;
+  }
+  row = nrow;
+  tile = ntile;
   }  // task loop
 }
 
@@ -389,7 +432,8 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
   const int nchunks = a.L / CH;
   a.tiles = (nchunks + 59) / 60;
   a.own = (nchunks + a.tiles - 1) / a.tiles;
-  a.tasks = rows * a.tiles;
+  SRF_CHECK_ARG(rows * a.tiles < (1L << 31) && rows / a.C <= 65535, "srf_pyramid: too many rows");
+  a.rows = (int)rows;
   // pass 1 persistent (grid = co-resident wavefronts, cached occupancy query) unless debug flag 128
   const bool persist = moments && !(srf_debug_flags() & 128);
   static long cached_waves[2] = {0, 0};
@@ -404,26 +448,30 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     cw = (long)cus * per_cu * 4;
   }
-  long nwaves = persist ? cw : a.tasks;
-  if (nwaves > a.tasks) nwaves = a.tasks;
-  a.tpw = (a.tasks + nwaves - 1) / nwaves;
-  if (persist) a.tpw = (a.tpw + a.tiles - 1) / a.tiles * a.tiles;   // whole rows per wave
-  nwaves = (a.tasks + a.tpw - 1) / a.tpw;
-  const unsigned nb = (unsigned)((nwaves + 3) / 4);
+  dim3 grid;
+  if (persist) {
+    long nwaves = cw < rows ? cw : rows;
+    a.rpw = (int)((rows + nwaves - 1) / nwaves);   // whole rows per wave
+    nwaves = (rows + a.rpw - 1) / a.rpw;
+    grid = dim3((unsigned)((nwaves + 3) / 4));
+  } else {
+    a.rpw = 1;
+    grid = dim3((unsigned)a.C, (unsigned)((a.tiles + 3) / 4), (unsigned)(rows / a.C));
+  }
   if (CH == 16) {
     if (moments && persist)
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, true>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, true>), grid, dim3(256), 0, st, a);
     else if (moments)
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, false>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, false>), grid, dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 16, false>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 16, false>), grid, dim3(256), 0, st, a);
   } else {
     if (moments && persist)
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32, true>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32, true>), grid, dim3(256), 0, st, a);
     else if (moments)
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32, false>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32, false>), grid, dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 32, false>), dim3(nb), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 32, false>), grid, dim3(256), 0, st, a);
   }
   SRF_CHECK_LAUNCH(moments ? "pyramid_moments" : "pyramid_merge", st);
   return SRF_OK;
