@@ -261,9 +261,13 @@ def main():
         if dom.startswith("pw_conv"):
             # fp32-equivalent FLOPs; the split-precision kernel issues 3 bf16 MFMAs per product block, so
             # its matrix-pipe peak is (bf16 dense peak)/3 in fp32-equivalent terms
-            peak = roofline.MFMA_BF16_PEAK_TFLOPS / 3 if dom == "pw_conv_bf16x3" else roofline.MFMA_F32_PEAK_TFLOPS
+            split = dom.startswith("pw_conv_bf16x3")
+            peak = roofline.MFMA_BF16_PEAK_TFLOPS / 3 if split else roofline.MFMA_F32_PEAK_TFLOPS
             rl = {"kernel": dom, "bound": "mfma", "achieved": kd["TFLOPs"], "peak": peak,
-                  "unit": "TFLOP/s", "frac": kd["TFLOPs"] / peak, "traffic": None}
+                  "unit": "TFLOP/s", "frac": kd["TFLOPs"] / peak, "traffic": None,
+                  "note": ("algorithmic fp32 FLOPs (2*Cin*Cout per output); peak = bf16 dense MFMA peak / 3 because "
+                           "each product is 3 bf16 MFMAs" if split else "exact fp32 MFMA"),
+                  "algorithmic_GBps": kd["algorithmic_GBps"]}
         else:
             rl = {"kernel": dom, "bound": "hbm", "achieved": kd["algorithmic_GBps"], "peak": roofline.HBM_PEAK_GBS,
                   "unit": "GB/s", "frac": kd["algorithmic_GBps"] / roofline.HBM_PEAK_GBS, "traffic": None}
