@@ -18,6 +18,7 @@
  *   srf_tac                <- TAC.forward                 models/groupcomm_sudormrf_v2.py:356-377
  *   srf_gln_apply_add      <- TAC_norm + residual add     models/groupcomm_sudormrf_v2.py:378-382
  *   srf_mixture_consistency<- mixture_consistency.apply   experiments/utils/mixture_consistency.py:14-36
+ *   srf_wav_normalize / srf_wav_denormalize <- the callers' normalise / rescale lines   README.md:100-114
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 (or fp64 for GlobLN sums) owned by the
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 3
+#define SRF_ABI_VERSION 4
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -197,6 +198,17 @@ int srf_tac(const float* x, float* q, const float* const* params, int Bt, int G,
 /* pr + w * (mix - sum_s pr), uniform weights (w = 1/S).  pr,out: [Bt,S,T], mix: [Bt,1,T]. */
 int srf_mixture_consistency(const float* pr, const float* mix, float* out, int Bt, int S, int T,
                             void* stream);
+
+/* Caller-side pre/post-processing that every user of the reference wraps around model() (README.md:100-114,
+ * experiments/simple_whamr_evaluation.py:142-148):
+ *   srf_wav_normalize:   out = (wav - mean) / (std + 1e-9) per row, std unbiased (torch.std default);
+ *                        stats[row] = {mean, std}.  wav,out: [rows,T].
+ *   srf_wav_denormalize: out = est * std + mean; with mix_norm != NULL additionally
+ *                        mixture_consistency.apply(out, mix_norm) (uniform), as the README prescribes for the
+ *                        GroupComm models.  est,out: [Bt,S,T]; stats: [Bt][2]; mix_norm: [Bt,1,T]. */
+int srf_wav_normalize(const float* wav, float* out, float* stats, int rows, int T, void* stream);
+int srf_wav_denormalize(const float* est, const float* stats, const float* mix_norm, float* out, int Bt, int S,
+                        int T, void* stream);
 
 #ifdef __cplusplus
 }

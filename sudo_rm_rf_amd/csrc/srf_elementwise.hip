@@ -179,3 +179,86 @@ int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, in
   SRF_CHECK_LAUNCH("overlap_add", st);
   return SRF_OK;
 }
+
+// ---- caller-side pre/post-processing -------------------------------------
+// Every caller of the reference wraps model() in the same few torch ops (README.md:100-114,
+// simple_whamr_evaluation.py:142-148):
+//     std = x.std(-1, keepdim=True); mean = x.mean(-1, keepdim=True)      (std is UNBIASED, torch default)
+//     y = model(((x - mean) / (std + 1e-9)).unsqueeze(1))
+//     y = y * std + mean;  [GroupComm:] y = mixture_consistency.apply(y, normalised_mixture)
+// srf_wav_normalize = the first two lines (one block per row: mean, then sum of squared deviations, both
+// fp64, then the normalised row; the row stays in L2 between the three sweeps); srf_wav_denormalize = the
+// last line in one pass.
+__global__ __launch_bounds__(256) void srf_wav_normalize_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                float* __restrict__ stats, int T) {
+  __shared__ double red[8];
+  __shared__ double bc;
+  const long r = blockIdx.x;
+  const float* xr = x + r * (long)T;
+  const int tid = threadIdx.x;
+  auto block_sum = [&](double v) {
+    v = srf_wave_sum(v);
+    __syncthreads();   // red / bc free again
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) bc = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return bc;
+  };
+  double s = 0.0;
+  for (int i = tid; i < T; i += 256) s += (double)xr[i];
+  const double mean = block_sum(s) / (double)T;
+  double q = 0.0;
+  for (int i = tid; i < T; i += 256) {
+    const double d = (double)xr[i] - mean;
+    q += d * d;
+  }
+  const double var = block_sum(q) / (double)(T > 1 ? T - 1 : 1);
+  const float fm = (float)mean, fs = (float)sqrt(var);
+  if (tid == 0) {
+    stats[2 * r] = fm;
+    stats[2 * r + 1] = fs;
+  }
+  const float den = fs + 1e-9f;
+  float* yr = y + r * (long)T;
+  for (int i = tid; i < T; i += 256) yr[i] = (xr[i] - fm) / den;
+}
+
+extern "C" int srf_wav_normalize(const float* wav, float* out, float* stats, int rows, int T, void* stream) {
+  SRF_CHECK_ARG(wav && out && stats && rows > 0 && T > 0, "srf_wav_normalize: bad arguments");
+  hipLaunchKernelGGL(srf_wav_normalize_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, wav, out,
+                     stats, T);
+  SRF_CHECK_LAUNCH("wav_normalize", stream);
+  return SRF_OK;
+}
+
+// est [Bt,S,T] (model output for the normalised mixture), stats [Bt][2], mix_norm [Bt,1,T] or null
+__global__ __launch_bounds__(256) void srf_wav_denormalize_kernel(const float* __restrict__ est,
+                                                                  const float* __restrict__ stats,
+                                                                  const float* __restrict__ mix, float* __restrict__ out,
+                                                                  int S, int T) {
+  const long b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float mean = stats[2 * b], sd = stats[2 * b + 1];
+  const float* e = est + b * (long)S * T + t;
+  float* o = out + b * (long)S * T + t;
+  if (!mix) {
+    for (int s = 0; s < S; ++s) o[(long)s * T] = e[(long)s * T] * sd + mean;
+  } else {
+    float tot = 0.f;
+    for (int s = 0; s < S; ++s) tot += e[(long)s * T] * sd + mean;
+    const float corr = (mix[b * (long)T + t] - tot) * (1.f / (float)S);
+    for (int s = 0; s < S; ++s) o[(long)s * T] = (e[(long)s * T] * sd + mean) + corr;
+  }
+}
+
+extern "C" int srf_wav_denormalize(const float* est, const float* stats, const float* mix_norm, float* out, int Bt,
+                                   int S, int T, void* stream) {
+  SRF_CHECK_ARG(est && stats && out && Bt > 0 && S > 0 && T > 0 && Bt <= 65535, "srf_wav_denormalize: bad arguments");
+  dim3 grid((unsigned)((T + 255) / 256), (unsigned)Bt);
+  hipLaunchKernelGGL(srf_wav_denormalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, est, stats, mix_norm, out,
+                     S, T);
+  SRF_CHECK_LAUNCH("wav_denormalize", stream);
+  return SRF_OK;
+}

@@ -199,6 +199,33 @@ def mixture_consistency(pr_batch, input_mixture):
     return out
 
 
+def wav_normalize(wav):
+    """Per-row (x - mean) / (std + 1e-9), std unbiased (README.md:100-103).  wav [rows,T] or [Bt,1,T] ->
+    (normalised wav of the same shape, stats [rows,2] = {mean, std})."""
+    dev = _chk(wav)
+    T = wav.shape[-1]
+    rows = wav.numel() // T
+    out = torch.empty_like(wav)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=dev)
+    rc = _lib.load().srf_wav_normalize(_lib.ptr(wav), _lib.ptr(out), _lib.ptr(stats), rows, T,
+                                       _lib.current_stream(dev))
+    _lib.check(rc, "srf_wav_normalize")
+    return out, stats
+
+
+def wav_denormalize(est, stats, mix_norm=None):
+    """est * std + mean per example (README.md:108-109); with mix_norm [Bt,1,T] additionally
+    mixture_consistency.apply(., mix_norm) (README.md:113-114).  est [Bt,S,T], stats [Bt,2]."""
+    dev = _chk(est, stats, mix_norm)
+    Bt, S, T = est.shape
+    assert stats.shape == (Bt, 2)
+    out = torch.empty_like(est)
+    rc = _lib.load().srf_wav_denormalize(_lib.ptr(est), _lib.ptr(stats), _lib.ptr(mix_norm), _lib.ptr(out),
+                                         Bt, S, T, _lib.current_stream(dev))
+    _lib.check(rc, "srf_wav_denormalize")
+    return out
+
+
 def set_debug_flags(flags):
     _lib.load().srf_set_debug_flags(int(flags))
 

@@ -156,3 +156,28 @@ def test_submodule_forwards(manifest):
     with torch.no_grad():
         y = model.sm[0](x).cpu().numpy()
     assert np.abs(y - tr["sm.0.UBlock.out"].reshape(y.shape)).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["improved", "groupcomm"])
+def test_separate_pipeline_matches_reference_recipe(variant):
+    """sudo_rm_rf_amd.pipeline.separate == the README's normalise / model / rescale (/ mixture consistency)
+    lines evaluated with the oracle model on the CPU (README.md:100-114)."""
+    from oracle import weights
+    from oracle.schema import ModelConfig
+    from sudo_rm_rf_amd import pipeline
+    cfg = (ModelConfig("improved", 16, 32, 2, 3, 11, 24, 2) if variant == "improved"
+           else ModelConfig("groupcomm", 16, 32, 2, 3, 11, 24, 2, 1, 4))
+    sd = weights.make_state_dict(cfg, seed=5)
+    model = build(cfg, sd)
+    g = torch.Generator().manual_seed(11)
+    mix = torch.randn(3, 1500, generator=g) * 2.5 + 0.3
+    std, mean = mix.std(-1, keepdim=True), mix.mean(-1, keepdim=True)
+    norm = ((mix - mean) / (std + 1e-9)).unsqueeze(1)
+    est = torch_oracle.forward(cfg, {k: torch.from_numpy(v) for k, v in sd.items()}, norm)
+    want = est * std.unsqueeze(1) + mean.unsqueeze(1)
+    if variant == "groupcomm":
+        want = want + (norm - want.sum(1, keepdim=True)) / want.shape[1]
+    got = pipeline.separate(model, mix.to(DEV))
+    err = (got.cpu() - want).abs().max().item()
+    assert err <= 1e-4, err

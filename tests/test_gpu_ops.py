@@ -310,6 +310,25 @@ def test_mixture_consistency():
     check(ops.mixture_consistency(dev32(pr), dev32(mix)), want, 1e-6, "mixture consistency")
 
 
+@pytest.mark.parametrize("Bt,S,T,mc", [(3, 2, 1001, False), (2, 2, 32000, True), (1, 3, 77, True), (4, 1, 5, False)])
+def test_wav_normalize_denormalize(Bt, S, T, mc):
+    """README.md:100-114: (x-mean)/(std+1e-9) with torch's unbiased std, est*std+mean, mixture consistency."""
+    from sudo_rm_rf_amd import ops
+    x = rnd(Bt, 1, T, seed=95, scale=3.0, shift=0.7)
+    std, mean = x.std(-1, keepdim=True), x.mean(-1, keepdim=True)
+    want = (x - mean) / (std + 1e-9)
+    got, stats = ops.wav_normalize(dev32(x))
+    check(got, want, 2e-6, "wav_normalize")
+    check(stats[:, 0], mean.view(-1), 1e-6, "mean")
+    check(stats[:, 1], std.view(-1), 1e-6, "std")
+    est = rnd(Bt, S, T, seed=96)
+    ref = est * std + mean
+    if mc:
+        ref = ref + (want - ref.sum(1, keepdim=True)) / S      # mixture_consistency.py:14-36, uniform
+    out = ops.wav_denormalize(dev32(est), stats, got if mc else None)
+    check(out, ref, 5e-6, "wav_denormalize")
+
+
 def test_stats_robust_to_large_mean():
     """E[x^2]-mu^2 in fp64 must survive mean >> std (fp32 accumulation would not)."""
     from sudo_rm_rf_amd import ops

@@ -199,3 +199,53 @@ def test_plan_geometry_matches_reference_padding_rule():
     h = C.c_void_p()
     assert lib.srf_plan_create(C.byref(bad), 1, 100, C.byref(h)) == -1
     assert b"odd" in lib.srf_last_error()
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoint tooling: DataParallel prefixes, whole-module pickles, wrapped dicts
+# ---------------------------------------------------------------------------------------------
+def _tiny_models():
+    from sudo_rm_rf_amd.dnn.models import groupcomm_sudormrf_v2, improved_sudormrf
+    torch.manual_seed(3)
+    a = improved_sudormrf.SuDORMRF(out_channels=16, in_channels=32, num_blocks=2, upsampling_depth=3,
+                                   enc_kernel_size=11, enc_num_basis=24, num_sources=2)
+    b = groupcomm_sudormrf_v2.GroupCommSudoRmRf(in_audio_channels=1, out_channels=16, in_channels=32,
+                                                num_blocks=2, upsampling_depth=3, enc_kernel_size=11,
+                                                enc_num_basis=24, num_sources=2, group_size=4)
+    return a, b
+
+
+def test_checkpoint_module_prefix_roundtrip():
+    from sudo_rm_rf_amd import checkpoint
+    for m in _tiny_models():
+        sd = m.state_dict()
+        pref = checkpoint.add_module_prefix(sd)
+        assert all(k.startswith("module.") for k in pref) and len(pref) == len(sd)
+        assert list(checkpoint.strip_module_prefix(pref).keys()) == list(sd.keys())
+        assert list(checkpoint.add_module_prefix(pref).keys()) == list(pref.keys())     # idempotent
+        fresh = type(m)(**checkpoint.config_from_module(m))
+        checkpoint.load_checkpoint({"state_dict": pref, "epoch": 3}, fresh)
+        for (k, v), (k2, v2) in zip(sd.items(), fresh.state_dict().items()):
+            assert k == k2 and torch.equal(v, v2)
+
+
+def test_checkpoint_whole_module_pickle_and_dataparallel(tmp_path):
+    from sudo_rm_rf_amd import checkpoint
+    for i, m in enumerate(_tiny_models()):
+        # the published pre-trained files are whole-module pickles (README.md:75-98)
+        p = tmp_path / ("whole%d.pt" % i)
+        torch.save(m, p)
+        got = checkpoint.load_checkpoint(str(p))
+        assert type(got) is type(m)
+        assert checkpoint.config_from_module(got) == checkpoint.config_from_module(m)
+        for v, v2 in zip(m.state_dict().values(), got.state_dict().values()):
+            assert torch.equal(v, v2)
+        # older runners saved the DataParallel wrapper's state_dict
+        p2 = tmp_path / ("dp%d.pt" % i)
+        torch.save(torch.nn.DataParallel(m).state_dict(), p2)
+        fresh = torch.nn.DataParallel(type(m)(**checkpoint.config_from_module(m)))
+        checkpoint.load_checkpoint(str(p2), fresh)
+        for v, v2 in zip(m.state_dict().values(), fresh.module.state_dict().values()):
+            assert torch.equal(v, v2)
+    with pytest.raises(TypeError):
+        checkpoint.load_checkpoint(m.state_dict())      # bare state_dict without a model to load into
