@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 4
+#define SRF_ABI_VERSION 5
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -209,6 +209,22 @@ int srf_mixture_consistency(const float* pr, const float* mix, float* out, int B
 int srf_wav_normalize(const float* wav, float* out, float* stats, int rows, int T, void* stream);
 int srf_wav_denormalize(const float* est, const float* stats, const float* mix_norm, float* out, int Bt, int S,
                         int T, void* stream);
+
+/* ---- training loss: clamp(PITLossWrapper(PairwiseNegSDR("sisdr"), pit_from='pw_mtx'), +-clamp)
+ * reference: losses/sisdr.py:426-458 (pairwise SI-SDR), :254-311,:342-387 (PIT), runner clamp
+ * experiments/run_improved_sudormrf.py:169-171.  est, tgt, grad_est: [Bt,S,T]; S <= 4.
+ *   work  : srf_pit_sisdr_work_bytes(Bt,S) bytes, 8-byte aligned, written by _forward and read by _backward;
+ *   pw    : optional [Bt,S,S] pairwise losses (estimate, target);
+ *   loss  : 2 floats {clamp(batch mean), raw batch mean}; clamp <= 0 disables the clamp;
+ *   srf_pit_sisdr_match: [Bt,S] int32, the estimate matched with target j (best permutation);
+ *   _backward: grad_est = upstream[0] * d loss[0] / d est (zero when the raw mean is outside +-clamp);
+ *              upstream is a DEVICE scalar (NULL = 1), so an autograd chain never synchronises. */
+size_t srf_pit_sisdr_work_bytes(int Bt, int S);
+int srf_pit_sisdr_forward(const float* est, const float* tgt, int Bt, int S, int T, float clamp, void* work,
+                          float* pw, float* loss, void* stream);
+int srf_pit_sisdr_match(const void* work, int Bt, int S, int* match_out, void* stream);
+int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt, int S, int T, float clamp, const void* work,
+                           const float* loss, const float* upstream, float* grad_est, void* stream);
 
 #ifdef __cplusplus
 }

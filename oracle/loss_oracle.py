@@ -1,0 +1,90 @@
+"""CPU restatement of the reference's training loss -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+    PITLossWrapper(PairwiseNegSDR("sisdr"), pit_from='pw_mtx')          run_improved_sudormrf.py:63-66
+    l = torch.clamp(loss(rec_sources_wavs, clean_wavs), min=-30., max=+30.)   run_improved_sudormrf.py:169-171
+
+PairwiseNegSDR.forward            losses/sisdr.py:426-458
+PITLossWrapper.forward            losses/sisdr.py:254-311 (pw_mtx branch: :276-278, :299-306)
+PITLossWrapper.find_best_perm     losses/sisdr.py:342-387
+
+Pinned against the reference module itself: tools/make_golden_loss.py imports losses/sisdr.py from
+/root/reference, evaluates loss / pairwise matrix / best permutation / autograd gradient on seeded inputs and
+stores them under tests/golden/loss_*.npz; tests/test_oracle_golden.py checks this file against those.
+"""
+import itertools
+
+import numpy as np
+import torch
+
+EPS = 1e-8
+
+
+def make_loss_case(batch, n_src, T, seed, snr_db=5.0, mode="noisy"):
+    """Seeded (estimates, targets), both [batch, n_src, T] float32.
+    mode: 'noisy'  est = permuted, rescaled targets + noise at snr_db (a realistic training state);
+          'exact'  est = targets (loss far below the -30 clamp);
+          'zero'   est = 0 (loss = +80 dB, above the +30 clamp);
+          'random' est independent of the targets."""
+    rng = np.random.default_rng(7919 * (seed + 1) + 13)
+    tgt = rng.standard_normal((batch, n_src, T)) * rng.uniform(0.3, 2.0, size=(batch, n_src, 1)) \
+        + rng.uniform(-0.2, 0.2, size=(batch, n_src, 1))
+    if mode == "exact":
+        est = tgt.copy()
+    elif mode == "zero":
+        est = np.zeros_like(tgt)
+    elif mode == "random":
+        est = rng.standard_normal((batch, n_src, T))
+    else:
+        est = np.empty_like(tgt)
+        for b in range(batch):
+            perm = rng.permutation(n_src)
+            for i in range(n_src):
+                s = tgt[b, perm[i]]
+                noise = rng.standard_normal(T) * np.sqrt(np.mean(s ** 2) / 10 ** (snr_db / 10))
+                est[b, i] = rng.uniform(0.5, 1.5) * s + noise + rng.uniform(-0.1, 0.1)
+    return est.astype(np.float32), tgt.astype(np.float32)
+
+
+def pairwise_neg_sisdr(est, tgt):
+    """PairwiseNegSDR('sisdr', zero_mean=True, take_log=True).forward  (losses/sisdr.py:426-458).
+    torch tensors [batch, n_src, T] -> [batch, n_src(est), n_src(tgt)]; differentiable."""
+    tgt = tgt - tgt.mean(dim=2, keepdim=True)                                   # :431-435
+    est = est - est.mean(dim=2, keepdim=True)
+    s_target = tgt.unsqueeze(1)                                                 # :437  [B,1,S,T]
+    s_estimate = est.unsqueeze(2)                                               # :438  [B,S,1,T]
+    dot = (s_estimate * s_target).sum(dim=3, keepdim=True)                      # :442
+    energy = (s_target ** 2).sum(dim=3, keepdim=True) + EPS                     # :445
+    proj = dot * s_target / energy                                              # :447
+    noise = s_estimate - proj                                                   # :454
+    sdr = (proj ** 2).sum(dim=3) / ((noise ** 2).sum(dim=3) + EPS)              # :456-457
+    return -10.0 * torch.log10(sdr + EPS)                                       # :458-460
+
+
+def best_perm(pw):
+    """find_best_perm (losses/sisdr.py:342-387, perm_reduce=None): pw [B, est, tgt] ->
+    (min_loss [B], index into itertools.permutations order, perms [P, S]).  perms[p][j] is the ESTIMATE
+    matched with TARGET j (:368 transposes so that dim 1 = sources, dim 2 = estimates)."""
+    n_src = pw.shape[1]
+    perms = torch.tensor(list(itertools.permutations(range(n_src))), dtype=torch.long)   # :370-371
+    pwl = pw.transpose(-1, -2)                                                            # :368
+    loss_set = torch.stack([pwl[:, torch.arange(n_src), p].mean(dim=1) for p in perms], dim=1)  # :375-380
+    idx = torch.argmin(loss_set, dim=1)                                                   # :385
+    return loss_set.gather(1, idx[:, None])[:, 0], idx, perms
+
+
+def pit_sisdr_loss(est, tgt, clamp=30.0):
+    """The scalar the runner back-propagates: clamp(mean_b min_perm mean_j pw[b, perm_j, j], -30, 30)."""
+    pw = pairwise_neg_sisdr(est, tgt)
+    min_loss, idx, perms = best_perm(pw)
+    raw = min_loss.mean()                                                       # sisdr.py:307
+    return (torch.clamp(raw, min=-clamp, max=clamp) if clamp else raw), raw, pw, perms[idx]
+
+
+def loss_and_grad(est_np, tgt_np, clamp=30.0, dtype=torch.float64):
+    """numpy in / numpy out: (clamped loss, raw loss, pw [B,S,S], matched estimate per target [B,S],
+    d clamped_loss / d est [B,S,T])."""
+    est = torch.tensor(est_np, dtype=dtype, requires_grad=True)
+    tgt = torch.tensor(tgt_np, dtype=dtype)
+    l, raw, pw, match = pit_sisdr_loss(est, tgt, clamp)
+    l.backward()
+    return (float(l.detach()), float(raw.detach()), pw.detach().numpy(), match.numpy().astype(np.int32), est.grad.numpy())

@@ -1,0 +1,238 @@
+// Training loss of the reference runners, forward and backward, on the device:
+//     l = clamp( PITLossWrapper(PairwiseNegSDR("sisdr"), pit_from='pw_mtx')(est, tgt), -30, +30 )
+//         experiments/run_improved_sudormrf.py:63-66,169-171
+//     PairwiseNegSDR.forward (zero-mean, SI-SDR, 10 log10)      losses/sisdr.py:426-458
+//     PITLossWrapper.forward / find_best_perm                   losses/sisdr.py:254-311 / 342-387
+// Everything the loss needs from the waveforms is a handful of inner products per example:
+//     sum e_i, sum e_i^2, sum t_j, sum t_j^2, sum e_i t_j          (4S + S^2 numbers, fp64)
+// so the forward is ONE streaming pass over est/tgt (srf_pit_stats_kernel) plus a tiny per-example
+// finalize (pairwise matrix, best permutation in itertools order with first-minimum tie-breaking like
+// torch.argmin, batch mean, clamp), and the gradient w.r.t. the estimates is a two-term combination
+//     dl/d e_i = A_i (e_i - mean e_i) + B_i (t_m(i) - mean t_m(i))
+// of the estimate and its matched target (second streaming pass, srf_pit_grad_kernel).  The reference
+// materialises [B,S,S,T] broadcast tensors for the same quantities (~10 passes, autograd doubling them).
+#include "srf_common.h"
+
+#define SRF_LOSS_MAX_SRC 4
+
+__global__ __launch_bounds__(256) void srf_pit_stats_kernel(const float* __restrict__ est,
+                                                            const float* __restrict__ tgt, double* __restrict__ work,
+                                                            int S, int T, int per_block) {
+  __shared__ double red[4][SRF_LOSS_MAX_SRC * (4 + SRF_LOSS_MAX_SRC)];
+  const long b = blockIdx.y;
+  const int beg = blockIdx.x * per_block, end = min(beg + per_block, T);
+  const int nstat = 4 * S + S * S;
+  double acc[SRF_LOSS_MAX_SRC * (4 + SRF_LOSS_MAX_SRC)];
+#pragma unroll
+  for (int k = 0; k < SRF_LOSS_MAX_SRC * (4 + SRF_LOSS_MAX_SRC); ++k) acc[k] = 0.0;
+  const float* eb = est + b * (long)S * T;
+  const float* tb = tgt + b * (long)S * T;
+  for (int t = beg + threadIdx.x; t < end; t += 256) {
+    float e[SRF_LOSS_MAX_SRC], g[SRF_LOSS_MAX_SRC];
+#pragma unroll
+    for (int i = 0; i < SRF_LOSS_MAX_SRC; ++i) {
+      e[i] = i < S ? eb[(long)i * T + t] : 0.f;
+      g[i] = i < S ? tb[(long)i * T + t] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SRF_LOSS_MAX_SRC; ++i) {
+      if (i < S) {
+        acc[i] += (double)e[i];
+        acc[S + i] += (double)e[i] * (double)e[i];
+        acc[2 * S + i] += (double)g[i];
+        acc[3 * S + i] += (double)g[i] * (double)g[i];
+#pragma unroll
+        for (int j = 0; j < SRF_LOSS_MAX_SRC; ++j)
+          if (j < S) acc[4 * S + i * S + j] += (double)e[i] * (double)g[j];
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < SRF_LOSS_MAX_SRC * (4 + SRF_LOSS_MAX_SRC); ++k) {
+    if (k < nstat) {
+      const double v = srf_wave_sum(acc[k]);
+      if (lane == 0) red[wave][k] = v;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nstat) {
+    const int k = threadIdx.x;
+    atomicAdd(work + b * nstat + k, (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]));
+  }
+}
+
+struct PitOut {
+  float* pw;      // [Bt][S][S] (est, tgt) or null
+  int* match;     // [Bt][S]: estimate matched with target j
+  float* coef;    // [Bt][S][4]: per estimate i {A, B, mean e_i, mean of its matched target}
+  int* tmatch;    // [Bt][S]: target matched with estimate i
+  float* loss;    // {clamped batch mean, raw batch mean}
+};
+
+__global__ __launch_bounds__(256) void srf_pit_finalize_kernel(const double* __restrict__ work, PitOut o, int Bt,
+                                                               int S, int T, float clamp) {
+  __shared__ double red[4];
+  const int nstat = 4 * S + S * S;
+  double mysum = 0.0;
+  for (int b = threadIdx.x; b < Bt; b += 256) {
+    const double* w = work + (long)b * nstat;
+    double pw[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC], cA[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC],
+        cB[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC];
+    const double dT = (double)T;
+    for (int i = 0; i < S; ++i) {
+      const double me = w[i] / dT, ee = w[S + i] - dT * me * me;
+      for (int j = 0; j < S; ++j) {
+        const double mt = w[2 * S + j] / dT;
+        const double tau0 = w[3 * S + j] - dT * mt * mt, tau = tau0 + 1e-8;
+        const double d = w[4 * S + i * S + j] - dT * me * mt;
+        const double al = d / tau;
+        const double P = al * al * tau0;
+        const double N = ee - 2.0 * al * d + al * al * tau0 + 1e-8;
+        const double sdr = P / N;
+        pw[i][j] = -10.0 * log10(sdr + 1e-8);
+        // d pw / d e_i = cA * (e_i - me) + cB * (t_j - mt)
+        const double k = -(10.0 / log(10.0)) / (sdr + 1e-8);
+        cA[i][j] = k * (-2.0 * P / (N * N));
+        cB[i][j] = k * (2.0 * al / (N * N)) * ((tau0 / tau) * N + P * (2.0 - tau0 / tau));
+        if (o.pw) o.pw[((long)b * S + i) * S + j] = (float)pw[i][j];
+      }
+    }
+    // permutations of (0..S-1) in lexicographic (= itertools.permutations) order; perm[j] = estimate for target j
+    int perm[SRF_LOSS_MAX_SRC], best[SRF_LOSS_MAX_SRC];
+    for (int j = 0; j < S; ++j) perm[j] = best[j] = j;
+    double best_loss = 0.0;
+    bool first = true;
+    for (;;) {
+      double l = 0.0;
+      for (int j = 0; j < S; ++j) l += pw[perm[j]][j];
+      l /= (double)S;
+      if (first || l < best_loss) {   // strict: the first minimum wins, like torch.argmin
+        best_loss = l;
+        for (int j = 0; j < S; ++j) best[j] = perm[j];
+        first = false;
+      }
+      // next lexicographic permutation
+      int p = S - 2;
+      while (p >= 0 && perm[p] > perm[p + 1]) --p;
+      if (p < 0) break;
+      int q = S - 1;
+      while (perm[q] < perm[p]) --q;
+      int tmp = perm[p];
+      perm[p] = perm[q];
+      perm[q] = tmp;
+      for (int lo = p + 1, hi = S - 1; lo < hi; ++lo, --hi) {
+        tmp = perm[lo];
+        perm[lo] = perm[hi];
+        perm[hi] = tmp;
+      }
+    }
+    mysum += best_loss;
+    const double scale = 1.0 / ((double)S * (double)Bt);   // mean over the matched pairs, then over the batch
+    for (int j = 0; j < S; ++j) {
+      const int i = best[j];
+      o.match[(long)b * S + j] = i;
+      o.tmatch[(long)b * S + i] = j;
+      float* c = o.coef + ((long)b * S + i) * 4;
+      c[0] = (float)(cA[i][j] * scale);
+      c[1] = (float)(cB[i][j] * scale);
+      c[2] = (float)(w[i] / dT);
+      c[3] = (float)(w[2 * S + j] / dT);
+    }
+  }
+  mysum = srf_wave_sum(mysum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mysum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double raw = ((red[0] + red[1]) + (red[2] + red[3])) / (double)Bt;
+    double cl = raw;
+    if (clamp > 0.f) cl = cl < -(double)clamp ? -(double)clamp : (cl > (double)clamp ? (double)clamp : cl);
+    o.loss[0] = (float)cl;
+    o.loss[1] = (float)raw;
+  }
+}
+
+__global__ __launch_bounds__(256) void srf_pit_grad_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                           const float* __restrict__ coef, const int* __restrict__ tmatch,
+                                                           const float* __restrict__ loss, float* __restrict__ grad,
+                                                           int S, int T, float clamp, const float* __restrict__ upstream) {
+  const long b = blockIdx.z;
+  const int i = blockIdx.y;
+  const float raw = loss[1];
+  // d clamp(raw) / d raw: 1 strictly inside the interval, 0 outside (torch.clamp passes the gradient on the
+  // boundary as well; a loss of exactly +-30.0 is not worth a special case)
+  const float gate = (clamp > 0.f && (raw < -clamp || raw > clamp)) ? 0.f : (upstream ? upstream[0] : 1.f);
+  const float* c = coef + (b * S + i) * 4;
+  const float A = c[0] * gate, B = c[1] * gate, me = c[2], mt = c[3];
+  const int j = tmatch[b * S + i];
+  const float* e = est + (b * S + i) * (long)T;
+  const float* t = tgt + (b * S + j) * (long)T;
+  float* g = grad + (b * S + i) * (long)T;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int x = blockIdx.x * 1024 + u * 256 + threadIdx.x;
+    if (x < T) g[x] = fmaf(A, e[x] - me, B * (t[x] - mt));
+  }
+}
+
+extern "C" size_t srf_pit_sisdr_work_bytes(int Bt, int S) {
+  if (Bt <= 0 || S <= 0 || S > SRF_LOSS_MAX_SRC) return 0;
+  // fp64 statistics | coef [Bt][S][4] f32 | match, tmatch [Bt][S] i32
+  return (size_t)Bt * ((4 * S + S * S) * sizeof(double) + S * 4 * sizeof(float) + 2 * S * sizeof(int));
+}
+
+static void pit_carve(void* work, int Bt, int S, double** stats, float** coef, int** match, int** tmatch) {
+  *stats = reinterpret_cast<double*>(work);
+  *coef = reinterpret_cast<float*>(*stats + (size_t)Bt * (4 * S + S * S));
+  *match = reinterpret_cast<int*>(*coef + (size_t)Bt * S * 4);
+  *tmatch = *match + (size_t)Bt * S;
+}
+
+extern "C" int srf_pit_sisdr_forward(const float* est, const float* tgt, int Bt, int S, int T, float clamp,
+                                     void* work, float* pw, float* loss, void* stream) {
+  SRF_CHECK_ARG(est && tgt && work && loss, "srf_pit_sisdr_forward: null pointer");
+  SRF_CHECK_ARG(Bt > 0 && Bt <= 65535 && T > 0, "srf_pit_sisdr_forward: bad sizes");
+  SRF_CHECK_ARG(S >= 1 && S <= SRF_LOSS_MAX_SRC, "srf_pit_sisdr_forward: %d sources unsupported (1..%d)", S,
+                SRF_LOSS_MAX_SRC);
+  hipStream_t st = (hipStream_t)stream;
+  double* stats;
+  PitOut o;
+  pit_carve(work, Bt, S, &stats, &o.coef, &o.match, &o.tmatch);
+  o.pw = pw;
+  o.loss = loss;
+  SRF_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * (size_t)Bt * (4 * S + S * S), st));
+  const int per_block = 256 * 16;
+  dim3 grid((unsigned)((T + per_block - 1) / per_block), (unsigned)Bt);
+  hipLaunchKernelGGL(srf_pit_stats_kernel, grid, dim3(256), 0, st, est, tgt, stats, S, T, per_block);
+  SRF_CHECK_LAUNCH("pit_sisdr_stats", st);
+  hipLaunchKernelGGL(srf_pit_finalize_kernel, dim3(1), dim3(256), 0, st, stats, o, Bt, S, T, clamp);
+  SRF_CHECK_LAUNCH("pit_sisdr_finalize", st);
+  return SRF_OK;
+}
+
+extern "C" int srf_pit_sisdr_match(const void* work, int Bt, int S, int* match_out, void* stream) {
+  SRF_CHECK_ARG(work && match_out && Bt > 0 && S >= 1 && S <= SRF_LOSS_MAX_SRC, "srf_pit_sisdr_match: bad arguments");
+  double* stats;
+  float* coef;
+  int *match, *tmatch;
+  pit_carve(const_cast<void*>(work), Bt, S, &stats, &coef, &match, &tmatch);
+  SRF_CHECK_HIP(hipMemcpyAsync(match_out, match, sizeof(int) * (size_t)Bt * S, hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream));
+  return SRF_OK;
+}
+
+extern "C" int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt, int S, int T, float clamp,
+                                      const void* work, const float* loss, const float* upstream, float* grad_est,
+                                      void* stream) {
+  SRF_CHECK_ARG(est && tgt && work && loss && grad_est, "srf_pit_sisdr_backward: null pointer");
+  SRF_CHECK_ARG(Bt > 0 && Bt <= 65535 && T > 0 && S >= 1 && S <= SRF_LOSS_MAX_SRC, "srf_pit_sisdr_backward: bad sizes");
+  double* stats;
+  float* coef;
+  int *match, *tmatch;
+  pit_carve(const_cast<void*>(work), Bt, S, &stats, &coef, &match, &tmatch);
+  dim3 grid((unsigned)((T + 1023) / 1024), (unsigned)S, (unsigned)Bt);
+  hipLaunchKernelGGL(srf_pit_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, est, tgt, coef, tmatch, loss,
+                     grad_est, S, T, clamp, upstream);
+  SRF_CHECK_LAUNCH("pit_sisdr_grad", stream);
+  return SRF_OK;
+}

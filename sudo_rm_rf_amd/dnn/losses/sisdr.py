@@ -1,0 +1,139 @@
+"""Host-side mirror of the part of the reference's ``sudo_rm_rf.dnn.losses.sisdr`` that its runners train with
+(SURVEY.md §8 a19):
+
+    PITLossWrapper(PairwiseNegSDR("sisdr"), pit_from='pw_mtx')      experiments/run_improved_sudormrf.py:63-66
+    PairwiseNegSDR                                                  losses/sisdr.py:390-458
+    PITLossWrapper                                                  losses/sisdr.py:199-387
+
+Same class names, constructor arguments and call signatures; the arithmetic runs in csrc/srf_loss.hip (one
+streaming pass for the forward, one for the gradient).  Configurations the runners never use (plain SNR / SD-SDR,
+``pit_from`` other than 'pw_mtx', a custom ``perm_reduce``) raise NotImplementedError instead of falling back
+to a CPU/ATen path.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+from torch.nn.modules.loss import _Loss
+
+from ... import _lib
+
+
+def _check(est, tgt):
+    if est.shape != tgt.shape:                      # sisdr.py:427
+        raise AssertionError("targets and estimates must have the same size, got %s vs %s" %
+                             (tuple(tgt.shape), tuple(est.shape)))
+    if est.dim() != 3:
+        raise RuntimeError("expected [batch, n_src, time], got %s" % (tuple(est.shape),))
+    if est.device.type != "cuda" or tgt.device != est.device:
+        raise _lib.SrfError("sudo_rm_rf_amd losses run on an MI355X only (estimates on %s, targets on %s); there "
+                            "is deliberately no CPU fallback" % (est.device, tgt.device))
+    if est.shape[1] > 4:
+        raise NotImplementedError("the HIP PIT loss supports up to 4 sources, got %d" % est.shape[1])
+
+
+def _forward(est, tgt, want_pw):
+    lib = _lib.load()
+    Bt, S, T = est.shape
+    dev = est.device
+    work = torch.empty(lib.srf_pit_sisdr_work_bytes(Bt, S), dtype=torch.uint8, device=dev)
+    loss = torch.empty(2, dtype=torch.float32, device=dev)
+    pw = torch.empty((Bt, S, S), dtype=torch.float32, device=dev) if want_pw else None
+    rc = lib.srf_pit_sisdr_forward(_lib.ptr(est), _lib.ptr(tgt), Bt, S, T, C.c_float(0.0), _lib.ptr(work),
+                                   _lib.ptr(pw), _lib.ptr(loss), _lib.current_stream(dev))
+    _lib.check(rc, "srf_pit_sisdr_forward")
+    return work, loss, pw
+
+
+class _PitSisdr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, est, tgt):
+        est_c = est.detach().to(torch.float32).contiguous()
+        tgt_c = tgt.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(est.device):
+            work, loss, _ = _forward(est_c, tgt_c, False)
+        ctx.save_for_backward(est_c, tgt_c, work, loss)
+        ctx.in_dtype = est.dtype
+        return loss[1].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        est, tgt, work, loss = ctx.saved_tensors
+        Bt, S, T = est.shape
+        up = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        grad = torch.empty_like(est)
+        with torch.cuda.device(est.device):
+            rc = _lib.load().srf_pit_sisdr_backward(_lib.ptr(est), _lib.ptr(tgt), Bt, S, T, C.c_float(0.0),
+                                                    _lib.ptr(work), _lib.ptr(loss), _lib.ptr(up), _lib.ptr(grad),
+                                                    _lib.current_stream(est.device))
+        _lib.check(rc, "srf_pit_sisdr_backward")
+        return grad.to(ctx.in_dtype), None
+
+
+class PairwiseNegSDR(_Loss):
+    """Pairwise negative SI-SDR on a batch (reference: losses/sisdr.py:390-458): [batch, n_src, time] x 2 ->
+    [batch, n_src (estimates), n_src (targets)]."""
+
+    def __init__(self, sdr_type, zero_mean=True, take_log=True):
+        super().__init__()
+        assert sdr_type in ["snr", "sisdr", "sdsdr"]            # sisdr.py:421
+        self.sdr_type = sdr_type
+        self.zero_mean = zero_mean
+        self.take_log = take_log
+
+    def _supported(self):
+        if self.sdr_type != "sisdr" or not self.zero_mean or not self.take_log:
+            raise NotImplementedError("the HIP path implements PairwiseNegSDR('sisdr', zero_mean=True, "
+                                      "take_log=True), the configuration the reference's runners train with")
+
+    def forward(self, est_targets, targets):
+        self._supported()
+        _check(est_targets, targets)
+        if torch.is_grad_enabled() and est_targets.requires_grad:
+            raise NotImplementedError("gradients flow through PITLossWrapper(PairwiseNegSDR('sisdr'), "
+                                      "pit_from='pw_mtx'); the bare pairwise matrix is forward-only")
+        est = est_targets.detach().to(torch.float32).contiguous()
+        tgt = targets.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(est.device):
+            return _forward(est, tgt, True)[2]
+
+
+class PITLossWrapper(nn.Module):
+    """Permutation-invariant wrapper (reference: losses/sisdr.py:199-387), 'pw_mtx' mode."""
+
+    def __init__(self, loss_func, pit_from='pw_mtx', perm_reduce=None):
+        super().__init__()
+        self.loss_func = loss_func
+        self.pit_from = pit_from
+        self.perm_reduce = perm_reduce
+        if self.pit_from not in ['pw_mtx', 'pw_pt', 'perm_avg']:          # sisdr.py:249-251
+            raise ValueError('Unsupported loss function type for now. Expected'
+                             'one of [`pw_mtx`, `pw_pt`, `perm_avg`]')
+
+    def forward(self, est_targets, targets, return_est=False, reduce_kwargs=None, **kwargs):
+        n_src = targets.shape[1]
+        assert n_src < 10, f"Expected source axis along dim 1, found {n_src}"      # sisdr.py:274
+        if self.pit_from != 'pw_mtx' or self.perm_reduce is not None or not isinstance(self.loss_func, PairwiseNegSDR):
+            raise NotImplementedError("the HIP path implements PITLossWrapper(PairwiseNegSDR('sisdr'), "
+                                      "pit_from='pw_mtx') (run_improved_sudormrf.py:63-66)")
+        self.loss_func._supported()
+        _check(est_targets, targets)
+        mean_loss = _PitSisdr.apply(est_targets, targets)
+        if not return_est:
+            return mean_loss
+        return mean_loss, self.reorder_source(est_targets, targets)
+
+    @staticmethod
+    def reorder_source(est_targets, targets):
+        """Estimates re-ordered so that source j is the estimate matched with target j (sisdr.py:309-311)."""
+        lib = _lib.load()
+        Bt, S, T = est_targets.shape
+        est = est_targets.detach().to(torch.float32).contiguous()
+        tgt = targets.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(est.device):
+            work, _, _ = _forward(est, tgt, False)
+            match = torch.empty((Bt, S), dtype=torch.int32, device=est.device)
+            rc = lib.srf_pit_sisdr_match(_lib.ptr(work), Bt, S, _lib.ptr(match), _lib.current_stream(est.device))
+            _lib.check(rc, "srf_pit_sisdr_match")
+        idx = match.long().unsqueeze(-1).expand(Bt, S, T)
+        return torch.gather(est_targets, 1, idx)

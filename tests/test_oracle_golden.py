@@ -73,3 +73,34 @@ def test_trace_keys(manifest):
     assert set(tr_np) == set(tr_t)
     for k in tr_np:
         assert np.abs(tr_np[k] - tr_t[k].numpy()).max() < 1e-4, k
+
+
+# ---------------------------------------------------------------------------------------------
+# training loss: oracle/loss_oracle.py vs fixtures generated from the reference's own
+# losses/sisdr.py (tools/make_golden_loss.py)
+# ---------------------------------------------------------------------------------------------
+def _loss_manifest():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "LOSS_MANIFEST.json")))
+
+
+@pytest.mark.parametrize("name", sorted(_loss_manifest()))
+def test_loss_oracle_matches_reference_golden(name):
+    import itertools
+    import os
+    from oracle import loss_oracle
+    c = _loss_manifest()[name]
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    est, tgt = loss_oracle.make_loss_case(c["batch"], c["n_src"], c["T"], c["seed"], c["snr_db"], c["mode"])
+    loss, raw, pw, match, grad = loss_oracle.loss_and_grad(est, tgt)
+    assert abs(loss - float(z["loss"])) <= 2e-5 * max(1.0, abs(loss))
+    assert abs(raw - float(z["raw"])) <= 1e-5 * max(1.0, abs(raw)) + 1e-4
+    assert (np.abs(pw - z["pw"]) <= 1e-4 + 5e-6 * np.abs(z["pw"])).all()
+    perms = list(itertools.permutations(range(c["n_src"])))
+    assert (np.array([perms[i] for i in z["perm_index"]]) == match).all()
+    k = z["grad_prefix"].shape[-1]
+    scale = max(np.abs(z["grad_prefix"]).max(), 1e-12)
+    assert np.abs(grad[..., :k] - z["grad_prefix"]).max() <= 2e-5 * scale
+    assert np.abs(grad.sum(-1) - z["grad_sum"]).max() <= 1e-5
+    assert np.abs((grad ** 2).sum(-1) - z["grad_sqsum"]).max() <= 1e-4 * max(z["grad_sqsum"].max(), 1e-12)

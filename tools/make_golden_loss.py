@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/loss_*.npz from the REAL reference loss (build container only).
+
+Imports losses/sisdr.py from /root/reference by file path, evaluates
+    torch.clamp(PITLossWrapper(PairwiseNegSDR("sisdr"), pit_from='pw_mtx')(est, tgt), -30, 30)
+(run_improved_sudormrf.py:63-66,169-171) in fp32 on seeded inputs (oracle/loss_oracle.make_loss_case) and stores
+loss, pairwise matrix, best permutation and the autograd gradient w.r.t. the estimates.
+
+    python tools/make_golden_loss.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from make_golden import load_ref_module  # noqa: E402
+from oracle.loss_oracle import make_loss_case  # noqa: E402
+
+# name: (batch, n_src, T, seed, snr_db, mode)
+CASES = {
+    "loss_noisy_s2": (4, 2, 4000, 1, 5.0, "noisy"),
+    "loss_noisy_s3": (3, 3, 1501, 2, 0.0, "noisy"),
+    "loss_high_snr": (2, 2, 8000, 3, 25.0, "noisy"),
+    "loss_random": (5, 2, 777, 4, 0.0, "random"),
+    "loss_exact_clamped": (2, 2, 1000, 5, 0.0, "exact"),
+    "loss_zero_clamped": (2, 2, 1000, 6, 0.0, "zero"),
+    "loss_cfg4_shape": (8, 2, 32000, 7, 8.0, "noisy"),
+}
+
+
+def main():
+    sisdr = load_ref_module("sudo_rm_rf/dnn/losses/sisdr.py", "_ref_sisdr")
+    loss_fn = sisdr.PITLossWrapper(sisdr.PairwiseNegSDR("sisdr"), pit_from="pw_mtx")
+    pw_fn = sisdr.PairwiseNegSDR("sisdr")
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    manifest = {}
+    for name, (B, S, T, seed, snr, mode) in CASES.items():
+        est_np, tgt_np = make_loss_case(B, S, T, seed, snr, mode)
+        est = torch.tensor(est_np, requires_grad=True)
+        tgt = torch.tensor(tgt_np)
+        raw = loss_fn(est, tgt)
+        l = torch.clamp(raw, min=-30.0, max=30.0)
+        l.backward()
+        with torch.no_grad():
+            pw = pw_fn(est, tgt)
+            _, idx = loss_fn.find_best_perm(pw, S)
+        g = est.grad.numpy()
+        keep = min(T, 2000)      # gradient: a prefix per row plus row-wise checksums keeps the files small
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), loss=np.float32(l.item()), raw=np.float32(raw.item()),
+                            pw=pw.numpy(), perm_index=idx.numpy().astype(np.int32), grad_prefix=g[..., :keep],
+                            grad_sum=g.sum(-1).astype(np.float64), grad_sqsum=(g.astype(np.float64) ** 2).sum(-1))
+        manifest[name] = dict(batch=B, n_src=S, T=T, seed=seed, snr_db=snr, mode=mode, loss=float(l.item()),
+                              raw=float(raw.item()))
+        print(name, manifest[name])
+    json.dump(manifest, open(os.path.join(out_dir, "LOSS_MANIFEST.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
