@@ -226,6 +226,17 @@ int srf_pit_sisdr_match(const void* work, int Bt, int S, int* match_out, void* s
 int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt, int S, int T, float clamp, const void* work,
                            const float* loss, const float* upstream, float* grad_est, void* stream);
 
+/* ---- training step, backward kernels (one entry point per kernel for unit parity) ---- */
+
+/* Weight / bias gradient of a pointwise conv y = W f(x) + bias (improved_sudormrf.py:174,196,256-259,268-269):
+ *   dw[m,n] = sum_{b,l} g[b,m,l] * f(x[b,n,l]),  dbias[m] = sum_{b,l} g[b,m,l]
+ * f = the forward's operand prologue (in_norm: GlobLN statistics of x + gamma/beta and/or PReLU slope; NULL = none).
+ * g: [Bt,Cout,L], x: [Bt,Cin,L], dw: [Cout,Cin], dbias: [Cout] or NULL; accumulate != 0 adds to dw / dbias.
+ * scratch: srf_pw_wgrad_scratch_bytes(...) bytes.  L % 4 == 0. */
+size_t srf_pw_wgrad_scratch_bytes(int Bt, int Cout, int Cin, int L);
+int srf_pw_wgrad(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout, int L, float* dw,
+                 float* dbias, int accumulate, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,28 @@ def mixture_consistency(pr_batch, input_mixture):
     return out
 
 
+def pw_wgrad(g, x, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None, dw=None, dbias=None, want_bias=True):
+    """Weight / bias gradient of a pointwise conv.  g [Bt,Cout,L], x [Bt,Cin,L] -> (dw [Cout,Cin], dbias [Cout]).
+    Passing dw / dbias accumulates into them."""
+    dev = _chk(g, x, in_sums, in_gamma, in_beta, in_prelu, dw, dbias)
+    Bt, Cout, L = g.shape
+    Cin = x.shape[1]
+    assert x.shape == (Bt, Cin, L)
+    lib = _lib.load()
+    acc = dw is not None
+    if dw is None:
+        dw = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+    if dbias is None and want_bias:
+        assert not acc
+        dbias = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.srf_pw_wgrad_scratch_bytes(Bt, Cout, Cin, L), dtype=torch.uint8, device=dev)
+    rc = lib.srf_pw_wgrad(_lib.ptr(g), _lib.ptr(x), _norm(in_sums, in_gamma, in_beta, in_prelu), Bt, Cin, Cout, L,
+                          _lib.ptr(dw), _lib.ptr(dbias), 1 if acc else 0, _lib.ptr(scratch),
+                          _lib.current_stream(dev))
+    _lib.check(rc, "srf_pw_wgrad")
+    return dw, dbias
+
+
 def wav_normalize(wav):
     """Per-row (x - mean) / (std + 1e-9), std unbiased (README.md:100-103).  wav [rows,T] or [Bt,1,T] ->
     (normalised wav of the same shape, stats [rows,2] = {mean, std})."""

@@ -1,0 +1,61 @@
+"""GPU parity of the training-step backward kernels against fp64 torch autograd of the same op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale + shift
+
+
+def dev32(t):
+    return t.to(torch.float32).to(DEV).contiguous()
+
+
+def rel_err(got, want):
+    return ((got.detach().cpu().double() - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+
+
+def gln64(x, gamma, beta):
+    m = x.mean(dim=(1, 2), keepdim=True)
+    v = ((x - m) ** 2).mean(dim=(1, 2), keepdim=True)
+    return gamma.view(1, -1, 1) * (x - m) / torch.sqrt(v + 1e-8) + beta.view(1, -1, 1)
+
+
+def sums64(x):
+    from sudo_rm_rf_amd import _lib
+    s = torch.zeros(x.shape[0], _lib.STAT_BUCKETS, 2, dtype=torch.float64)
+    s[:, 0, 0] = x.sum(dim=(1, 2))
+    s[:, 0, 1] = (x * x).sum(dim=(1, 2))
+    return s.to(DEV)
+
+
+@pytest.mark.parametrize("Bt,Cin,Cout,L", [(3, 256, 512, 3200), (2, 512, 256, 832), (2, 64, 42, 200), (5, 48, 160, 132),
+                                           (1, 16, 32, 36), (32, 256, 512, 3200)])
+@pytest.mark.parametrize("pro", [0, 1, 2, 3])
+def test_pw_wgrad(Bt, Cin, Cout, L, pro):
+    from sudo_rm_rf_amd import ops
+    if Bt == 32 and pro not in (0, 2):
+        pytest.skip("full-size case: proj / res_conv prologues only")
+    x = rnd(Bt, Cin, L, seed=1, scale=1.3, shift=0.2)
+    g = rnd(Bt, Cout, L, seed=2, scale=0.7)
+    gamma, beta = rnd(Cin, seed=3, scale=0.3, shift=1.0), rnd(Cin, seed=4, scale=0.3)
+    slope = torch.tensor([0.17], dtype=torch.float64)
+    fx, kw = x, {}
+    if pro in (1, 2):
+        fx = gln64(x, gamma, beta)
+        kw.update(in_sums=sums64(x), in_gamma=dev32(gamma), in_beta=dev32(beta))
+    if pro in (2, 3):
+        fx = torch.where(fx >= 0, fx, slope * fx)
+        kw.update(in_prelu=dev32(slope))
+    want_w = torch.einsum("bml,bnl->mn", g, fx)
+    want_b = g.sum(dim=(0, 2))
+    dw, db = ops.pw_wgrad(dev32(g), dev32(x), **kw)
+    assert rel_err(dw, want_w) <= 2e-5, rel_err(dw, want_w)
+    assert rel_err(db, want_b) <= 2e-5
+    dw2, db2 = ops.pw_wgrad(dev32(g), dev32(x), dw=dw.clone(), dbias=db.clone(), **kw)     # accumulate
+    assert rel_err(dw2, 2 * want_w) <= 2e-5 and rel_err(db2, 2 * want_b) <= 2e-5
