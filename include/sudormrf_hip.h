@@ -237,6 +237,14 @@ size_t srf_pw_wgrad_scratch_bytes(int Bt, int Cout, int Cin, int L);
 int srf_pw_wgrad(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout, int L, float* dw,
                  float* dbias, int accumulate, void* scratch, void* stream);
 
+/* GlobLN (+PReLU when norm->prelu) backward (improved_sudormrf.py:30-47, PReLU of ConvNormAct :73 / NormAct :113).
+ * gout (+ optional gout2, added on load): gradient w.r.t. the normalised (activated) tensor; x: the GlobLN input;
+ * norm: {sums of x, gamma, beta, slope}.  gx (accumulate_gx != 0: added to).  dgamma, dbeta [C], dslope [1] are
+ * ACCUMULATED into (NULL = skip).  scratch: srf_gln_bwd_scratch_bytes(groups, C). */
+size_t srf_gln_bwd_scratch_bytes(int groups, int C);
+int srf_gln_bwd(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C, int L,
+                float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,8 @@ _PROTOS = {
     "srf_pit_sisdr_backward": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "srf_pw_wgrad_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "srf_pw_wgrad": (_i, [_vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "srf_gln_bwd_scratch_bytes": (_sz, [_i, _i]),
+    "srf_gln_bwd": (_i, [_vp, _vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "srf_wav_normalize": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "srf_wav_denormalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srf_dwconv5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp]),

@@ -1,0 +1,180 @@
+// Backward kernels of the streaming ops (training step).  Each mirrors one autograd node
+// of the reference's forward graph; the per-kernel entry points exist for unit parity against torch autograd.
+//   GlobLN (+PReLU) backward        improved_sudormrf.py:30-47 (+ :13-27 affine, PReLU of ConvNormAct/NormAct)
+//   Upsample(x2 nearest)+add merge  improved_sudormrf.py:190-194,214-216
+//   depthwise k=5 conv (s=1|2)      improved_sudormrf.py:138-159,178-189
+//   mask ReLU * encoder output      improved_sudormrf.py:296-298
+//   conv_transpose1d / conv1d frame gathers for the decoder / encoder weight gradients  :247-251,272-279
+#include "srf_common.h"
+
+// =============================================================================================
+// GlobLN (+PReLU) backward.   z = gamma_c * xh + beta_c, xh = (x - mean_b) * rstd_b, out = PReLU_a(z)
+//   g_z   = g_out * (z >= 0 ? 1 : a)                 d a    += sum g_out * z [z < 0]
+//   d gamma_c += sum_{b,t} g_z xh                    d beta_c += sum_{b,t} g_z
+//   g_x   = rstd_b * (gamma_c g_z - S1_b / n - xh * S2_b / n),   S1_b = sum_{c,t} gamma_c g_z,  S2_b = sum gamma_c g_z xh
+// Pass A: one block per row (b, c): {sum g_z, sum g_z xh, slope term} -> rowpart (plain stores) and S1/S2 into
+// the per-example fp64 buckets (same bucketed layout as the forward statistics: no same-address atomics).
+// Pass A2: per-channel reduction of rowpart over the batch.  Pass B: apply.
+// =============================================================================================
+struct GlnBwdArgs {
+  const float* gout;
+  const float* gout2;   // optional second gradient contribution, added on load
+  const float* x;
+  SrfNormDev nrm;
+  double inv_count;
+  float* rowpart;       // [rows][4]
+  double* bsums;        // [groups][SRF_STAT_BUCKETS][2]  {S1, S2}
+  float* gx;
+  int C, L, accumulate;
+};
+
+__global__ __launch_bounds__(256) void srf_gln_bwd_reduce_kernel(GlnBwdArgs a) {
+  __shared__ float red[4][3];
+  const long row = blockIdx.x;
+  const int c = (int)(row % a.C);
+  const long g = row / a.C;
+  float mean, rstd;
+  srf_finalize_stats(a.nrm.sums, g, a.inv_count, mean, rstd);
+  const float gam = a.nrm.gamma[c], bet = a.nrm.beta[c];
+  const bool act = a.nrm.prelu != nullptr;
+  const float slope = act ? a.nrm.prelu[0] : 1.f;
+  const float* go = a.gout + row * (long)a.L;
+  const float* go2 = a.gout2 ? a.gout2 + row * (long)a.L : nullptr;
+  const float* xr = a.x + row * (long)a.L;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int l = threadIdx.x; l < a.L; l += 256) {
+    float gv = go[l];
+    if (go2) gv += go2[l];
+    const float xh = (xr[l] - mean) * rstd;
+    const float z = fmaf(gam, xh, bet);
+    float gz = gv;
+    if (act && z < 0.f) {
+      s2 = fmaf(gv, z, s2);
+      gz = gv * slope;
+    }
+    s0 += gz;
+    s1 = fmaf(gz, xh, s1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[w][0] = s0;
+    red[w][1] = s1;
+    red[w][2] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    const float t1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    const float t2 = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+    float* rp = a.rowpart + row * 4;
+    rp[0] = t0;
+    rp[1] = t1;
+    rp[2] = t2;
+    double* dst = srf_stat_slot(a.bsums, g, c);
+    atomicAdd(dst, (double)gam * (double)t0);
+    atomicAdd(dst + 1, (double)gam * (double)t1);
+  }
+}
+
+// per channel: dgamma[c] += sum_b rowpart[b][c][1], dbeta[c] += sum_b rowpart[b][c][0]; slope: one atomic per block
+__global__ __launch_bounds__(256) void srf_gln_bwd_params_kernel(const float* __restrict__ rowpart, int groups, int C,
+                                                                 float* dgamma, float* dbeta, float* dslope) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  double sg = 0.0, sb = 0.0, ss = 0.0;
+  if (c < C) {
+    for (int g = 0; g < groups; ++g) {
+      const float* rp = rowpart + ((long)g * C + c) * 4;
+      sb += (double)rp[0];
+      sg += (double)rp[1];
+      ss += (double)rp[2];
+    }
+    if (dgamma) dgamma[c] += (float)sg;
+    if (dbeta) dbeta[c] += (float)sb;
+  }
+  if (dslope) {
+    __shared__ double red[4];
+    ss = srf_wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dslope, (float)((red[0] + red[1]) + (red[2] + red[3])));
+  }
+}
+
+__global__ __launch_bounds__(256) void srf_gln_bwd_apply_kernel(GlnBwdArgs a, int chunks) {
+  const long row = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - row * chunks;
+  const int c = (int)(row % a.C);
+  const long g = row / a.C;
+  float mean, rstd;
+  srf_finalize_stats(a.nrm.sums, g, a.inv_count, mean, rstd);
+  // S1, S2 from the buckets (same access pattern as srf_finalize_stats)
+  const double2 bk = reinterpret_cast<const double2*>(a.bsums)[g * SRF_STAT_BUCKETS + (threadIdx.x & (SRF_STAT_BUCKETS - 1))];
+  const float m1 = (float)(srf_wave_sum(bk.x) * a.inv_count), m2 = (float)(srf_wave_sum(bk.y) * a.inv_count);
+  const float gam = a.nrm.gamma[c], bet = a.nrm.beta[c];
+  const bool act = a.nrm.prelu != nullptr;
+  const float slope = act ? a.nrm.prelu[0] : 1.f;
+  const size_t base = (size_t)row * a.L;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int l = chunk * 1024 + u * 256 + threadIdx.x;
+    if (l < a.L) {
+      float gv = a.gout[base + l];
+      if (a.gout2) gv += a.gout2[base + l];
+      const float xh = (a.x[base + l] - mean) * rstd;
+      const float z = fmaf(gam, xh, bet);
+      const float gz = (act && z < 0.f) ? gv * slope : gv;
+      float r = rstd * (gam * gz - m1 - xh * m2);
+      if (a.accumulate) r += a.gx[base + l];
+      a.gx[base + l] = r;
+    }
+  }
+}
+
+extern "C" size_t srf_gln_bwd_scratch_bytes(int groups, int C) {
+  if (groups <= 0 || C <= 0) return 0;
+  return sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2 + sizeof(float) * (size_t)groups * C * 4;
+}
+
+// gout (+gout2): [groups,C,L] gradient w.r.t. PReLU(GlobLN(x)) (PReLU only if norm->prelu); x: the GlobLN input;
+// norm: statistics of x, gamma, beta, slope.  gx: [groups,C,L] (accumulate_gx != 0: added to).  dgamma/dbeta [C],
+// dslope [1] are ACCUMULATED into (NULL = skip).
+extern "C" int srf_gln_bwd(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
+                           int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope,
+                           void* scratch, void* stream) {
+  SRF_CHECK_ARG(gout && x && norm && norm->sums && norm->gamma && norm->beta && gx && scratch,
+                "srf_gln_bwd: null pointer");
+  SRF_CHECK_ARG(groups > 0 && C > 0 && L > 0, "srf_gln_bwd: bad sizes");
+  const long rows = (long)groups * C;
+  const int chunks = (L + 1023) / 1024;
+  SRF_CHECK_ARG(rows * chunks < (1L << 31), "srf_gln_bwd: tensor too large");
+  hipStream_t st = (hipStream_t)stream;
+  GlnBwdArgs a;
+  a.gout = gout;
+  a.gout2 = gout2;
+  a.x = x;
+  a.nrm = srf_norm_dev(norm);
+  a.inv_count = 1.0 / ((double)C * (double)L);
+  a.bsums = reinterpret_cast<double*>(scratch);
+  a.rowpart = reinterpret_cast<float*>(a.bsums + (size_t)groups * SRF_STAT_BUCKETS * 2);
+  a.gx = gx;
+  a.C = C;
+  a.L = L;
+  a.accumulate = accumulate_gx;
+  SRF_CHECK_HIP(hipMemsetAsync(a.bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
+  hipLaunchKernelGGL(srf_gln_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, a);
+  SRF_CHECK_LAUNCH("gln_bwd_reduce", st);
+  if (dgamma || dbeta || (dslope && norm->prelu)) {
+    hipLaunchKernelGGL(srf_gln_bwd_params_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, a.rowpart, groups,
+                       C, dgamma, dbeta, norm->prelu ? dslope : nullptr);
+    SRF_CHECK_LAUNCH("gln_bwd_params", st);
+  }
+  hipLaunchKernelGGL(srf_gln_bwd_apply_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, st, a, chunks);
+  SRF_CHECK_LAUNCH("gln_bwd_apply", st);
+  return SRF_OK;
+}

@@ -221,6 +221,27 @@ def pw_wgrad(g, x, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None, dw=
     return dw, dbias
 
 
+def gln_bwd(gout, x, sums, gamma, beta, prelu=None, gout2=None, gx=None, dgamma=None, dbeta=None, dslope=None):
+    """GlobLN (+PReLU) backward.  Returns (gx, dgamma, dbeta, dslope); passing gx / d* accumulates into them."""
+    dev = _chk(gout, x, sums, gamma, beta, prelu, gout2, gx, dgamma, dbeta, dslope)
+    groups, Cc, L = x.shape
+    lib = _lib.load()
+    acc = gx is not None
+    if gx is None:
+        gx = torch.empty_like(x)
+    dgamma = torch.zeros(Cc, dtype=torch.float32, device=dev) if dgamma is None else dgamma
+    dbeta = torch.zeros(Cc, dtype=torch.float32, device=dev) if dbeta is None else dbeta
+    if prelu is not None and dslope is None:
+        dslope = torch.zeros(1, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.srf_gln_bwd_scratch_bytes(groups, Cc), dtype=torch.uint8, device=dev)
+    n = _norm(sums, gamma, beta, prelu)
+    rc = lib.srf_gln_bwd(_lib.ptr(gout), _lib.ptr(gout2), _lib.ptr(x), n, groups, Cc, L, _lib.ptr(gx),
+                         1 if acc else 0, _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dslope), _lib.ptr(scratch),
+                         _lib.current_stream(dev))
+    _lib.check(rc, "srf_gln_bwd")
+    return gx, dgamma, dbeta, dslope
+
+
 def wav_normalize(wav):
     """Per-row (x - mean) / (std + 1e-9), std unbiased (README.md:100-103).  wav [rows,T] or [Bt,1,T] ->
     (normalised wav of the same shape, stats [rows,2] = {mean, std})."""

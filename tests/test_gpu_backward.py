@@ -59,3 +59,31 @@ def test_pw_wgrad(Bt, Cin, Cout, L, pro):
     assert rel_err(db, want_b) <= 2e-5
     dw2, db2 = ops.pw_wgrad(dev32(g), dev32(x), dw=dw.clone(), dbias=db.clone(), **kw)     # accumulate
     assert rel_err(dw2, 2 * want_w) <= 2e-5 and rel_err(db2, 2 * want_b) <= 2e-5
+
+
+@pytest.mark.parametrize("Bt,C,L", [(3, 64, 3200), (2, 20, 203), (4, 5, 1), (32, 512, 400)])
+@pytest.mark.parametrize("act", [False, True])
+def test_gln_bwd(Bt, C, L, act):
+    from sudo_rm_rf_amd import ops
+    x = rnd(Bt, C, L, seed=10, scale=1.7, shift=-0.4).requires_grad_(True)
+    gamma = rnd(C, seed=11, scale=0.3, shift=1.0).requires_grad_(True)
+    beta = rnd(C, seed=12, scale=0.3).requires_grad_(True)
+    slope = torch.tensor([0.23], dtype=torch.float64, requires_grad=True)
+    gout, gout2 = rnd(Bt, C, L, seed=13), rnd(Bt, C, L, seed=14, scale=0.5)
+    y = gln64(x, gamma, beta)
+    if act:
+        y = torch.where(y >= 0, y, slope * y)
+    y.backward(gout + gout2)
+    gx, dg, db, ds = ops.gln_bwd(dev32(gout), dev32(x.detach()), sums64(x.detach()), dev32(gamma.detach()),
+                                 dev32(beta.detach()), prelu=dev32(slope.detach()) if act else None,
+                                 gout2=dev32(gout2))
+    assert rel_err(gx, x.grad) <= 3e-5, rel_err(gx, x.grad)
+    assert rel_err(dg, gamma.grad) <= 3e-5 and rel_err(db, beta.grad) <= 3e-5
+    if act:
+        assert rel_err(ds, slope.grad) <= 3e-5
+    # accumulation into existing buffers
+    gx2, dg2, db2, _ = ops.gln_bwd(dev32(gout), dev32(x.detach()), sums64(x.detach()), dev32(gamma.detach()),
+                                   dev32(beta.detach()), prelu=dev32(slope.detach()) if act else None,
+                                   gout2=dev32(gout2), gx=gx.clone(), dgamma=dg.clone(), dbeta=db.clone(),
+                                   dslope=ds.clone() if act else None)
+    assert rel_err(gx2, 2 * x.grad) <= 3e-5 and rel_err(dg2, 2 * gamma.grad) <= 3e-5 and rel_err(db2, 2 * beta.grad) <= 3e-5
