@@ -245,6 +245,17 @@ size_t srf_gln_bwd_scratch_bytes(int groups, int C);
 int srf_gln_bwd(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C, int L,
                 float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch, void* stream);
 
+/* Merge backward (improved_sudormrf.py:214-216): g_levels[k][j] = sum of g_merged over the 2^k samples level k was
+ * upsampled to, k = 1..D-1 ([rows, L >> k]); level 0's gradient IS g_merged (g_levels[0] is ignored). */
+int srf_merge_bwd(const float* g_merged, float* const* g_levels, int D, long rows, int L, void* stream);
+
+/* Depthwise k=5 conv backward (improved_sudormrf.py:138-159,178-189).  gd: [groups,C,Lout] gradient w.r.t. the conv
+ * output; xin: [groups,C,Lin] the conv's PRE-prologue input, in_norm its prologue (NULL = identity); gin: gradient
+ * w.r.t. the prologue's output (overwritten; NULL = skip); dw [C,5], dbias [C]: ACCUMULATED into (NULL = skip). */
+size_t srf_dwconv5_bwd_scratch_bytes(int groups, int C);
+int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups, int C,
+                    int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,3 +178,170 @@ extern "C" int srf_gln_bwd(const float* gout, const float* gout2, const float* x
   SRF_CHECK_LAUNCH("gln_bwd_apply", st);
   return SRF_OK;
 }
+
+// =============================================================================================
+// Merge backward.  merged[i] = sum_k n_k[i >> k]  (improved_sudormrf.py:214-216)  =>
+//   g_n_0 = g_merged,  g_n_k[j] = g_n_{k-1}[2j] + g_n_{k-1}[2j+1]      (a chain of pair sums)
+// =============================================================================================
+__global__ __launch_bounds__(256) void srf_pairsum_kernel(const float* __restrict__ in, float* __restrict__ out, long n_out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  const float2 v = reinterpret_cast<const float2*>(in)[i];
+  out[i] = v.x + v.y;
+}
+
+// g_levels[0] is not written (it IS g_merged); g_levels[k] : [rows, L >> k] for k = 1..D-1
+extern "C" int srf_merge_bwd(const float* g_merged, float* const* g_levels, int D, long rows, int L, void* stream) {
+  SRF_CHECK_ARG(g_merged && g_levels && D >= 1 && D <= SRF_MAX_DEPTH && rows > 0 && L > 0, "srf_merge_bwd: bad arguments");
+  SRF_CHECK_ARG((L % (1 << (D - 1))) == 0, "srf_merge_bwd: L must be a multiple of 2^(D-1)");
+  const float* src = g_merged;
+  for (int k = 1; k < D; ++k) {
+    SRF_CHECK_ARG(g_levels[k] != nullptr, "srf_merge_bwd: null level %d", k);
+    const long n_out = rows * (long)(L >> k);
+    hipLaunchKernelGGL(srf_pairsum_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       g_levels[k], n_out);
+    src = g_levels[k];
+  }
+  SRF_CHECK_LAUNCH("merge_bwd", stream);
+  return SRF_OK;
+}
+
+// =============================================================================================
+// Depthwise k=5 conv backward (stride 1 | 2, padding 2).   d[c,j] = bias[c] + sum_t w[c,t] u[c, s j + t - 2],
+// u = f(xin) = the forward's operand prologue (GlobLN of the previous level, + PReLU for level 0).
+//   g_u[c,i]  = sum_t w[c,t] g_d[c,(i + 2 - t)/s]   (terms with s | (i+2-t) and 0 <= j < Lout)
+//   d w[c,t] += sum_{b,j} g_d[b,c,j] u[b,c,s j + t - 2],   d bias[c] += sum_{b,j} g_d[b,c,j]
+// One block per row (b,c): row partials of the 6 parameter sums (reduced over the batch by a second kernel) and
+// the input gradient.
+// =============================================================================================
+struct DwBwdArgs {
+  const float* gd;
+  const float* xin;
+  SrfNormDev nrm;
+  double inv_count;
+  const float* w;
+  float* gin;
+  float* rowpart;   // [rows][8]
+  int C, Lin, Lout, stride;
+};
+
+__global__ __launch_bounds__(256) void srf_dwconv5_bwd_kernel(DwBwdArgs a) {
+  __shared__ float red[4][6];
+  const long row = blockIdx.x;
+  const int c = (int)(row % a.C);
+  const long g = row / a.C;
+  float sc = 1.f, sh = 0.f;
+  if (a.nrm.sums) {
+    float mean, rstd;
+    srf_finalize_stats(a.nrm.sums, g, a.inv_count, mean, rstd);
+    sc = a.nrm.gamma[c] * rstd;
+    sh = a.nrm.beta[c] - mean * sc;
+  }
+  const bool act = a.nrm.prelu != nullptr;
+  const float slope = act ? a.nrm.prelu[0] : 1.f;
+  float w[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) w[t] = a.w[c * 5 + t];
+  const float* gd = a.gd + row * (long)a.Lout;
+  const float* xr = a.xin + row * (long)a.Lin;
+  const int s = a.stride, Lin = a.Lin, Lout = a.Lout;
+  // ---- parameter sums
+  float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j = threadIdx.x; j < Lout; j += 256) {
+    const float gv = gd[j];
+    p[5] += gv;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int i = s * j + t - 2;
+      if (i >= 0 && i < Lin) {
+        float u = fmaf(xr[i], sc, sh);
+        if (act) u = srf_prelu(u, slope);
+        p[t] = fmaf(gv, u, p[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) p[k] += __shfl_xor(p[k], o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[threadIdx.x >> 6][k] = p[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    a.rowpart[row * 8 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  }
+  // ---- input gradient
+  if (a.gin) {
+    float* gi = a.gin + row * (long)Lin;
+    for (int i = threadIdx.x; i < Lin; i += 256) {
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int num = i + 2 - t;
+        if (num >= 0 && (s == 1 || (num & 1) == 0)) {
+          const int j = s == 1 ? num : num >> 1;
+          if (j < Lout) acc = fmaf(w[t], gd[j], acc);
+        }
+      }
+      gi[i] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void srf_dwconv5_bwd_params_kernel(const float* __restrict__ rowpart, int groups, int C,
+                                                                     float* dw, float* dbias) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int g = 0; g < groups; ++g) {
+    const float* rp = rowpart + ((long)g * C + c) * 8;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] += (double)rp[k];
+  }
+  if (dw) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t) dw[c * 5 + t] += (float)s[t];
+  }
+  if (dbias) dbias[c] += (float)s[5];
+}
+
+extern "C" size_t srf_dwconv5_bwd_scratch_bytes(int groups, int C) {
+  return groups > 0 && C > 0 ? sizeof(float) * (size_t)groups * C * 8 : 0;
+}
+
+// gd: [groups,C,Lout]; xin: [groups,C,Lin] the PRE-norm input tensor of this conv, in_norm its prologue (NULL =
+// identity); gin: [groups,C,Lin] gradient w.r.t. the prologue's OUTPUT (overwritten; NULL = skip); dw [C,5] and
+// dbias [C] are ACCUMULATED into.
+extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups,
+                               int C, int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch,
+                               void* stream) {
+  SRF_CHECK_ARG(gd && xin && w && scratch, "srf_dwconv5_bwd: null pointer");
+  SRF_CHECK_ARG(groups > 0 && C > 0 && Lin > 0 && (stride == 1 || stride == 2), "srf_dwconv5_bwd: bad sizes");
+  const long rows = (long)groups * C;
+  SRF_CHECK_ARG(rows < (1L << 31), "srf_dwconv5_bwd: too many rows");
+  DwBwdArgs a;
+  a.gd = gd;
+  a.xin = xin;
+  a.nrm = srf_norm_dev(in_norm);
+  a.inv_count = 1.0 / ((double)C * (double)Lin);
+  a.w = w;
+  a.gin = gin;
+  a.rowpart = reinterpret_cast<float*>(scratch);
+  a.C = C;
+  a.Lin = Lin;
+  a.Lout = (Lin - 1) / stride + 1;
+  a.stride = stride;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(srf_dwconv5_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, st, a);
+  SRF_CHECK_LAUNCH("dwconv5_bwd", st);
+  if (dw || dbias) {
+    hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, a.rowpart,
+                       groups, C, dw, dbias);
+    SRF_CHECK_LAUNCH("dwconv5_bwd_params", st);
+  }
+  return SRF_OK;
+}

@@ -242,6 +242,34 @@ def gln_bwd(gout, x, sums, gamma, beta, prelu=None, gout2=None, gx=None, dgamma=
     return gx, dgamma, dbeta, dslope
 
 
+def merge_bwd(g_merged, D):
+    """-> [g_merged, g_n_1, ..., g_n_{D-1}] (level k: [groups, C, L >> k])."""
+    dev = _chk(g_merged)
+    groups, Cc, L = g_merged.shape
+    outs = [g_merged] + [torch.empty((groups, Cc, L >> k), dtype=torch.float32, device=dev) for k in range(1, D)]
+    arr = (C.c_void_p * D)(*[t.data_ptr() for t in outs])
+    rc = _lib.load().srf_merge_bwd(_lib.ptr(g_merged), arr, D, groups * Cc, L, _lib.current_stream(dev))
+    _lib.check(rc, "srf_merge_bwd")
+    return outs
+
+
+def dwconv5_bwd(gd, xin, weight, stride, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None, dw=None,
+                dbias=None, want_gin=True):
+    """Depthwise conv backward -> (gin, dw [C,1,5], dbias [C]); dw / dbias passed in are accumulated into."""
+    dev = _chk(gd, xin, weight, in_sums, in_gamma, in_beta, in_prelu, dw, dbias)
+    groups, Cc, Lin = xin.shape
+    lib = _lib.load()
+    gin = torch.empty_like(xin) if want_gin else None
+    dw = torch.zeros((Cc, 1, 5), dtype=torch.float32, device=dev) if dw is None else dw
+    dbias = torch.zeros((Cc,), dtype=torch.float32, device=dev) if dbias is None else dbias
+    scratch = torch.empty(lib.srf_dwconv5_bwd_scratch_bytes(groups, Cc), dtype=torch.uint8, device=dev)
+    rc = lib.srf_dwconv5_bwd(_lib.ptr(gd), _lib.ptr(xin), _norm(in_sums, in_gamma, in_beta, in_prelu), _lib.ptr(weight),
+                             groups, Cc, Lin, stride, _lib.ptr(gin), _lib.ptr(dw), _lib.ptr(dbias), _lib.ptr(scratch),
+                             _lib.current_stream(dev))
+    _lib.check(rc, "srf_dwconv5_bwd")
+    return gin, dw, dbias
+
+
 def wav_normalize(wav):
     """Per-row (x - mean) / (std + 1e-9), std unbiased (README.md:100-103).  wav [rows,T] or [Bt,1,T] ->
     (normalised wav of the same shape, stats [rows,2] = {mean, std})."""

@@ -87,3 +87,46 @@ def test_gln_bwd(Bt, C, L, act):
                                    gout2=dev32(gout2), gx=gx.clone(), dgamma=dg.clone(), dbeta=db.clone(),
                                    dslope=ds.clone() if act else None)
     assert rel_err(gx2, 2 * x.grad) <= 3e-5 and rel_err(dg2, 2 * gamma.grad) <= 3e-5 and rel_err(db2, 2 * beta.grad) <= 3e-5
+
+
+@pytest.mark.parametrize("Bt,C,L,D", [(2, 16, 3200, 5), (3, 5, 64, 3), (1, 7, 32, 6), (2, 4, 10, 1)])
+def test_merge_bwd(Bt, C, L, D):
+    from sudo_rm_rf_amd import ops
+    levels = [rnd(Bt, C, L >> k, seed=20 + k).requires_grad_(True) for k in range(D)]
+    out = levels[-1]
+    for k in range(D - 2, -1, -1):                                       # improved_sudormrf.py:214-216
+        out = levels[k] + F.interpolate(out, scale_factor=2, mode="nearest")
+    gm = rnd(Bt, C, L, seed=30)
+    out.backward(gm)
+    got = ops.merge_bwd(dev32(gm), D)
+    for k in range(D):
+        assert rel_err(got[k], levels[k].grad) <= 1e-6
+
+
+@pytest.mark.parametrize("Bt,C,Lin,stride", [(2, 64, 3200, 1), (2, 64, 3200, 2), (3, 20, 200, 2), (1, 3, 7, 1),
+                                             (2, 3, 5, 2), (1, 2, 1, 1), (4, 512, 400, 2)])
+@pytest.mark.parametrize("pro", [0, 1, 2])
+def test_dwconv5_bwd(Bt, C, Lin, stride, pro):
+    from sudo_rm_rf_amd import ops
+    x = rnd(Bt, C, Lin, seed=40, scale=1.4, shift=0.3)
+    w = rnd(C, 1, 5, seed=41, scale=0.4).requires_grad_(True)
+    b = rnd(C, seed=42, scale=0.2).requires_grad_(True)
+    gamma, beta = rnd(C, seed=43, scale=0.3, shift=1.0), rnd(C, seed=44, scale=0.3)
+    slope = torch.tensor([0.21], dtype=torch.float64)
+    u, kw = x, {}
+    if pro >= 1:
+        u = gln64(x, gamma, beta)
+        kw.update(in_sums=sums64(x), in_gamma=dev32(gamma), in_beta=dev32(beta))
+    if pro == 2:
+        u = torch.where(u >= 0, u, slope * u)
+        kw.update(in_prelu=dev32(slope))
+    u = u.detach().requires_grad_(True)
+    d = F.conv1d(u, w, b, stride=stride, padding=2, groups=C)
+    gd = rnd(*d.shape, seed=45)
+    d.backward(gd)
+    gin, dw, db = ops.dwconv5_bwd(dev32(gd), dev32(x), dev32(w.detach()), stride, **kw)
+    assert rel_err(gin, u.grad) <= 2e-6
+    assert rel_err(dw, w.grad) <= 2e-5 and rel_err(db, b.grad) <= 2e-5
+    _, dw2, db2 = ops.dwconv5_bwd(dev32(gd), dev32(x), dev32(w.detach()), stride, dw=dw.clone(), dbias=db.clone(),
+                                  want_gin=False, **kw)
+    assert rel_err(dw2, 2 * w.grad) <= 2e-5 and rel_err(db2, 2 * b.grad) <= 2e-5
