@@ -256,6 +256,22 @@ size_t srf_dwconv5_bwd_scratch_bytes(int groups, int C);
 int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups, int C,
                     int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch, void* stream);
 
+/* Mask application v = relu(m) * enc (improved_sudormrf.py:296-298; the inference path fuses it into the mask GEMM)
+ * and its backward: gm = gv * enc * [m > 0] (may alias gv), genc (+)= sum_s gv * relu(m).
+ * m, v, gv, gm: [Bt, SA*N, L]; enc, genc: [Bt, N, L]. */
+int srf_mask_apply(const float* m, const float* enc, float* v, int Bt, int SA, int N, int L, void* stream);
+int srf_mask_bwd(const float* gv, const float* m, const float* enc, float* gm, float* genc, int accumulate_genc, int Bt,
+                 int SA, int N, int L, void* stream);
+
+/* Stand-alone PReLU backward (mask_net.0, improved_sudormrf.py:268): gx = gout * (x >= 0 ? 1 : a) (may alias gout),
+ * dslope[0] += sum gout * x [x < 0] (NULL = skip). */
+int srf_prelu_bwd(const float* gout, const float* x, const float* slope, float* gx, float* dslope, long n, void* stream);
+
+/* out[b, r*K + k, l] = src[b, r, hop*l + k - pad] (0 outside [0,T); rows R*K..rows_out-1 are zero).  src: [Bt,R,T],
+ * out: [Bt,rows_out,L].  Feeds the encoder's weight gradient and the decoder's backward (:247-251, :272-279). */
+int srf_frames_gather(const float* src, float* out, int Bt, int R, int T, int K, int hop, int pad, int L, int rows_out,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

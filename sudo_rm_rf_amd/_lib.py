@@ -70,6 +70,10 @@ _PROTOS = {
     "srf_merge_bwd": (_i, [_vp, C.POINTER(_vp), _i, C.c_long, _i, _vp]),
     "srf_dwconv5_bwd_scratch_bytes": (_sz, [_i, _i]),
     "srf_dwconv5_bwd": (_i, [_vp, _vp, C.POINTER(srf_norm), _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "srf_mask_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "srf_mask_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srf_prelu_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_long, _vp]),
+    "srf_frames_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "srf_wav_normalize": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "srf_wav_denormalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srf_dwconv5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp]),

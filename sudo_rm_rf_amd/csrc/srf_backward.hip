@@ -345,3 +345,134 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
   }
   return SRF_OK;
 }
+
+// =============================================================================================
+// Mask application and its backward (improved_sudormrf.py:296-298): v[b, s N + n, l] = relu(m[b, s N + n, l]) * e[b, n, l]
+// The inference path fuses this into the mask GEMM's epilogue; training needs the pre-activation m afterwards,
+// so the training forward writes m and applies the mask here.
+//   g_m = g_v * e * [m > 0]            g_e[b,n,l] += sum_s g_v[b, s N + n, l] * relu(m[b, s N + n, l])
+// =============================================================================================
+__global__ __launch_bounds__(256) void srf_mask_apply_kernel(const float* __restrict__ m, const float* __restrict__ e,
+                                                             float* __restrict__ v, int SA, int N, int L) {
+  const long b = blockIdx.z;
+  const int n = blockIdx.y;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  const float ev = e[(b * N + n) * (long)L + l];
+  for (int s = 0; s < SA; ++s) {
+    const size_t idx = ((size_t)b * SA * N + (size_t)s * N + n) * L + l;
+    v[idx] = fmaxf(m[idx], 0.f) * ev;
+  }
+}
+
+__global__ __launch_bounds__(256) void srf_mask_bwd_kernel(const float* __restrict__ gv, const float* __restrict__ m,
+                                                           const float* __restrict__ e, float* __restrict__ gm,
+                                                           float* __restrict__ ge, int SA, int N, int L, int acc_ge) {
+  const long b = blockIdx.z;
+  const int n = blockIdx.y;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  const size_t eidx = (b * N + n) * (size_t)L + l;
+  const float ev = e[eidx];
+  float accum = acc_ge ? ge[eidx] : 0.f;
+  for (int s = 0; s < SA; ++s) {
+    const size_t idx = ((size_t)b * SA * N + (size_t)s * N + n) * L + l;
+    const float mv = m[idx], g = gv[idx];
+    gm[idx] = mv > 0.f ? g * ev : 0.f;
+    accum = fmaf(g, fmaxf(mv, 0.f), accum);
+  }
+  ge[eidx] = accum;
+}
+
+extern "C" int srf_mask_apply(const float* m, const float* enc, float* v, int Bt, int SA, int N, int L, void* stream) {
+  SRF_CHECK_ARG(m && enc && v && Bt > 0 && SA > 0 && N > 0 && L > 0 && Bt <= 65535 && N <= 65535, "srf_mask_apply: bad arguments");
+  dim3 grid((unsigned)((L + 255) / 256), (unsigned)N, (unsigned)Bt);
+  hipLaunchKernelGGL(srf_mask_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, m, enc, v, SA, N, L);
+  SRF_CHECK_LAUNCH("mask_apply", stream);
+  return SRF_OK;
+}
+
+// gv, m, gm: [Bt, SA*N, L]; enc, genc: [Bt, N, L]; gm may alias gv; accumulate_genc != 0: genc += ...
+extern "C" int srf_mask_bwd(const float* gv, const float* m, const float* enc, float* gm, float* genc, int accumulate_genc,
+                            int Bt, int SA, int N, int L, void* stream) {
+  SRF_CHECK_ARG(gv && m && enc && gm && genc && Bt > 0 && SA > 0 && N > 0 && L > 0 && Bt <= 65535 && N <= 65535,
+                "srf_mask_bwd: bad arguments");
+  dim3 grid((unsigned)((L + 255) / 256), (unsigned)N, (unsigned)Bt);
+  hipLaunchKernelGGL(srf_mask_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gv, m, enc, gm, genc, SA, N, L,
+                     accumulate_genc);
+  SRF_CHECK_LAUNCH("mask_bwd", stream);
+  return SRF_OK;
+}
+
+// =============================================================================================
+// PReLU backward for a stand-alone PReLU (mask_net.0, improved_sudormrf.py:268): gx = gout * (x >= 0 ? 1 : a),
+// d a += sum gout * x [x < 0].  gx may alias gout.
+// =============================================================================================
+__global__ __launch_bounds__(256) void srf_prelu_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+                                                            const float* __restrict__ slope, float* __restrict__ gx,
+                                                            float* dslope, long n) {
+  __shared__ double red[4];
+  const float a = slope[0];
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < min(n, ((long)blockIdx.x + 1) * 1024); i += 256) {
+    const float g = gout[i], xv = x[i];
+    if (xv < 0.f) {
+      acc += (double)g * (double)xv;
+      gx[i] = g * a;
+    } else {
+      gx[i] = g;
+    }
+  }
+  acc = srf_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && dslope) {
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t != 0.0) atomicAdd(dslope, (float)t);
+  }
+}
+
+extern "C" int srf_prelu_bwd(const float* gout, const float* x, const float* slope, float* gx, float* dslope, long n,
+                             void* stream) {
+  SRF_CHECK_ARG(gout && x && slope && gx && n > 0, "srf_prelu_bwd: bad arguments");
+  const long blocks = (n + 1023) / 1024;
+  SRF_CHECK_ARG(blocks < (1L << 31), "srf_prelu_bwd: tensor too large");
+  hipLaunchKernelGGL(srf_prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gout, x, slope, gx,
+                     dslope, n);
+  SRF_CHECK_LAUNCH("prelu_bwd", stream);
+  return SRF_OK;
+}
+
+// =============================================================================================
+// Frame gather: out[b, r*K + k, l] = src[b, r, hop*l + k - pad]  (0 outside [0,T); rows >= R*K up to rows_out are 0).
+// Turns the encoder's weight gradient (improved_sudormrf.py:247-251: dW[n,k] = sum_{b,l} g_s[b,n,l] x[b, hop l + k - pad])
+// and the decoder's backward (:272-279: g_v = W_d g_frames, dW_d = v g_frames^T with g_frames[(o,k), l] =
+// g_out[o, hop l + k - pad]) into the pointwise GEMM / weight-gradient GEMM.
+// =============================================================================================
+__global__ __launch_bounds__(256) void srf_frames_gather_kernel(const float* __restrict__ src, float* __restrict__ out,
+                                                                int R, int T, int K, int hop, int pad, int L,
+                                                                int rows_out) {
+  const long b = blockIdx.z;
+  const int row = blockIdx.y;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  float v = 0.f;
+  if (row < R * K) {
+    const int r = row / K, k = row - r * K;
+    const int t = hop * l + k - pad;
+    if (t >= 0 && t < T) v = src[(b * R + r) * (long)T + t];
+  }
+  out[(b * rows_out + row) * (long)L + l] = v;
+}
+
+extern "C" int srf_frames_gather(const float* src, float* out, int Bt, int R, int T, int K, int hop, int pad, int L,
+                                 int rows_out, void* stream) {
+  SRF_CHECK_ARG(src && out && Bt > 0 && R > 0 && T > 0 && K > 0 && hop > 0 && L > 0 && rows_out >= R * K &&
+                    Bt <= 65535 && rows_out <= 65535,
+                "srf_frames_gather: bad arguments");
+  dim3 grid((unsigned)((L + 255) / 256), (unsigned)rows_out, (unsigned)Bt);
+  hipLaunchKernelGGL(srf_frames_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, out, R, T, K, hop, pad, L,
+                     rows_out);
+  SRF_CHECK_LAUNCH("frames_gather", stream);
+  return SRF_OK;
+}

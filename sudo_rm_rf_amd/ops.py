@@ -270,6 +270,47 @@ def dwconv5_bwd(gd, xin, weight, stride, in_sums=None, in_gamma=None, in_beta=No
     return gin, dw, dbias
 
 
+def mask_apply(m, enc):
+    dev = _chk(m, enc)
+    Bt, SN, L = m.shape
+    N = enc.shape[1]
+    v = torch.empty_like(m)
+    _lib.check(_lib.load().srf_mask_apply(_lib.ptr(m), _lib.ptr(enc), _lib.ptr(v), Bt, SN // N, N, L,
+                                          _lib.current_stream(dev)), "srf_mask_apply")
+    return v
+
+
+def mask_bwd(gv, m, enc, genc=None):
+    dev = _chk(gv, m, enc, genc)
+    Bt, SN, L = m.shape
+    N = enc.shape[1]
+    acc = genc is not None
+    genc = torch.empty_like(enc) if genc is None else genc
+    gm = torch.empty_like(gv)
+    _lib.check(_lib.load().srf_mask_bwd(_lib.ptr(gv), _lib.ptr(m), _lib.ptr(enc), _lib.ptr(gm), _lib.ptr(genc),
+                                        1 if acc else 0, Bt, SN // N, N, L, _lib.current_stream(dev)), "srf_mask_bwd")
+    return gm, genc
+
+
+def prelu_bwd(gout, x, slope, dslope=None):
+    dev = _chk(gout, x, slope, dslope)
+    gx = torch.empty_like(gout)
+    dslope = torch.zeros(1, dtype=torch.float32, device=dev) if dslope is None else dslope
+    _lib.check(_lib.load().srf_prelu_bwd(_lib.ptr(gout), _lib.ptr(x), _lib.ptr(slope), _lib.ptr(gx), _lib.ptr(dslope),
+                                         gout.numel(), _lib.current_stream(dev)), "srf_prelu_bwd")
+    return gx, dslope
+
+
+def frames_gather(src, K, hop, pad, L, rows_out=None):
+    dev = _chk(src)
+    Bt, R, T = src.shape
+    rows_out = R * K if rows_out is None else rows_out
+    out = torch.empty((Bt, rows_out, L), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().srf_frames_gather(_lib.ptr(src), _lib.ptr(out), Bt, R, T, K, hop, pad, L, rows_out,
+                                             _lib.current_stream(dev)), "srf_frames_gather")
+    return out
+
+
 def wav_normalize(wav):
     """Per-row (x - mean) / (std + 1e-9), std unbiased (README.md:100-103).  wav [rows,T] or [Bt,1,T] ->
     (normalised wav of the same shape, stats [rows,2] = {mean, std})."""

@@ -130,3 +130,68 @@ def test_dwconv5_bwd(Bt, C, Lin, stride, pro):
     _, dw2, db2 = ops.dwconv5_bwd(dev32(gd), dev32(x), dev32(w.detach()), stride, dw=dw.clone(), dbias=db.clone(),
                                   want_gin=False, **kw)
     assert rel_err(dw2, 2 * w.grad) <= 2e-5 and rel_err(db2, 2 * b.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("Bt,S,N,L", [(2, 2, 24, 300), (1, 3, 5, 17), (3, 2, 512, 256)])
+def test_mask_apply_and_bwd(Bt, S, N, L):
+    from sudo_rm_rf_amd import ops
+    m = rnd(Bt, S * N, L, seed=50).requires_grad_(True)
+    e = rnd(Bt, N, L, seed=51).requires_grad_(True)
+    v = (torch.relu(m).view(Bt, S, N, L) * e.unsqueeze(1)).reshape(Bt, S * N, L)   # improved_sudormrf.py:296-298
+    gv = rnd(Bt, S * N, L, seed=52)
+    v.backward(gv)
+    assert rel_err(ops.mask_apply(dev32(m.detach()), dev32(e.detach())), v.detach()) <= 1e-6
+    gm, ge = ops.mask_bwd(dev32(gv), dev32(m.detach()), dev32(e.detach()))
+    assert rel_err(gm, m.grad) <= 1e-6 and rel_err(ge, e.grad) <= 2e-6
+    _, ge2 = ops.mask_bwd(dev32(gv), dev32(m.detach()), dev32(e.detach()), genc=ge.clone())
+    assert rel_err(ge2, 2 * e.grad) <= 2e-6
+
+
+def test_prelu_bwd():
+    from sudo_rm_rf_amd import ops
+    x = rnd(3, 40, 1001, seed=60).requires_grad_(True)
+    a = torch.tensor([0.31], dtype=torch.float64, requires_grad=True)
+    g = rnd(3, 40, 1001, seed=61)
+    F.prelu(x, a).backward(g)
+    gx, da = ops.prelu_bwd(dev32(g), dev32(x.detach()), dev32(a.detach()))
+    assert rel_err(gx, x.grad) <= 1e-6 and rel_err(da, a.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("Bt,A,T,K,N", [(2, 1, 3200, 21, 48), (1, 2, 330, 11, 16), (3, 1, 50, 21, 8)])
+def test_encoder_weight_grad_via_frames(Bt, A, T, K, N):
+    """dW_enc = wgrad GEMM over gathered input frames == autograd of conv1d(stride K//2, padding K//2)."""
+    from sudo_rm_rf_amd import ops
+    h = K // 2
+    Tp = ((T + h * 4 - 1) // (h * 4)) * (h * 4)
+    x = torch.zeros(Bt, A, Tp, dtype=torch.float64)
+    x[..., :T] = rnd(Bt, A, T, seed=70)
+    w = rnd(N, A, K, seed=71, scale=0.3).requires_grad_(True)
+    s = F.conv1d(x, w, None, stride=h, padding=h)
+    L = Tp // h
+    s = s[..., :L]
+    gs = rnd(Bt, N, L, seed=72)
+    s.backward(gs)
+    frames = ops.frames_gather(dev32(x[..., :T]), K, h, h, L)
+    dw, _ = ops.pw_wgrad(dev32(gs), frames, want_bias=False)
+    assert rel_err(dw.view(N, A, K), w.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("Bt,Ci,Co,K,L", [(2, 64, 2, 21, 100), (1, 96, 2, 21, 64), (2, 32, 4, 11, 40)])
+def test_decoder_backward_via_frames(Bt, Ci, Co, K, L):
+    """g_v = W_d (padded to 64 columns) x gathered output-gradient frames, dW_d = wgrad(v, frames)."""
+    from sudo_rm_rf_amd import ops
+    h = K // 2
+    T = h * L
+    v = rnd(Bt, Ci, L, seed=80).requires_grad_(True)
+    w = rnd(Ci, Co, K, seed=81, scale=Ci ** -0.5).requires_grad_(True)
+    out = F.conv_transpose1d(v, w, None, stride=h, padding=h, output_padding=h - 1)[..., :T]
+    go = rnd(Bt, Co, T, seed=82)
+    out.backward(go)
+    rows = ((Co * K + 63) // 64) * 64
+    frames = ops.frames_gather(dev32(go), K, h, h, L, rows_out=rows)
+    wp = torch.zeros(Ci, rows, dtype=torch.float32, device=DEV)
+    wp[:, :Co * K] = dev32(w.detach()).view(Ci, Co * K)
+    gv = ops.pw_conv(frames, wp, torch.zeros(Ci, dtype=torch.float32, device=DEV))
+    assert rel_err(gv, v.grad) <= 2e-5
+    dw, _ = ops.pw_wgrad(dev32(v.detach()), frames, want_bias=False)
+    assert rel_err(dw[:, :Co * K].reshape(Ci, Co, K), w.grad) <= 2e-5
