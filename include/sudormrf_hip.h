@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 5
+#define SRF_ABI_VERSION 6
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -174,7 +174,8 @@ int srf_merge(const float* const* levels, const srf_norm* norms, int D, float* y
  * applied on load) -> merged [groups,C,L] (+ out_sums for final_norm).  w/bias/gamma/beta: D pointers
  * each (spp_dw[k].conv.weight/.bias, spp_dw[k].norm.gamma/.beta).  Equivalent to D x srf_dwconv5 +
  * srf_merge but moves 3 C*L instead of 7.75 C*L through HBM.  srf_pyramid_supported() tells whether
- * the shape qualifies (L % (4*2^(D-1)) == 0, L >> (D-1) >= 8, row fits LDS).  merged may alias y1. */
+ * the shape qualifies (L % (4*2^(D-1)) == 0, L >> (D-1) >= 8, row fits LDS).  merged must NOT alias y1
+ * (pass 2 re-reads y1 with halos while other wavefronts write merged). */
 int srf_pyramid_supported(int C, int L, int D);
 size_t srf_pyramid_scratch_bytes(int groups, int C, int L, int D);
 int srf_pyramid(const float* y1, float* merged, const srf_norm* in_norm, const float* const* w,
@@ -232,10 +233,14 @@ int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt, int S, in
  *   dw[m,n] = sum_{b,l} g[b,m,l] * f(x[b,n,l]),  dbias[m] = sum_{b,l} g[b,m,l]
  * f = the forward's operand prologue (in_norm: GlobLN statistics of x + gamma/beta and/or PReLU slope; NULL = none).
  * g: [Bt,Cout,L], x: [Bt,Cin,L], dw: [Cout,Cin], dbias: [Cout] or NULL; accumulate != 0 adds to dw / dbias.
- * scratch: srf_pw_wgrad_scratch_bytes(...) bytes.  L % 4 == 0. */
+ * scratch: srf_pw_wgrad_scratch_bytes(...) bytes.  L % 4 == 0.
+ * srf_pw_wgrad_cols: dw is [Cout, dw_cols] and only the first dw_cols <= Cin columns are produced (x rows beyond
+ * them are padding, e.g. the decoder's 42 frame rows padded to 64 for the GEMM). */
 size_t srf_pw_wgrad_scratch_bytes(int Bt, int Cout, int Cin, int L);
 int srf_pw_wgrad(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout, int L, float* dw,
                  float* dbias, int accumulate, void* scratch, void* stream);
+int srf_pw_wgrad_cols(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout, int L,
+                      float* dw, int dw_cols, float* dbias, int accumulate, void* scratch, void* stream);
 
 /* GlobLN (+PReLU when norm->prelu) backward (improved_sudormrf.py:30-47, PReLU of ConvNormAct :73 / NormAct :113).
  * gout (+ optional gout2, added on load): gradient w.r.t. the normalised (activated) tensor; x: the GlobLN input;
@@ -271,6 +276,23 @@ int srf_prelu_bwd(const float* gout, const float* x, const float* slope, float* 
  * out: [Bt,rows_out,L].  Feeds the encoder's weight gradient and the decoder's backward (:247-251, :272-279). */
 int srf_frames_gather(const float* src, float* out, int Bt, int R, int T, int K, int hop, int pad, int L, int rows_out,
                       void* stream);
+
+/* ---- training step (Improved SuDoRM-RF only; SURVEY.md §8b proposal: srf_forward_train / srf_backward) ----
+ * srf_forward_train: the forward of srf_forward, un-fused where the backward needs an intermediate, keeping what
+ *   the backward needs in `saved` (srf_train_saved_bytes: GlobLN statistics, encoder output, residual stream,
+ *   per block y1 / D levels / merged, mask pre-activation, masked encoding).
+ * srf_backward: grad_out [Bt, S, T] -> parameter gradients ACCUMULATED into grads[i] (same order and shapes as
+ *   params; the caller zeroes them like optimizer.zero_grad()).  Reference: torch autograd over
+ *   SuDORMRF.forward (improved_sudormrf.py:283-301), run_improved_sudormrf.py:167-172.
+ * saved / scratch: 256-byte aligned device buffers of srf_train_saved_bytes / srf_train_scratch_bytes; `saved`
+ *   must stay untouched between the two calls, `scratch` may be reused by anything in between. */
+size_t srf_train_saved_bytes(const srf_plan* plan);
+size_t srf_train_scratch_bytes(const srf_plan* plan);
+int srf_forward_train(const srf_plan* plan, const float* const* params, int num_params, const float* wav, float* out,
+                      void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+int srf_backward(const srf_plan* plan, const float* const* params, float* const* grads, int num_params,
+                 const float* wav, const float* grad_out, const void* saved, size_t saved_bytes, void* scratch,
+                 size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

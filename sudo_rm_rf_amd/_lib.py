@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 STAT_BUCKETS = 64
 
 SRF_OK = 0
@@ -64,6 +64,7 @@ _PROTOS = {
     "srf_pit_sisdr_match": (_i, [_vp, _i, _i, _vp, _vp]),
     "srf_pit_sisdr_backward": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "srf_pw_wgrad_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "srf_pw_wgrad_cols": (_i, [_vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "srf_pw_wgrad": (_i, [_vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "srf_gln_bwd_scratch_bytes": (_sz, [_i, _i]),
     "srf_gln_bwd": (_i, [_vp, _vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -74,6 +75,10 @@ _PROTOS = {
     "srf_mask_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srf_prelu_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_long, _vp]),
     "srf_frames_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "srf_train_saved_bytes": (_sz, [_vp]),
+    "srf_train_scratch_bytes": (_sz, [_vp]),
+    "srf_forward_train": (_i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "srf_backward": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "srf_wav_normalize": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "srf_wav_denormalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srf_dwconv5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp]),

@@ -123,23 +123,7 @@ extern "C" int srf_decoder(const float* v, const float* w, float* out, int Bt, i
 // ---------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------
-struct srf_plan {
-  srf_config cfg;
-  int Bt, T, Tp, L, A, SA;
-  int Bg, nB, nC;  // folded batch (Bt*G), channels outside / inside the U-block per group
-  int n_params, n_launches;
-  // parameter indices
-  int p_block0, p_block_stride, p_ublock_off, p_tail;
-  // workspace offsets (bytes)
-  size_t off_stats, stats_bytes, off_enc, off_xa, off_xb, off_xq, off_xu, off_y1, off_lv[SRF_MAX_DEPTH],
-      off_masked, off_dec, off_pyr, total_bytes;
-  int fused_pyramid;
-  int slots_per_block, n_slots;
-  // pre-packed (split-bf16) weights of the 1x1 convolutions: param index -> workspace offset (0 = none)
-  std::vector<int> pk_param, pk_cout, pk_cin;
-  std::vector<size_t> pk_off;
-  std::vector<size_t> pk_of_param;  // [n_params] offset or 0
-};
+#include "srf_plan.h"
 
 static int plan_fail(srf_plan* p, int rc) {
   delete p;

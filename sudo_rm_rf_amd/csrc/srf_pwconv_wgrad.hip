@@ -182,12 +182,15 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_kernel(WgArgs a) {
   }
 }
 
+// out[m][n] (n < cols_out) = sum_p part[p][m][n]   (part rows have `cols` entries)
 __global__ __launch_bounds__(256) void srf_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                               long n, int P, float beta) {
+                                                               int rows, int cols, int cols_out, int P, float beta) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= (long)rows * cols_out) return;
+  const int m = (int)(i / cols_out), n = (int)(i - (long)m * cols_out);
+  const size_t src = (size_t)m * cols + n, stride = (size_t)rows * cols;
   float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(size_t)p * n + i];
+  for (int p = 0; p < P; ++p) s += part[(size_t)p * stride + src];
   out[i] = beta != 0.f ? fmaf(beta, out[i], s) : s;
 }
 
@@ -216,11 +219,14 @@ extern "C" size_t srf_pw_wgrad_scratch_bytes(int Bt, int Cout, int Cin, int L) {
 }
 
 // g: [Bt,Cout,L] gradient w.r.t. the conv output; x: [Bt,Cin,L] the conv's (pre-prologue) input;
-// dw: [Cout,Cin]; dbias: [Cout] or NULL.  accumulate != 0: dw += ..., dbias += ... (else overwrite).
-extern "C" int srf_pw_wgrad(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout, int L,
-                            float* dw, float* dbias, int accumulate, void* scratch, void* stream) {
+// dw: [Cout,dw_cols] (first dw_cols columns of the Cout x Cin product); dbias: [Cout] or NULL.
+// accumulate != 0: dw += ..., dbias += ... (else overwrite).
+extern "C" int srf_pw_wgrad_cols(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout,
+                                 int L, float* dw, int dw_cols, float* dbias, int accumulate, void* scratch,
+                                 void* stream) {
   SRF_CHECK_ARG(g && x && dw && scratch, "srf_pw_wgrad: null pointer");
   SRF_CHECK_ARG(Bt > 0 && Cin > 0 && Cout > 0 && L > 0 && (L % 4) == 0, "srf_pw_wgrad: bad sizes (L %% 4 == 0 required)");
+  SRF_CHECK_ARG(dw_cols > 0 && dw_cols <= Cin, "srf_pw_wgrad: dw_cols out of range");
   SRF_CHECK_ARG(srf_aligned16(g) && srf_aligned16(x), "srf_pw_wgrad: operands must be 16-byte aligned");
   WgArgs a;
   a.g = g;
@@ -245,12 +251,17 @@ extern "C" int srf_pw_wgrad(const float* g, const float* x, const srf_norm* in_n
     default: hipLaunchKernelGGL(srf_pw_wgrad_kernel<3>, grid, block, 0, st, a); break;
   }
   SRF_CHECK_LAUNCH("pw_wgrad", st);
-  const long nw = (long)Cout * Cin;
-  hipLaunchKernelGGL(srf_wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a.part, dw, nw,
-                     a.P, accumulate ? 1.f : 0.f);
+  const long nw = (long)Cout * dw_cols;
+  hipLaunchKernelGGL(srf_wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout,
+                     Cin, dw_cols, a.P, accumulate ? 1.f : 0.f);
   if (dbias)
     hipLaunchKernelGGL(srf_wgrad_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, st, a.bias_part,
-                       dbias, (long)Cout, a.P, accumulate ? 1.f : 0.f);
+                       dbias, Cout, 1, 1, a.P, accumulate ? 1.f : 0.f);
   SRF_CHECK_LAUNCH("pw_wgrad_reduce", st);
   return SRF_OK;
+}
+
+extern "C" int srf_pw_wgrad(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout, int L,
+                            float* dw, float* dbias, int accumulate, void* scratch, void* stream) {
+  return srf_pw_wgrad_cols(g, x, in_norm, Bt, Cin, Cout, L, dw, Cin, dbias, accumulate, scratch, stream);
 }

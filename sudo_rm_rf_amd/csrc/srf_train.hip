@@ -1,0 +1,364 @@
+// Training step, device side: forward that keeps what the backward needs, and the backward
+// of the whole Improved SuDoRM-RF graph (improved_sudormrf.py:283-301 under autograd), as sequences of the
+// per-kernel entry points of this library.  The reference gets the same result from torch autograd over ~1.8 k
+// ATen nodes (run_improved_sudormrf.py:167-172: rec = model(x); l = clamp(loss(rec, clean)); l.backward()).
+//
+//   srf_forward_train : encoder -> bottleneck -> U x [proj, D depthwise levels, merge, res_conv] -> mask GEMM ->
+//                       mask -> decoder, every GlobLN still folded into its neighbours, but un-fused where the
+//                       backward needs an intermediate (pyramid levels, mask pre-activation).  `saved` holds:
+//                       GlobLN statistics, encoder output, the residual stream x_0..x_U, and per block the
+//                       projection output y1, the D pre-norm levels and the merged tensor; the mask
+//                       pre-activation m and the masked encoding v.
+//   srf_backward      : walks the graph in reverse; parameter gradients are ACCUMULATED into `grads` (same
+//                       order / shapes as the parameters; the caller zeroes them, like optimizer.zero_grad()).
+// GroupComm (TAC) has no backward yet: both entry points refuse that variant.
+#include "srf_plan.h"
+
+int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
+
+static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct TrainLayout {
+  size_t stats, enc, x0, x_stride, blk0, blk_stride, y1, lv[SRF_MAX_DEPTH], merged, m, v, total;
+};
+
+static TrainLayout train_layout(const srf_plan* p) {
+  TrainLayout t;
+  const srf_config& c = p->cfg;
+  const size_t F = sizeof(float), L = p->L, Bt = p->Bt;
+  const int D = c.upsampling_depth, U = c.num_blocks;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = al256(off + bytes);
+    return o;
+  };
+  t.stats = take(p->stats_bytes);
+  t.enc = take(F * Bt * c.enc_num_basis * L);
+  t.x_stride = al256(F * Bt * c.out_channels * L);
+  t.x0 = take(t.x_stride * (U + 1));
+  // per block (relative offsets)
+  size_t rel = 0;
+  auto rtake = [&](size_t bytes) {
+    const size_t o = rel;
+    rel = al256(rel + bytes);
+    return o;
+  };
+  t.y1 = rtake(F * Bt * c.in_channels * L);
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) t.lv[k] = k < D ? rtake(F * Bt * c.in_channels * (L >> k)) : 0;
+  t.merged = rtake(F * Bt * c.in_channels * L);
+  t.blk_stride = rel;
+  t.blk0 = take(rel * U);
+  t.m = take(F * Bt * p->SA * c.enc_num_basis * L);
+  t.v = take(F * Bt * p->SA * c.enc_num_basis * L);
+  t.total = off;
+  return t;
+}
+
+struct ScratchLayout {
+  size_t dec, gv, genc, gxa, gxb, gf, go, gd, gn[SRF_MAX_DEPTH], gu[SRF_MAX_DEPTH], frames, wt, zeros, wdpad, wg,
+      gln, dw, total;
+  int dec_rows;
+};
+
+static size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+static ScratchLayout scratch_layout(const srf_plan* p) {
+  ScratchLayout s;
+  const srf_config& c = p->cfg;
+  const size_t F = sizeof(float), L = p->L, Bt = p->Bt;
+  const int D = c.upsampling_depth, K = c.enc_kernel_size, N = c.enc_num_basis, B = c.out_channels, C = c.in_channels;
+  const int SAN = p->SA * N;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = al256(off + bytes);
+    return o;
+  };
+  s.dec = take(F * srf_decoder_scratch_floats(p->Bt, SAN, p->SA, K, p->L));
+  s.gv = take(F * Bt * SAN * L);
+  s.genc = take(F * Bt * N * L);
+  s.gxa = take(F * Bt * B * L);
+  s.gxb = take(F * Bt * B * L);
+  s.gf = take(F * Bt * C * L);
+  s.go = take(F * Bt * C * L);
+  s.gd = take(F * Bt * C * L);
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+    s.gn[k] = (k >= 1 && k < D) ? take(F * Bt * C * (L >> k)) : 0;
+    s.gu[k] = (k >= 1 && k < D) ? take(F * Bt * C * (L >> k)) : 0;   // gradient w.r.t. normalised level k from level k+1
+  }
+  s.dec_rows = (p->SA * K + 63) / 64 * 64;
+  const size_t enc_rows = (size_t)p->A * K;
+  s.frames = take(F * Bt * L * (s.dec_rows > (int)enc_rows ? s.dec_rows : enc_rows));
+  s.wt = take(F * max3((size_t)B * N, (size_t)B * C, (size_t)B * SAN));
+  s.zeros = take(F * max3(C, SAN, N));
+  s.wdpad = take(F * (size_t)SAN * s.dec_rows);
+  size_t wg = 0;
+  auto wgmax = [&](int cout, int cin) {
+    const size_t b = srf_pw_wgrad_scratch_bytes(p->Bt, cout, cin, p->L);
+    if (b > wg) wg = b;
+  };
+  wgmax(B, N);
+  wgmax(C, B);
+  wgmax(B, C);
+  wgmax(SAN, B);
+  wgmax(SAN, s.dec_rows);
+  wgmax(N, (int)enc_rows);
+  s.wg = take(wg);
+  s.gln = take(srf_gln_bwd_scratch_bytes(p->Bt, C > N ? C : N));
+  s.dw = take(srf_dwconv5_bwd_scratch_bytes(p->Bt, C));
+  s.total = off;
+  return s;
+}
+
+static int train_check(const srf_plan* p, const char* who) {
+  if (p->cfg.variant != SRF_VARIANT_IMPROVED) {
+    srf_set_error("%s: the training step implements the Improved SuDoRM-RF (the GroupComm TAC has no backward yet)", who);
+    return SRF_EINVAL;
+  }
+  if (p->L % 4 != 0) {
+    srf_set_error("%s: L=%d must be a multiple of 4", who, p->L);
+    return SRF_EINVAL;
+  }
+  return SRF_OK;
+}
+
+extern "C" size_t srf_train_saved_bytes(const srf_plan* p) { return p ? train_layout(p).total : 0; }
+extern "C" size_t srf_train_scratch_bytes(const srf_plan* p) { return p ? scratch_layout(p).total : 0; }
+
+extern "C" int srf_forward_train(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
+                                 void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  SRF_CHECK_ARG(p && P && wav && out && saved && scratch, "srf_forward_train: null pointer");
+  SRF_CHECK_ARG(num_params == p->n_params, "srf_forward_train: expected %d parameter tensors, got %d", p->n_params,
+                num_params);
+  int rc = train_check(p, "srf_forward_train");
+  if (rc) return rc;
+  const TrainLayout t = train_layout(p);
+  const ScratchLayout s = scratch_layout(p);
+  SRF_CHECK_ARG(saved_bytes >= t.total && scratch_bytes >= s.total, "srf_forward_train: saved / scratch buffer too small");
+  SRF_CHECK_ARG(((((size_t)saved) | ((size_t)scratch)) & 255) == 0, "srf_forward_train: buffers must be 256-byte aligned");
+  const srf_config& c = p->cfg;
+  const int D = c.upsampling_depth, U = c.num_blocks, N = c.enc_num_basis, K = c.enc_kernel_size;
+  const int Bt = p->Bt, L = p->L, B = c.out_channels, C = c.in_channels;
+  char* sv = (char*)saved;
+  char* sc = (char*)scratch;
+  hipStream_t st = (hipStream_t)stream;
+  double* stats = (double*)(sv + t.stats);
+  auto slot = [&](int i) { return stats + (size_t)i * Bt * SRF_STAT_BUCKETS * 2; };
+  auto xbuf = [&](int i) { return (float*)(sv + t.x0 + t.x_stride * i); };
+  SRF_CHECK_HIP(hipMemsetAsync(stats, 0, p->stats_bytes, st));
+
+  float* enc = (float*)(sv + t.enc);
+  rc = srf_encoder(wav, P[0], enc, slot(0), Bt, p->A, p->T, N, K, L, stream);
+  if (rc) return rc;
+  {
+    srf_norm ln{slot(0), P[1], P[2], nullptr};
+    rc = srf_pw_conv(enc, P[3], P[4], xbuf(0), Bt, N, B, L, &ln, nullptr, nullptr, 0, nullptr, 0, stream);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < U; ++i) {
+    const float* const* Pu = P + p->p_block0 + (size_t)i * p->p_block_stride;
+    const int s0 = 1 + i * p->slots_per_block;
+    char* blk = sv + t.blk0 + t.blk_stride * i;
+    float* y1 = (float*)(blk + t.y1);
+    float* merged = (float*)(blk + t.merged);
+    rc = srf_pw_conv(xbuf(i), Pu[0], Pu[1], y1, Bt, B, C, L, nullptr, nullptr, slot(s0), 0, nullptr, 0, stream);
+    if (rc) return rc;
+    const float* levels[SRF_MAX_DEPTH];
+    srf_norm norms[SRF_MAX_DEPTH];
+    for (int k = 0; k < D; ++k) {
+      const float* const* Pk = Pu + 5 + 4 * k;
+      float* dk = (float*)(blk + t.lv[k]);
+      srf_norm in;
+      const float* src;
+      int Lin, stride;
+      if (k == 0) {
+        in = srf_norm{slot(s0), Pu[2], Pu[3], Pu[4]};
+        src = y1;
+        Lin = L;
+        stride = 1;
+      } else {
+        const float* const* Pprev = Pu + 5 + 4 * (k - 1);
+        in = srf_norm{slot(s0 + k), Pprev[2], Pprev[3], nullptr};
+        src = (const float*)(blk + t.lv[k - 1]);
+        Lin = L >> (k - 1);
+        stride = 2;
+      }
+      rc = srf_dwconv5(src, Pk[0], Pk[1], dk, Bt, C, Lin, stride, &in, slot(s0 + 1 + k), stream);
+      if (rc) return rc;
+      levels[k] = dk;
+      norms[k] = srf_norm{slot(s0 + 1 + k), Pk[2], Pk[3], nullptr};
+    }
+    rc = srf_merge(levels, norms, D, merged, Bt, C, L, slot(s0 + 1 + D), stream);
+    if (rc) return rc;
+    const float* const* Pf = Pu + 5 + 4 * D;
+    srf_norm fn{slot(s0 + 1 + D), Pf[0], Pf[1], Pf[2]};
+    rc = srf_pw_conv(merged, Pf[3], Pf[4], xbuf(i + 1), Bt, C, B, L, &fn, xbuf(i), nullptr, 0, nullptr, 0, stream);
+    if (rc) return rc;
+  }
+  const float* const* Pt = P + p->p_tail;
+  float* m = (float*)(sv + t.m);
+  float* v = (float*)(sv + t.v);
+  {
+    srf_norm pre{nullptr, nullptr, nullptr, Pt[0]};
+    rc = srf_pw_conv(xbuf(U), Pt[1], Pt[2], m, Bt, B, p->SA * N, L, &pre, nullptr, nullptr, 0, nullptr, 0, stream);
+    if (rc) return rc;
+  }
+  rc = srf_mask_apply(m, enc, v, Bt, p->SA, N, L, stream);
+  if (rc) return rc;
+  return srf_decoder(v, Pt[3], out, Bt, p->SA * N, p->SA, K, L, p->T, (float*)(sc + s.dec), stream);
+}
+
+extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* const* G, int num_params, const float* wav,
+                            const float* grad_out, const void* saved, size_t saved_bytes, void* scratch,
+                            size_t scratch_bytes, void* stream) {
+  SRF_CHECK_ARG(p && P && G && wav && grad_out && saved && scratch, "srf_backward: null pointer");
+  SRF_CHECK_ARG(num_params == p->n_params, "srf_backward: expected %d parameter tensors, got %d", p->n_params, num_params);
+  int rc = train_check(p, "srf_backward");
+  if (rc) return rc;
+  for (int i = 0; i < num_params; ++i) SRF_CHECK_ARG(P[i] && G[i], "srf_backward: parameter / gradient %d is null", i);
+  const TrainLayout t = train_layout(p);
+  const ScratchLayout s = scratch_layout(p);
+  SRF_CHECK_ARG(saved_bytes >= t.total && scratch_bytes >= s.total, "srf_backward: saved / scratch buffer too small");
+  const srf_config& c = p->cfg;
+  const int D = c.upsampling_depth, U = c.num_blocks, N = c.enc_num_basis, K = c.enc_kernel_size, h = K / 2;
+  const int Bt = p->Bt, L = p->L, B = c.out_channels, C = c.in_channels, SA = p->SA, SAN = p->SA * N;
+  const char* sv = (const char*)saved;
+  char* sc = (char*)scratch;
+  hipStream_t st = (hipStream_t)stream;
+  double* stats = (double*)(sv + t.stats);
+  auto slot = [&](int i) { return stats + (size_t)i * Bt * SRF_STAT_BUCKETS * 2; };
+  auto xbuf = [&](int i) { return (const float*)(sv + t.x0 + t.x_stride * i); };
+  auto fp = [&](size_t o) { return (float*)(sc + o); };
+  const float* enc = (const float*)(sv + t.enc);
+  const float* m = (const float*)(sv + t.m);
+  const float* v = (const float*)(sv + t.v);
+  float* zeros = fp(s.zeros);
+  float* wt = fp(s.wt);
+  void* wg = sc + s.wg;
+  const size_t zmax = max3(C, SAN, N);
+  SRF_CHECK_HIP(hipMemsetAsync(zeros, 0, sizeof(float) * zmax, st));
+
+  const int pt = p->p_tail;
+  // ---- decoder: out = overlap_add(W_d^T v)                       improved_sudormrf.py:272-279,300
+  float* frames = fp(s.frames);
+  rc = srf_frames_gather(grad_out, frames, Bt, SA, p->T, K, h, h, L, s.dec_rows, stream);
+  if (rc) return rc;
+  rc = srf_pw_wgrad_cols(v, frames, nullptr, Bt, s.dec_rows, SAN, L, G[pt + 3], SA * K, nullptr, 1, wg, stream);
+  if (rc) return rc;
+  float* wdpad = fp(s.wdpad);
+  SRF_CHECK_HIP(hipMemsetAsync(wdpad, 0, sizeof(float) * (size_t)SAN * s.dec_rows, st));
+  SRF_CHECK_HIP(hipMemcpy2DAsync(wdpad, sizeof(float) * s.dec_rows, P[pt + 3], sizeof(float) * SA * K,
+                                 sizeof(float) * SA * K, SAN, hipMemcpyDeviceToDevice, st));
+  float* gv = fp(s.gv);
+  rc = srf_pw_conv(frames, wdpad, zeros, gv, Bt, s.dec_rows, SAN, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+  if (rc) return rc;
+  // ---- mask: v = relu(m) * enc                                  :296-298
+  float* genc = fp(s.genc);
+  rc = srf_mask_bwd(gv, m, enc, gv, genc, 0, Bt, SA, N, L, stream);   // gv now holds g_m
+  if (rc) return rc;
+  // ---- mask_net: m = W_m PReLU(x_U) + b_m                       :268-269,295
+  float* gx = fp(s.gxa);
+  float* gx_other = fp(s.gxb);
+  {
+    srf_norm pre{nullptr, nullptr, nullptr, P[pt]};
+    rc = srf_pw_wgrad(gv, xbuf(U), &pre, Bt, B, SAN, L, G[pt + 1], G[pt + 2], 1, wg, stream);
+    if (rc) return rc;
+    rc = srf_transpose_launch(P[pt + 1], wt, SAN, B, st);   // [SAN][B] -> [B][SAN]
+    if (rc) return rc;
+    rc = srf_pw_conv(gv, wt, zeros, gx, Bt, SAN, B, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+    if (rc) return rc;
+    rc = srf_prelu_bwd(gx, xbuf(U), P[pt], gx, G[pt], (long)Bt * B * L, stream);
+    if (rc) return rc;
+  }
+  // ---- U-ConvBlocks in reverse                                  :198-220
+  float* gf = fp(s.gf);
+  float* go = fp(s.go);
+  float* gd = fp(s.gd);
+  for (int i = U - 1; i >= 0; --i) {
+    const int pu = p->p_block0 + i * p->p_block_stride;
+    const float* const* Pu = P + pu;
+    float* const* Gu = G + pu;
+    const int s0 = 1 + i * p->slots_per_block;
+    const char* blk = sv + t.blk0 + t.blk_stride * i;
+    const float* y1 = (const float*)(blk + t.y1);
+    const float* merged = (const float*)(blk + t.merged);
+    const int pf = 5 + 4 * D;   // final_norm.gamma, .beta, act.weight, res_conv.weight, .bias
+    // res_conv: x_{i+1} = W_r PReLU(GlobLN(merged)) + b_r + x_i
+    srf_norm fn{slot(s0 + 1 + D), Pu[pf], Pu[pf + 1], Pu[pf + 2]};
+    rc = srf_pw_wgrad(gx, merged, &fn, Bt, C, B, L, Gu[pf + 3], Gu[pf + 4], 1, wg, stream);
+    if (rc) return rc;
+    rc = srf_transpose_launch(Pu[pf + 3], wt, B, C, st);    // [B][C] -> [C][B]
+    if (rc) return rc;
+    rc = srf_pw_conv(gx, wt, zeros, gf, Bt, B, C, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+    if (rc) return rc;
+    rc = srf_gln_bwd(gf, nullptr, merged, &fn, Bt, C, L, gf, 0, Gu[pf], Gu[pf + 1], Gu[pf + 2], sc + s.gln, stream);
+    if (rc) return rc;                                       // gf now holds g_merged = g_n_0 (merge part)
+    float* gn[SRF_MAX_DEPTH];
+    gn[0] = gf;
+    for (int k = 1; k < D; ++k) gn[k] = fp(s.gn[k]);
+    rc = srf_merge_bwd(gf, gn, D, (long)Bt * C, L, stream);
+    if (rc) return rc;
+    for (int k = D - 1; k >= 0; --k) {
+      const float* const* Pk = Pu + 5 + 4 * k;   // conv.weight, conv.bias, norm.gamma, norm.beta
+      float* const* Gk = Gu + 5 + 4 * k;
+      const float* dk = (const float*)(blk + t.lv[k]);
+      const int Lk = L >> k;
+      srf_norm nk{slot(s0 + 1 + k), Pk[2], Pk[3], nullptr};
+      const float* gu_in = (k < D - 1) ? (k == 0 ? go : fp(s.gu[k])) : nullptr;   // from level k+1's conv
+      // careful: for k == 0 the contribution of level 1's conv lives in gu0 (see below)
+      rc = srf_gln_bwd(gn[k], gu_in, dk, &nk, Bt, C, Lk, gd, 0, Gk[2], Gk[3], nullptr, sc + s.gln, stream);
+      if (rc) return rc;
+      srf_norm in;
+      const float* src;
+      int Lin, stride;
+      float* gin;
+      if (k == 0) {
+        in = srf_norm{slot(s0), Pu[2], Pu[3], Pu[4]};
+        src = y1;
+        Lin = L;
+        stride = 1;
+        gin = go;       // gradient w.r.t. o = PReLU(GlobLN(y1)); (go was consumed as gu_in above)
+      } else {
+        const float* const* Pprev = Pu + 5 + 4 * (k - 1);
+        in = srf_norm{slot(s0 + k), Pprev[2], Pprev[3], nullptr};
+        src = (const float*)(blk + t.lv[k - 1]);
+        Lin = L >> (k - 1);
+        stride = 2;
+        gin = (k - 1 == 0) ? go : fp(s.gu[k - 1]);   // gradient w.r.t. normalised level k-1
+      }
+      rc = srf_dwconv5_bwd(gd, src, &in, Pk[0], Bt, C, Lin, stride, gin, Gk[0], Gk[1], sc + s.dw, stream);
+      if (rc) return rc;
+    }
+    // proj_1x1: y1 = W_p x_i + b_p, o = PReLU(GlobLN(y1))
+    srf_norm pn{slot(s0), Pu[2], Pu[3], Pu[4]};
+    rc = srf_gln_bwd(go, nullptr, y1, &pn, Bt, C, L, go, 0, Gu[2], Gu[3], Gu[4], sc + s.gln, stream);   // go = g_y1
+    if (rc) return rc;
+    rc = srf_pw_wgrad(go, xbuf(i), nullptr, Bt, B, C, L, Gu[0], Gu[1], 1, wg, stream);
+    if (rc) return rc;
+    rc = srf_transpose_launch(Pu[0], wt, C, B, st);          // [C][B] -> [B][C]
+    if (rc) return rc;
+    rc = srf_pw_conv(go, wt, zeros, gx_other, Bt, C, B, L, nullptr, gx, nullptr, 0, nullptr, 0, stream);   // + skip
+    if (rc) return rc;
+    float* tmp = gx;
+    gx = gx_other;
+    gx_other = tmp;
+  }
+  // ---- bottleneck: x_0 = W_b GlobLN(enc) + b_b                  :256-259,292
+  {
+    srf_norm ln{slot(0), P[1], P[2], nullptr};
+    rc = srf_pw_wgrad(gx, enc, &ln, Bt, N, B, L, G[3], G[4], 1, wg, stream);
+    if (rc) return rc;
+    rc = srf_transpose_launch(P[3], wt, B, N, st);           // [B][N] -> [N][B]
+    if (rc) return rc;
+    // g_ln into the (now free) gv buffer, then GlobLN backward accumulated onto the mask path's g_enc
+    rc = srf_pw_conv(gx, wt, zeros, gv, Bt, B, N, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+    if (rc) return rc;
+    rc = srf_gln_bwd(gv, nullptr, enc, &ln, Bt, N, L, genc, 1, G[1], G[2], nullptr, sc + s.gln, stream);
+    if (rc) return rc;
+  }
+  // ---- encoder weight                                           :247-251,286
+  rc = srf_frames_gather(wav, frames, Bt, p->A, p->T, K, h, h, L, p->A * K, stream);
+  if (rc) return rc;
+  return srf_pw_wgrad(genc, frames, nullptr, Bt, p->A * K, N, L, G[0], nullptr, 1, wg, stream);
+}

@@ -50,6 +50,17 @@ class Plan:
         except Exception:
             pass
 
+    def train_sizes(self):
+        """(saved bytes, scratch bytes) of the training step (srf_forward_train / srf_backward)."""
+        lib = _lib.load()
+        return lib.srf_train_saved_bytes(self.handle), lib.srf_train_scratch_bytes(self.handle)
+
+    def train_scratch(self):
+        """Backward scratch, shared by every training step of this plan (stream-ordered reuse)."""
+        if getattr(self, "_train_scratch", None) is None:
+            self._train_scratch = torch.empty(self.train_sizes()[1], dtype=torch.uint8, device=self.device)
+        return self._train_scratch
+
     def forward(self, param_ptrs, wav, out):
         lib = _lib.load()
         rc = lib.srf_forward(self.handle, param_ptrs, self.num_params, _lib.ptr(wav), _lib.ptr(out),
@@ -63,6 +74,57 @@ class Plan:
                                          dst.numel(), _lib.current_stream(self.device))
         _lib.check(rc, "srf_debug_fetch")
         return dst
+
+
+class _TrainStep(torch.autograd.Function):
+    """SuDORMRF.forward under autograd: srf_forward_train keeps the activations the backward needs in one
+    `saved` buffer, srf_backward turns d loss / d output into all parameter gradients (one flat buffer, returned
+    as per-parameter views).  Replaces torch autograd over the reference's ~1.8 k ATen nodes
+    (run_improved_sudormrf.py:167-172)."""
+
+    @staticmethod
+    def forward(ctx, engine, out_ch, wav, *params):
+        lib = _lib.load()
+        x = wav.detach().to(torch.float32).contiguous()
+        batch, _, T = x.shape
+        dev = x.device
+        with torch.cuda.device(dev):
+            plan = engine.plan_for(batch, T, dev)
+            saved_bytes, scratch_bytes = plan.train_sizes()
+            saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+            scratch = plan.train_scratch()
+            out = torch.empty((batch, out_ch, T), dtype=torch.float32, device=dev)
+            table = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+            rc = lib.srf_forward_train(plan.handle, table, len(params), _lib.ptr(x), _lib.ptr(out), _lib.ptr(saved),
+                                       saved_bytes, _lib.ptr(scratch), scratch_bytes, _lib.current_stream(dev))
+            _lib.check(rc, "srf_forward_train")
+        ctx.plan, ctx.saved_buf, ctx.x = plan, saved, x
+        ctx.save_for_backward(*params)
+        engine.last_plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        params = ctx.saved_tensors
+        plan, saved, x = ctx.plan, ctx.saved_buf, ctx.x
+        dev = x.device
+        g = grad_out.detach().to(torch.float32).contiguous()
+        sizes = [p.numel() for p in params]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for p, n in zip(params, sizes):
+            grads.append(flat[off:off + n].view_as(p))
+            off += n
+        with torch.cuda.device(dev):
+            scratch = plan.train_scratch()
+            ptab = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+            gtab = (C.c_void_p * len(params))(*[t.data_ptr() for t in grads])
+            rc = lib.srf_backward(plan.handle, ptab, gtab, len(params), _lib.ptr(x), _lib.ptr(g), _lib.ptr(saved),
+                                  saved.numel(), _lib.ptr(scratch), scratch.numel(), _lib.current_stream(dev))
+            _lib.check(rc, "srf_backward")
+        ctx.saved_buf = None
+        return (None, None, None) + tuple(grads)
 
 
 class ModelEngine:
@@ -99,6 +161,15 @@ class ModelEngine:
         self._ptr_cache[dkey] = (key, arr)
         return arr
 
+    def _run_train(self, module, wav, expected_channels):
+        params = list(module.state_dict(keep_vars=True).values())
+        for p in params:
+            if p.device != wav.device or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.SrfError("all parameters must be contiguous float32 on %s" % wav.device)
+        if wav.shape[0] == 0 or wav.shape[-1] == 0:
+            raise RuntimeError("empty input %s" % (tuple(wav.shape),))
+        return _TrainStep.apply(self, module.num_sources * expected_channels, wav, *params)
+
     def run(self, module, wav, expected_channels):
         if not isinstance(wav, torch.Tensor):
             raise TypeError("input must be a torch.Tensor")
@@ -112,11 +183,15 @@ class ModelEngine:
             raise _lib.SrfError(
                 "sudo_rm_rf_amd runs on an MI355X only: input is on %s.  There is deliberately no CPU "
                 "fallback (use the reference implementation for CPU inference)." % wav.device)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()) and \
-                not self._warned_grad:
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+        # model.train() + grad mode = the training step (what the reference's runner does before its loop,
+        # run_improved_sudormrf.py:144); model.eval() always takes the fused inference path
+        if wants_grad and module.training and type(module).__name__ == "SuDORMRF":
+            return self._run_train(module, wav, expected_channels)
+        if wants_grad and module.training and not self._warned_grad:
             self._warned_grad = True
-            warnings.warn("sudo_rm_rf_amd: forward is inference-only in this build; the output does "
-                          "not carry autograd history.", stacklevel=3)
+            warnings.warn("sudo_rm_rf_amd: the training step (autograd) is implemented for the Improved SuDoRM-RF; "
+                          "this model's output does not carry autograd history.", stacklevel=3)
         params = [p.detach() for p in module.state_dict(keep_vars=True).values()]
         for p in params:
             if p.device != wav.device or p.dtype != torch.float32 or not p.is_contiguous():
