@@ -225,11 +225,15 @@ struct DwBwdArgs {
   int C, Lin, Lout, stride;
 };
 
+// Block = (row, chunk of 2048 input positions); a thread owns 8 consecutive input positions i0..i0+7 and the
+// conv outputs j that start inside them (stride 1: j = i0..i0+7, stride 2: j = i0/2..i0/2+3), so the input
+// gradient and the parameter sums come from two 12-value register windows (u and g_d around the chunk).
+template <int S>
 __global__ __launch_bounds__(256) void srf_dwconv5_bwd_kernel(DwBwdArgs a) {
   __shared__ float red[4][6];
-  const long row = blockIdx.x;
-  const int c = (int)(row % a.C);
-  const long g = row / a.C;
+  const int c = blockIdx.y;
+  const long g = blockIdx.z;
+  const long row = g * a.C + c;
   float sc = 1.f, sh = 0.f;
   if (a.nrm.sums) {
     float mean, rstd;
@@ -244,19 +248,78 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_kernel(DwBwdArgs a) {
   for (int t = 0; t < 5; ++t) w[t] = a.w[c * 5 + t];
   const float* gd = a.gd + row * (long)a.Lout;
   const float* xr = a.xin + row * (long)a.Lin;
-  const int s = a.stride, Lin = a.Lin, Lout = a.Lout;
-  // ---- parameter sums
+  const int Lin = a.Lin, Lout = a.Lout;
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
   float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int j = threadIdx.x; j < Lout; j += 256) {
-    const float gv = gd[j];
-    p[5] += gv;
+  if (i0 < Lin) {
+    // u window: positions i0-2 .. i0+9 (zero outside the row: the conv pads the prologue's OUTPUT)
+    float u[12];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int i = s * j + t - 2;
+    for (int e = 0; e < 12; ++e) {
+      const int i = i0 - 2 + e;
+      float v = 0.f;
       if (i >= 0 && i < Lin) {
-        float u = fmaf(xr[i], sc, sh);
-        if (act) u = srf_prelu(u, slope);
-        p[t] = fmaf(gv, u, p[t]);
+        v = fmaf(xr[i], sc, sh);
+        if (act) v = srf_prelu(v, slope);
+      }
+      u[e] = v;
+    }
+    if (S == 1) {
+      // g_d window: j = i0-2 .. i0+9
+      float gw[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) {
+        const int j = i0 - 2 + e;
+        gw[e] = (j >= 0 && j < Lout) ? gd[j] : 0.f;
+      }
+      // parameters: j = i0 + e (e < 8): u index = j + t - 2 -> window slot e + t
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gv = gw[e + 2];
+        p[5] += gv;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) p[t] = fmaf(gv, u[e + t], p[t]);
+      }
+      // input gradient: g_u[i] = sum_t w[t] g_d[i + 2 - t] -> window slot (i - i0) + 4 - t
+      if (a.gin) {
+        float* gi = a.gin + row * (long)Lin;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < 5; ++t) acc = fmaf(w[t], gw[e + 4 - t], acc);
+          if (i0 + e < Lin) gi[i0 + e] = acc;
+        }
+      }
+    } else {
+      // stride 2: outputs j = j0-1 .. j0+4 with j0 = i0/2 (i0 is a multiple of 8)
+      const int j0 = i0 >> 1;
+      float gw[6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int j = j0 - 1 + e;
+        gw[e] = (j >= 0 && j < Lout) ? gd[j] : 0.f;
+      }
+      // parameters: j = j0 + q (q < 4): u index 2j + t - 2 = i0 + 2q + t - 2 -> window slot 2q + t
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float gv = gw[q + 1];
+        p[5] += gv;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) p[t] = fmaf(gv, u[2 * q + t], p[t]);
+      }
+      // input gradient: i = i0 + e; terms with (i + 2 - t) even: j = (i + 2 - t)/2 -> window slot j - j0 + 1
+      if (a.gin) {
+        float* gi = a.gin + row * (long)Lin;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < 5; ++t) {
+            if (((e + 2 - t) & 1) == 0) acc = fmaf(w[t], gw[(e + 2 - t) / 2 + 1], acc);   // (e+2-t) in [-2, 9]
+          }
+          if (i0 + e < Lin) gi[i0 + e] = acc;
+        }
       }
     }
   }
@@ -272,23 +335,146 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_kernel(DwBwdArgs a) {
   __syncthreads();
   if (threadIdx.x < 6) {
     const int k = threadIdx.x;
-    a.rowpart[row * 8 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    if (gridDim.x == 1)
+      a.rowpart[row * 8 + k] = v;
+    else
+      atomicAdd(&a.rowpart[row * 8 + k], v);
   }
-  // ---- input gradient
-  if (a.gin) {
-    float* gi = a.gin + row * (long)Lin;
-    for (int i = threadIdx.x; i < Lin; i += 256) {
+}
+
+// Fast variant (Lin % 4 == 0, 16-byte aligned rows): a thread owns 4 consecutive input positions (one float4 of
+// xin / of the input gradient, one float4 or float2 of g_d), neighbouring lanes are neighbouring positions, so
+// every global access is a fully coalesced 1 KB (512 B) per wavefront instruction; the 2-sample halos of both
+// windows come from the neighbouring lanes (wavefront shuffles), the wavefront's two edge lanes load theirs.
+template <int S>
+__global__ __launch_bounds__(256) void srf_dwconv5_bwd_fast_kernel(DwBwdArgs a) {
+  __shared__ float red[4][6];
+  const int c = blockIdx.y;
+  const long g = blockIdx.z;
+  const long row = g * a.C + c;
+  float sc = 1.f, sh = 0.f;
+  if (a.nrm.sums) {
+    float mean, rstd;
+    srf_finalize_stats(a.nrm.sums, g, a.inv_count, mean, rstd);
+    sc = a.nrm.gamma[c] * rstd;
+    sh = a.nrm.beta[c] - mean * sc;
+  }
+  const bool act = a.nrm.prelu != nullptr;
+  const float slope = act ? a.nrm.prelu[0] : 1.f;
+  float w[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) w[t] = a.w[c * 5 + t];
+  const float* gd = a.gd + row * (long)a.Lout;
+  const float* xr = a.xin + row * (long)a.Lin;
+  const int Lin = a.Lin, Lout = a.Lout;
+  const int lane = threadIdx.x & 63;
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool valid = i0 < Lin;
+  auto pro = [&](float v) {
+    v = fmaf(v, sc, sh);
+    return act ? srf_prelu(v, slope) : v;
+  };
+  float u[8];
+  {
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) xv = *reinterpret_cast<const float4*>(xr + i0);
+    u[2] = valid ? pro(xv.x) : 0.f;
+    u[3] = valid ? pro(xv.y) : 0.f;
+    u[4] = valid ? pro(xv.z) : 0.f;
+    u[5] = valid ? pro(xv.w) : 0.f;
+    u[0] = __shfl_up(u[4], 1, 64);
+    u[1] = __shfl_up(u[5], 1, 64);
+    u[6] = __shfl_down(u[2], 1, 64);
+    u[7] = __shfl_down(u[3], 1, 64);
+    if (lane == 0) {
+      u[0] = (i0 - 2 >= 0 && i0 - 2 < Lin) ? pro(xr[i0 - 2]) : 0.f;
+      u[1] = (i0 - 1 >= 0 && i0 - 1 < Lin) ? pro(xr[i0 - 1]) : 0.f;
+    }
+    if (lane == 63) {
+      u[6] = (i0 + 4 < Lin) ? pro(xr[i0 + 4]) : 0.f;
+      u[7] = (i0 + 5 < Lin) ? pro(xr[i0 + 5]) : 0.f;
+    }
+  }
+  float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float gi[4];
+  if (S == 1) {
+    float gw[8];
+    float4 gv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) gv4 = *reinterpret_cast<const float4*>(gd + i0);
+    gw[2] = gv4.x;
+    gw[3] = gv4.y;
+    gw[4] = gv4.z;
+    gw[5] = gv4.w;
+    gw[0] = __shfl_up(gw[4], 1, 64);
+    gw[1] = __shfl_up(gw[5], 1, 64);
+    gw[6] = __shfl_down(gw[2], 1, 64);
+    gw[7] = __shfl_down(gw[3], 1, 64);
+    if (lane == 0) {
+      gw[0] = (i0 - 2 >= 0 && i0 - 2 < Lout) ? gd[i0 - 2] : 0.f;
+      gw[1] = (i0 - 1 >= 0 && i0 - 1 < Lout) ? gd[i0 - 1] : 0.f;
+    }
+    if (lane == 63) {
+      gw[6] = (i0 + 4 < Lout) ? gd[i0 + 4] : 0.f;
+      gw[7] = (i0 + 5 < Lout) ? gd[i0 + 5] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gv = gw[e + 2];
+      p[5] += gv;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) p[t] = fmaf(gv, u[e + t], p[t]);
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) acc = fmaf(w[t], gw[e + 4 - t], acc);
+      gi[e] = acc;
+    }
+  } else {
+    const int j0 = i0 >> 1;
+    float gq[4];
+    float2 g2 = make_float2(0.f, 0.f);
+    if (valid) g2 = *reinterpret_cast<const float2*>(gd + j0);   // Lout = Lin/2: both outputs exist
+    gq[1] = g2.x;
+    gq[2] = g2.y;
+    gq[0] = __shfl_up(gq[2], 1, 64);
+    gq[3] = __shfl_down(gq[1], 1, 64);
+    if (lane == 0) gq[0] = (j0 - 1 >= 0 && j0 - 1 < Lout) ? gd[j0 - 1] : 0.f;
+    if (lane == 63) gq[3] = (j0 + 2 < Lout) ? gd[j0 + 2] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float gv = gq[q + 1];
+      p[5] += gv;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) p[t] = fmaf(gv, u[2 * q + t], p[t]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
       float acc = 0.f;
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        const int num = i + 2 - t;
-        if (num >= 0 && (s == 1 || (num & 1) == 0)) {
-          const int j = s == 1 ? num : num >> 1;
-          if (j < Lout) acc = fmaf(w[t], gd[j], acc);
-        }
+        if (((e + 2 - t) & 1) == 0) acc = fmaf(w[t], gq[(e + 2 - t) / 2 + 1], acc);   // (e+2-t) in [-2, 5]
       }
-      gi[i] = acc;
+      gi[e] = acc;
     }
+  }
+  if (a.gin && valid) *reinterpret_cast<float4*>(a.gin + row * (long)Lin + i0) = make_float4(gi[0], gi[1], gi[2], gi[3]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) p[k] += __shfl_xor(p[k], o, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[threadIdx.x >> 6][k] = p[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    if (gridDim.x == 1)
+      a.rowpart[row * 8 + k] = v;
+    else
+      atomicAdd(&a.rowpart[row * 8 + k], v);
   }
 }
 
@@ -336,7 +522,21 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
   a.Lout = (Lin - 1) / stride + 1;
   a.stride = stride;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(srf_dwconv5_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, st, a);
+  SRF_CHECK_ARG(groups <= 65535 && C <= 65535, "srf_dwconv5_bwd: groups / channels exceed 65535");
+  const bool fast = (Lin % 4) == 0 && srf_aligned16(gd) && srf_aligned16(xin) && (!gin || srf_aligned16(gin)) &&
+                    srf_kernel_mode() != 1;
+  const int per_block = fast ? 1024 : 2048;
+  const int chunks = (Lin + per_block - 1) / per_block;
+  if (chunks > 1) SRF_CHECK_HIP(hipMemsetAsync(a.rowpart, 0, sizeof(float) * (size_t)rows * 8, st));
+  dim3 grid((unsigned)chunks, (unsigned)C, (unsigned)groups);
+  if (fast && stride == 1)
+    hipLaunchKernelGGL(srf_dwconv5_bwd_fast_kernel<1>, grid, dim3(256), 0, st, a);
+  else if (fast)
+    hipLaunchKernelGGL(srf_dwconv5_bwd_fast_kernel<2>, grid, dim3(256), 0, st, a);
+  else if (stride == 1)
+    hipLaunchKernelGGL(srf_dwconv5_bwd_kernel<1>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(srf_dwconv5_bwd_kernel<2>, grid, dim3(256), 0, st, a);
   SRF_CHECK_LAUNCH("dwconv5_bwd", st);
   if (dw || dbias) {
     hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, a.rowpart,

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void srf_wgrad_reduce_kernel(const float* __re
 }
 
 static int wg_pick_partials(int ntiles, int nchunks) {
-  int P = (4 * 256 + ntiles - 1) / ntiles;   // ~4 blocks per CU in total (2 resident)
+  int P = (2 * 256 + ntiles - 1) / ntiles;   // one resident wave of blocks (2 per CU): fewer, longer partials
   if (P > nchunks) P = nchunks;
   if (P > 128) P = 128;
   if (P < 1) P = 1;
