@@ -77,3 +77,28 @@ def separate_sharded(model, mixtures, gather=False):
     parts = [torch.empty_like(local) for _ in range(ws)]
     dist.all_gather(parts, local.contiguous())
     return torch.cat(parts, 0)
+
+
+def allreduce_gradients(parameters, average=True):
+    """The training step's only collective: ONE all-reduce of the flat fp32 gradient over
+    RCCL / xGMI after backward, then 1/world scaling -- what replaces the reference's DataParallel gather of
+    replica gradients onto GPU 0 (run_improved_sudormrf.py:118).  Every rank then runs the identical
+    clip_grad_norm_ + Adam step on identical gradients, so the replicas stay bit-identical without a broadcast.
+    With equal shard sizes the averaged gradient equals the gradient of the reference's batch-mean loss
+    (losses/sisdr.py:307); the +-30 clamp of the runner acts on each shard's mean here (it only gates the gradient
+    when the loss is saturated).  Returns the flat gradient (a copy; .grad tensors are updated)."""
+    params = [p for p in parameters if p.grad is not None]
+    if not params:
+        return None
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    _, ws, _ = world()
+    if dist.is_initialized() and ws > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat.mul_(1.0 / ws)
+        off = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+    return flat

@@ -48,6 +48,18 @@ def _worker(rank, world, port, q):
         local = D.separate_sharded(model, wav)
         gathered = D.separate_sharded(model, wav, gather=True)
     assert local.shape[0] == 2
+    # training step collective: sharded batch-mean gradients, all-reduced and averaged == full-batch gradient
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    tgt = torch.from_numpy(make_mixture(4, 640, 7, channels=2, normalize=False))
+    lo2, hi2 = D.shard_slice(4, r, ws)
+    ((torch_oracle.forward(cfg, sdg, wav[lo2:hi2]) - tgt[lo2:hi2]) ** 2).mean().backward()
+    flat = D.allreduce_gradients(list(sdg.values()))
+    sdf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ((torch_oracle.forward(cfg, sdf, wav) - tgt) ** 2).mean().backward()
+    gerr = max(float((a.grad - b.grad).abs().max() / b.grad.abs().max().clamp_min(1e-12))
+               for a, b in zip(sdg.values(), sdf.values()))
+    assert gerr < 1e-4, gerr
+    assert flat.numel() == sum(v.numel() for v in sd.values())
     q.put((rank, float((gathered - full).abs().max()), float((local - full[2 * rank:2 * rank + 2]).abs().max())))
     dist.barrier()
     dist.destroy_process_group()
