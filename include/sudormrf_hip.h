@@ -241,6 +241,16 @@ int srf_pw_wgrad(const float* g, const float* x, const srf_norm* in_norm, int Bt
                  float* dbias, int accumulate, void* scratch, void* stream);
 int srf_pw_wgrad_cols(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout, int L,
                       float* dw, int dw_cols, float* dbias, int accumulate, void* scratch, void* stream);
+/* ... and with a row pitch of dw_ld floats (a column block of a wider matrix, e.g. the two halves of TAC_output) */
+int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout, int L,
+                    float* dw, int dw_cols, int dw_ld, float* dbias, int accumulate, void* scratch, void* stream);
+
+/* TAC backward (groupcomm_sudormrf_v2.py:356-377 under autograd).  x, go, gx: [Bt,G,n,L]; go = gradient w.r.t. the
+ * TAC MLP output (before TAC_norm); gx = gradient through the MLP only; params / grads: the 9 TAC tensors as in
+ * srf_tac / same shapes, gradients ACCUMULATED into.  n in {2,4,8,16}, G in {2,4,8,16}, L % 4 == 0. */
+size_t srf_tac_bwd_scratch_bytes(int Bt, int G, int n, int L);
+int srf_tac_bwd(const float* x, const float* go, const float* const* params, float* const* grads, int Bt, int G, int n,
+                int H, int L, float* gx, void* scratch, void* stream);
 
 /* GlobLN (+PReLU when norm->prelu) backward (improved_sudormrf.py:30-47, PReLU of ConvNormAct :73 / NormAct :113).
  * gout (+ optional gout2, added on load): gradient w.r.t. the normalised (activated) tensor; x: the GlobLN input;

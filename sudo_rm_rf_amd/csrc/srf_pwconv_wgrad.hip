@@ -184,14 +184,15 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_kernel(WgArgs a) {
 
 // out[m][n] (n < cols_out) = sum_p part[p][m][n]   (part rows have `cols` entries)
 __global__ __launch_bounds__(256) void srf_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                               int rows, int cols, int cols_out, int P, float beta) {
+                                                               int rows, int cols, int cols_out, int ld_out, int P,
+                                                               float beta) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)rows * cols_out) return;
   const int m = (int)(i / cols_out), n = (int)(i - (long)m * cols_out);
-  const size_t src = (size_t)m * cols + n, stride = (size_t)rows * cols;
+  const size_t src = (size_t)m * cols + n, stride = (size_t)rows * cols, dst = (size_t)m * ld_out + n;
   float s = 0.f;
   for (int p = 0; p < P; ++p) s += part[(size_t)p * stride + src];
-  out[i] = beta != 0.f ? fmaf(beta, out[i], s) : s;
+  out[dst] = beta != 0.f ? fmaf(beta, out[dst], s) : s;
 }
 
 static int wg_pick_partials(int ntiles, int nchunks) {
@@ -221,12 +222,23 @@ extern "C" size_t srf_pw_wgrad_scratch_bytes(int Bt, int Cout, int Cin, int L) {
 // g: [Bt,Cout,L] gradient w.r.t. the conv output; x: [Bt,Cin,L] the conv's (pre-prologue) input;
 // dw: [Cout,dw_cols] (first dw_cols columns of the Cout x Cin product); dbias: [Cout] or NULL.
 // accumulate != 0: dw += ..., dbias += ... (else overwrite).
+extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout,
+                               int L, float* dw, int dw_cols, int dw_ld, float* dbias, int accumulate, void* scratch,
+                               void* stream);
+
 extern "C" int srf_pw_wgrad_cols(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout,
                                  int L, float* dw, int dw_cols, float* dbias, int accumulate, void* scratch,
                                  void* stream) {
+  return srf_pw_wgrad_ld(g, x, in_norm, Bt, Cin, Cout, L, dw, dw_cols, dw_cols, dbias, accumulate, scratch, stream);
+}
+
+// dw rows have a pitch of dw_ld floats (>= dw_cols): writes a column block of a wider matrix
+extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout,
+                               int L, float* dw, int dw_cols, int dw_ld, float* dbias, int accumulate, void* scratch,
+                               void* stream) {
   SRF_CHECK_ARG(g && x && dw && scratch, "srf_pw_wgrad: null pointer");
   SRF_CHECK_ARG(Bt > 0 && Cin > 0 && Cout > 0 && L > 0 && (L % 4) == 0, "srf_pw_wgrad: bad sizes (L %% 4 == 0 required)");
-  SRF_CHECK_ARG(dw_cols > 0 && dw_cols <= Cin, "srf_pw_wgrad: dw_cols out of range");
+  SRF_CHECK_ARG(dw_cols > 0 && dw_cols <= Cin && dw_ld >= dw_cols, "srf_pw_wgrad: dw_cols / dw_ld out of range");
   SRF_CHECK_ARG(srf_aligned16(g) && srf_aligned16(x), "srf_pw_wgrad: operands must be 16-byte aligned");
   WgArgs a;
   a.g = g;
@@ -253,10 +265,10 @@ extern "C" int srf_pw_wgrad_cols(const float* g, const float* x, const srf_norm*
   SRF_CHECK_LAUNCH("pw_wgrad", st);
   const long nw = (long)Cout * dw_cols;
   hipLaunchKernelGGL(srf_wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout,
-                     Cin, dw_cols, a.P, accumulate ? 1.f : 0.f);
+                     Cin, dw_cols, dw_ld, a.P, accumulate ? 1.f : 0.f);
   if (dbias)
     hipLaunchKernelGGL(srf_wgrad_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, st, a.bias_part,
-                       dbias, Cout, 1, 1, a.P, accumulate ? 1.f : 0.f);
+                       dbias, Cout, 1, 1, 1, a.P, accumulate ? 1.f : 0.f);
   SRF_CHECK_LAUNCH("pw_wgrad_reduce", st);
   return SRF_OK;
 }

@@ -323,3 +323,308 @@ extern "C" int srf_tac(const float* x, float* q, const float* const* params, int
   SRF_CHECK_LAUNCH("tac", st);
   return SRF_OK;
 }
+
+extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* in_norm, int Bt, int Cin, int Cout, int L,
+                               float* dw, int dw_cols, int dw_ld, float* dbias, int accumulate, void* scratch,
+                               void* stream);
+
+__global__ void srf_tac_slope_add_kernel(const float* __restrict__ d, float* gi, float* gm, float* go) {
+  if (threadIdx.x == 0) {
+    gi[0] += d[0];
+    gm[0] += d[1];
+    go[0] += d[2];
+  }
+}
+
+// =============================================================================================
+// TAC backward (training step; reference autograd over groupcomm_sudormrf_v2.py:356-377).
+// Same lane = (time step, group) mapping as the forward: the whole MLP is recomputed per lane, the three
+// group reductions of the backward (sum_g g_po for the q path, the hidden-unit split of Wm^T g_pq, and its
+// all-reduce) are DPP butterflies again.  The kernel writes the input gradient of the MLP path and the operand
+// tensors of the four weight-gradient GEMMs (srf_pw_wgrad: dWi = g_pz x^T, dWo[:, :H] = g_po z^T,
+// dWo[:, H:] = (sum_g g_po) q^T, dWm = g_pq zbar^T; their bias sums come with them), and accumulates the three
+// PReLU slope gradients.
+// =============================================================================================
+struct TacBwdArgs {
+  const float* x;     // [Bt,G,n,L]
+  const float* go;    // [Bt,G,n,L] gradient w.r.t. the MLP output (pre TAC_norm)
+  const float *wm, *bm, *ai, *am, *ao;
+  float* gx;          // [Bt,G,n,L]
+  float *Z, *GPZ;     // [Bt*G,H,L]
+  float* GPO;         // [Bt*G,n,L]
+  float* GS;          // [Bt,n,L]
+  float *Q, *GPQ, *ZB;   // [Bt,H,L]
+  float* dslope;      // 3 accumulators {ai, am, ao} (device, atomically added)
+  int G, L;
+};
+
+template <int NN, int G>
+__global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, const float* __restrict__ wi,
+                                                                const float* __restrict__ bi,
+                                                                const float* __restrict__ wo,
+                                                                const float* __restrict__ bo) {
+  constexpr int HH = 3 * NN, CW = 64 / G, JPL = (HH + G - 1) / G;
+  constexpr int PM = HH + 4, PO = NN + 4;
+  __shared__ __attribute__((aligned(16))) float s_wm[HH * PM];   // Wm[j][i]
+  __shared__ __attribute__((aligned(16))) float s_wq[HH * PO];   // Wo[i][H + j] stored as [j][i]
+  __shared__ float s_bm[HH];
+  __shared__ float s_red[4][3];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane & (G - 1), c = lane / G;
+  const long b = blockIdx.y;
+  const int L = a.L;
+  for (int e = tid; e < HH * HH; e += 256) s_wm[(e / HH) * PM + (e % HH)] = a.wm[e];
+  for (int e = tid; e < HH * NN; e += 256) {
+    const int j = e / NN, i = e % NN;
+    s_wq[j * PO + i] = wo[i * 2 * HH + HH + j];
+  }
+  for (int e = tid; e < HH; e += 256) s_bm[e] = a.bm[e];
+  __syncthreads();
+  const float ai = a.ai[0], am = a.am[0], ao = a.ao[0];
+  const size_t rowg = (size_t)b * G + g;   // folded (batch, group) row
+  float d_ai = 0.f, d_am = 0.f, d_ao = 0.f;
+
+  const int l0 = (blockIdx.x * 4 + wave) * CW;   // wave-uniform
+  if (l0 < L) {
+    const int l = l0 + c;
+    const bool valid = l < L;
+    const int lc = valid ? l : L - 1;
+    const int jrow = g * JPL;
+
+    float x[NN];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) x[i] = a.x[(rowg * NN + i) * L + lc];
+
+    // ---- forward recompute: pz, zbar (written by the lane that owns the hidden unit), this lane's slice of pq
+    float pz[HH], qacc[JPL];
+#pragma unroll
+    for (int t = 0; t < JPL; ++t) qacc[t] = 0.f;
+#pragma unroll
+    for (int j = 0; j < HH; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) t = fmaf(wi[j * NN + i], x[i], t);
+      pz[j] = t + bi[j];
+      const float zj = srf_prelu(pz[j], ai);
+      const float zb = srf_group_allsum<G>(zj) * (1.f / (float)G);
+      if (valid) {
+        a.Z[(rowg * HH + j) * L + l] = zj;
+        if (j / JPL == g) a.ZB[((size_t)b * HH + j) * L + l] = zb;
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < JPL; ++t2) {
+        const int jr = jrow + t2 < HH ? jrow + t2 : HH - 1;
+        qacc[t2] = fmaf(s_wm[jr * PM + j], zb, qacc[t2]);
+      }
+    }
+    float pq[JPL], r[NN];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) r[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < JPL; ++t) {
+      const bool jm = jrow + t < HH;
+      const int jc = jm ? jrow + t : HH - 1;
+      pq[t] = qacc[t] + s_bm[jc];
+      float qv = srf_prelu(pq[t], am);
+      qv = jm ? qv : 0.f;
+      if (valid && jm) a.Q[((size_t)b * HH + jc) * L + l] = qv;
+      const float* wq = s_wq + jc * PO;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) r[i] = fmaf(wq[i], qv, r[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NN; ++i) r[i] = srf_group_allsum<G>(r[i]);
+
+    // ---- output layer backward
+    float gpo[NN], gs[NN];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) {
+      float po = 0.f;
+#pragma unroll
+      for (int j = 0; j < HH; ++j) po = fmaf(wo[i * 2 * HH + j], srf_prelu(pz[j], ai), po);
+      po = (po + r[i]) + bo[i];
+      const float gv = valid ? a.go[(rowg * NN + i) * L + lc] : 0.f;
+      gpo[i] = po >= 0.f ? gv : gv * ao;
+      if (po < 0.f) d_ao = fmaf(gv, po, d_ao);
+      if (valid) a.GPO[(rowg * NN + i) * L + l] = gpo[i];
+      gs[i] = srf_group_allsum<G>(gpo[i]);
+      if (valid && g == 0) a.GS[((size_t)b * NN + i) * L + l] = gs[i];
+    }
+    // g_z (direct part) = Wo[:, :H]^T g_po
+    float gz[HH];
+#pragma unroll
+    for (int j = 0; j < HH; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) t = fmaf(wo[i * 2 * HH + j], gpo[i], t);
+      gz[j] = t;
+    }
+    // this lane's slice of g_pq = PReLU'(pq) * (Wo[:, H:]^T sum_g g_po)
+    float gpq[JPL];
+#pragma unroll
+    for (int t = 0; t < JPL; ++t) {
+      const bool jm = jrow + t < HH;
+      const int jc = jm ? jrow + t : HH - 1;
+      const float* wq = s_wq + jc * PO;
+      float gq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) gq = fmaf(wq[i], gs[i], gq);
+      gq = jm ? gq : 0.f;
+      gpq[t] = pq[t] >= 0.f ? gq : gq * am;
+      if (valid && jm) {
+        if (pq[t] < 0.f) d_am = fmaf(gq, pq[t], d_am);
+        a.GPQ[((size_t)b * HH + jc) * L + l] = gpq[t];
+      }
+    }
+    // g_zbar = Wm^T g_pq (hidden units split over the G lanes, then all-reduced); g_z += g_zbar / G
+#pragma unroll
+    for (int i = 0; i < HH; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int t2 = 0; t2 < JPL; ++t2) {
+        const int jr = jrow + t2 < HH ? jrow + t2 : HH - 1;
+        t = fmaf(s_wm[jr * PM + i], gpq[t2], t);
+      }
+      gz[i] = fmaf(srf_group_allsum<G>(t), 1.f / (float)G, gz[i]);
+    }
+    // input layer backward
+    float gx[NN];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) gx[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < HH; ++j) {
+      const float gp = pz[j] >= 0.f ? gz[j] : gz[j] * ai;
+      if (valid) {
+        if (pz[j] < 0.f) d_ai = fmaf(gz[j], pz[j], d_ai);
+        a.GPZ[(rowg * HH + j) * L + l] = gp;
+      }
+#pragma unroll
+      for (int i = 0; i < NN; ++i) gx[i] = fmaf(wi[j * NN + i], gp, gx[i]);
+    }
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < NN; ++i) a.gx[(rowg * NN + i) * L + l] = gx[i];
+    } else {
+      d_ao = 0.f;
+    }
+  }
+  // ---- slope gradients: block reduction, one atomic per block and slope
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    d_ai += __shfl_xor(d_ai, o, 64);
+    d_am += __shfl_xor(d_am, o, 64);
+    d_ao += __shfl_xor(d_ao, o, 64);
+  }
+  if (lane == 0) {
+    s_red[wave][0] = d_ai;
+    s_red[wave][1] = d_am;
+    s_red[wave][2] = d_ao;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const float t = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    if (t != 0.f) atomicAdd(a.dslope + tid, t);
+  }
+}
+
+template <int NN>
+static bool srf_tac_bwd_g(const TacBwdArgs& a, const float* const* P, int Bt, hipStream_t st) {
+#define SRF_TAC_BWD_GO(GG)                                                                                  \
+  {                                                                                                          \
+    constexpr int CW = 64 / GG;                                                                              \
+    dim3 grid((a.L + 4 * CW - 1) / (4 * CW), Bt);                                                            \
+    hipLaunchKernelGGL((srf_tac_bwd_lanes_kernel<NN, GG>), grid, dim3(256), 0, st, a, P[0], P[1], P[6], P[7]); \
+    return true;                                                                                             \
+  }
+  switch (a.G) {
+    case 2: SRF_TAC_BWD_GO(2)
+    case 4: SRF_TAC_BWD_GO(4)
+    case 8: SRF_TAC_BWD_GO(8)
+    case 16: SRF_TAC_BWD_GO(16)
+    default: return false;
+  }
+#undef SRF_TAC_BWD_GO
+}
+
+static size_t tac_al(size_t v) { return (v + 63) / 64 * 64; }
+
+extern "C" size_t srf_tac_bwd_scratch_bytes(int Bt, int G, int n, int L) {
+  if (Bt <= 0 || G <= 0 || n <= 0 || L <= 0) return 0;
+  const size_t H = 3 * (size_t)n, BG = (size_t)Bt * G;
+  const size_t fl = 2 * tac_al(BG * H * L) + tac_al(BG * n * L) + tac_al((size_t)Bt * n * L) + 3 * tac_al((size_t)Bt * H * L) + 64;
+  size_t wg = srf_pw_wgrad_scratch_bytes((int)BG, (int)H, n, L);
+  const size_t w2 = srf_pw_wgrad_scratch_bytes((int)BG, n, (int)H, L), w3 = srf_pw_wgrad_scratch_bytes(Bt, (int)H, (int)H, L);
+  if (w2 > wg) wg = w2;
+  if (w3 > wg) wg = w3;
+  return sizeof(float) * fl + wg + 256;
+}
+
+// x, go, gx: [Bt,G,n,L]; params: the 9 TAC tensors as in srf_tac; grads: 9 device pointers of the same shapes,
+// ACCUMULATED into.  gx receives the MLP-path gradient only (the residual / TAC_norm paths are the caller's).
+extern "C" int srf_tac_bwd(const float* x, const float* go, const float* const* params, float* const* grads, int Bt,
+                           int G, int n, int H, int L, float* gx, void* scratch, void* stream) {
+  SRF_CHECK_ARG(x && go && params && grads && gx && scratch, "srf_tac_bwd: null pointer");
+  SRF_CHECK_ARG(Bt > 0 && G > 0 && n > 0 && L > 0 && Bt <= 65535 && (L % 4) == 0, "srf_tac_bwd: bad sizes (L %% 4 == 0)");
+  SRF_CHECK_ARG(H == 3 * n, "srf_tac_bwd: hidden size must be 3*n");
+  for (int i = 0; i < 9; ++i) SRF_CHECK_ARG(params[i] && grads[i], "srf_tac_bwd: null parameter / gradient %d", i);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t BG = (size_t)Bt * G;
+  float* f = reinterpret_cast<float*>(scratch);
+  TacBwdArgs a;
+  a.x = x;
+  a.go = go;
+  a.wm = params[3];
+  a.bm = params[4];
+  a.ai = params[2];
+  a.am = params[5];
+  a.ao = params[8];
+  a.gx = gx;
+  a.Z = f;
+  f += tac_al(BG * H * L);
+  a.GPZ = f;
+  f += tac_al(BG * H * L);
+  a.GPO = f;
+  f += tac_al(BG * n * L);
+  a.GS = f;
+  f += tac_al((size_t)Bt * n * L);
+  a.Q = f;
+  f += tac_al((size_t)Bt * H * L);
+  a.GPQ = f;
+  f += tac_al((size_t)Bt * H * L);
+  a.ZB = f;
+  f += tac_al((size_t)Bt * H * L);
+  a.dslope = f;
+  f += 64;
+  void* wg = f;
+  a.G = G;
+  a.L = L;
+  SRF_CHECK_HIP(hipMemsetAsync(a.dslope, 0, 3 * sizeof(float), st));
+  bool ok = false;
+  switch (n) {
+    case 2: ok = srf_tac_bwd_g<2>(a, params, Bt, st); break;
+    case 4: ok = srf_tac_bwd_g<4>(a, params, Bt, st); break;
+    case 8: ok = srf_tac_bwd_g<8>(a, params, Bt, st); break;
+    case 16: ok = srf_tac_bwd_g<16>(a, params, Bt, st); break;
+    default: break;
+  }
+  if (!ok) {
+    srf_set_error("srf_tac_bwd: n=%d, G=%d unsupported (n in 2,4,8,16; G in 2,4,8,16)", n, G);
+    return SRF_EINVAL;
+  }
+  SRF_CHECK_LAUNCH("tac_bwd", st);
+  int rc;
+  // weight / bias gradients: four reductions over (batch, group, time) as weight-gradient GEMMs
+  rc = srf_pw_wgrad(a.GPZ, x, nullptr, (int)BG, n, H, L, grads[0], grads[1], 1, wg, stream);              // dWi, dbi
+  if (rc) return rc;
+  rc = srf_pw_wgrad_ld(a.GPO, a.Z, nullptr, (int)BG, H, n, L, grads[6], H, 2 * H, grads[7], 1, wg, stream);   // dWo[:, :H], dbo
+  if (rc) return rc;
+  rc = srf_pw_wgrad_ld(a.GS, a.Q, nullptr, Bt, H, n, L, grads[6] + H, H, 2 * H, nullptr, 1, wg, stream);      // dWo[:, H:]
+  if (rc) return rc;
+  rc = srf_pw_wgrad(a.GPQ, a.ZB, nullptr, Bt, H, H, L, grads[3], grads[4], 1, wg, stream);                 // dWm, dbm
+  if (rc) return rc;
+  // the three slope gradients: grads[2,5,8] += dslope[0,1,2]
+  hipLaunchKernelGGL(srf_tac_slope_add_kernel, dim3(1), dim3(64), 0, st, a.dslope, grads[2], grads[5], grads[8]);
+  SRF_CHECK_LAUNCH("tac_bwd_slopes", st);
+  return SRF_OK;
+}

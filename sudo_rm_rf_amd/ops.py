@@ -311,6 +311,23 @@ def frames_gather(src, K, hop, pad, L, rows_out=None):
     return out
 
 
+def tac_bwd(x, go, params, grads=None):
+    """TAC MLP backward.  x, go [Bt,G,n,L]; params: the 9 TAC tensors -> (gx, grads) (grads accumulated into)."""
+    dev = _chk(x, go, *params)
+    Bt, G, n, L = x.shape
+    lib = _lib.load()
+    if grads is None:
+        grads = [torch.zeros_like(p) for p in params]
+    gx = torch.empty_like(x)
+    scratch = torch.empty(lib.srf_tac_bwd_scratch_bytes(Bt, G, n, L), dtype=torch.uint8, device=dev)
+    parr = (C.c_void_p * 9)(*[p.data_ptr() for p in params])
+    garr = (C.c_void_p * 9)(*[g.data_ptr() for g in grads])
+    rc = lib.srf_tac_bwd(_lib.ptr(x), _lib.ptr(go), parr, garr, Bt, G, n, 3 * n, L, _lib.ptr(gx), _lib.ptr(scratch),
+                         _lib.current_stream(dev))
+    _lib.check(rc, "srf_tac_bwd")
+    return gx, grads
+
+
 def wav_normalize(wav):
     """Per-row (x - mean) / (std + 1e-9), std unbiased (README.md:100-103).  wav [rows,T] or [Bt,1,T] ->
     (normalised wav of the same shape, stats [rows,2] = {mean, std})."""

@@ -195,3 +195,28 @@ def test_decoder_backward_via_frames(Bt, Ci, Co, K, L):
     assert rel_err(gv, v.grad) <= 2e-5
     dw, _ = ops.pw_wgrad(dev32(v.detach()), frames, want_bias=False)
     assert rel_err(dw[:, :Co * K].reshape(Ci, Co, K), w.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("Bt,G,n,L", [(2, 16, 16, 300), (1, 4, 8, 76), (2, 8, 4, 132), (2, 2, 2, 64), (3, 16, 8, 40)])
+def test_tac_bwd(Bt, G, n, L):
+    """TAC MLP backward (groupcomm_sudormrf_v2.py:356-377) against fp64 autograd."""
+    from sudo_rm_rf_amd import ops
+    H = 3 * n
+    x = rnd(Bt, G, n, L, seed=90).requires_grad_(True)
+    P = [rnd(H, n, seed=91, scale=n ** -0.5), rnd(H, seed=92, scale=0.2), torch.tensor([0.2], dtype=torch.float64),
+         rnd(H, H, seed=93, scale=H ** -0.5), rnd(H, seed=94, scale=0.2), torch.tensor([0.3], dtype=torch.float64),
+         rnd(n, 2 * H, seed=95, scale=(2 * H) ** -0.5), rnd(n, seed=96, scale=0.2),
+         torch.tensor([0.15], dtype=torch.float64)]
+    P = [p.requires_grad_(True) for p in P]
+    pr = lambda t, a: torch.where(t >= 0, t, a * t)
+    rows = x.permute(0, 3, 1, 2).reshape(-1, n)
+    z = pr(rows @ P[0].T + P[1], P[2]).view(Bt, L, G, H)
+    q = pr(z.mean(2).view(Bt * L, H) @ P[3].T + P[4], P[5])
+    cat = torch.cat([z.view(Bt * L, G, H), q.unsqueeze(1).expand(Bt * L, G, H)], 2).reshape(-1, 2 * H)
+    o = pr(cat @ P[6].T + P[7], P[8]).view(Bt, L, G, n).permute(0, 2, 3, 1).contiguous()
+    go = rnd(Bt, G, n, L, seed=97)
+    o.backward(go)
+    gx, grads = ops.tac_bwd(dev32(x.detach()), dev32(go), [dev32(p.detach()) for p in P])
+    assert rel_err(gx, x.grad) <= 3e-5, rel_err(gx, x.grad)
+    for i, (g, p) in enumerate(zip(grads, P)):
+        assert rel_err(g, p.grad) <= 5e-5, (i, rel_err(g, p.grad))
