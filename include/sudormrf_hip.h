@@ -287,7 +287,7 @@ int srf_prelu_bwd(const float* gout, const float* x, const float* slope, float* 
 int srf_frames_gather(const float* src, float* out, int Bt, int R, int T, int K, int hop, int pad, int L, int rows_out,
                       void* stream);
 
-/* ---- training step (Improved SuDoRM-RF only; SURVEY.md §8b proposal: srf_forward_train / srf_backward) ----
+/* ---- training step (both models; SURVEY.md §8b proposal: srf_forward_train / srf_backward) ----
  * srf_forward_train: the forward of srf_forward, un-fused where the backward needs an intermediate, keeping what
  *   the backward needs in `saved` (srf_train_saved_bytes: GlobLN statistics, encoder output, residual stream,
  *   per block y1 / D levels / merged, mask pre-activation, masked encoding).

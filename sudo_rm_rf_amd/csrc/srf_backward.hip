@@ -676,3 +676,25 @@ extern "C" int srf_frames_gather(const float* src, float* out, int Bt, int R, in
   SRF_CHECK_LAUNCH("frames_gather", stream);
   return SRF_OK;
 }
+
+// dst += src (gradient accumulation where no producer epilogue can do it)
+__global__ __launch_bounds__(256) void srf_accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 a = *reinterpret_cast<float4*>(dst + i);
+    const float4 b = *reinterpret_cast<const float4*>(src + i);
+    a.x += b.x;
+    a.y += b.y;
+    a.z += b.z;
+    a.w += b.w;
+    *reinterpret_cast<float4*>(dst + i) = a;
+  } else {
+    for (long k = i; k < n; ++k) dst[k] += src[k];
+  }
+}
+
+int srf_accumulate_launch(float* dst, const float* src, long n, hipStream_t st) {
+  hipLaunchKernelGGL(srf_accumulate_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, dst, src, n);
+  SRF_CHECK_LAUNCH("accumulate", st);
+  return SRF_OK;
+}

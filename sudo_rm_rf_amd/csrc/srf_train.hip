@@ -1,5 +1,5 @@
 // Training step, device side: forward that keeps what the backward needs, and the backward
-// of the whole Improved SuDoRM-RF graph (improved_sudormrf.py:283-301 under autograd), as sequences of the
+// of the whole SuDoRM-RF graph (improved_sudormrf.py:283-301 / groupcomm_sudormrf_v2.py:302-322 under autograd), as sequences of the
 // per-kernel entry points of this library.  The reference gets the same result from torch autograd over ~1.8 k
 // ATen nodes (run_improved_sudormrf.py:167-172: rec = model(x); l = clamp(loss(rec, clean)); l.backward()).
 //
@@ -11,15 +11,18 @@
 //                       pre-activation m and the masked encoding v.
 //   srf_backward      : walks the graph in reverse; parameter gradients are ACCUMULATED into `grads` (same
 //                       order / shapes as the parameters; the caller zeroes them, like optimizer.zero_grad()).
-// GroupComm (TAC) has no backward yet: both entry points refuse that variant.
+// GroupComm: each block is preceded by TAC (MLP + TAC_norm + residual, groupcomm_sudormrf_v2.py:356-384) and the
+// U-ConvBlock runs on the (batch x group)-folded tensor with channels / G (:388-418); `saved` additionally keeps the
+// TAC MLP output q and the block input u = x + GlobLN(q).
 #include "srf_plan.h"
 
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
+int srf_accumulate_launch(float* dst, const float* src, long n, hipStream_t st);
 
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct TrainLayout {
-  size_t stats, enc, x0, x_stride, blk0, blk_stride, y1, lv[SRF_MAX_DEPTH], merged, m, v, total;
+  size_t stats, enc, x0, x_stride, blk0, blk_stride, y1, lv[SRF_MAX_DEPTH], merged, q, u, m, v, total;
 };
 
 static TrainLayout train_layout(const srf_plan* p) {
@@ -47,6 +50,9 @@ static TrainLayout train_layout(const srf_plan* p) {
   t.y1 = rtake(F * Bt * c.in_channels * L);
   for (int k = 0; k < SRF_MAX_DEPTH; ++k) t.lv[k] = k < D ? rtake(F * Bt * c.in_channels * (L >> k)) : 0;
   t.merged = rtake(F * Bt * c.in_channels * L);
+  const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;
+  t.q = gc ? rtake(F * Bt * c.out_channels * L) : 0;
+  t.u = gc ? rtake(F * Bt * c.out_channels * L) : 0;
   t.blk_stride = rel;
   t.blk0 = take(rel * U);
   t.m = take(F * Bt * p->SA * c.enc_num_basis * L);
@@ -57,7 +63,7 @@ static TrainLayout train_layout(const srf_plan* p) {
 
 struct ScratchLayout {
   size_t dec, gv, genc, gxa, gxb, gf, go, gd, gn[SRF_MAX_DEPTH], gu[SRF_MAX_DEPTH], frames, wt, zeros, wdpad, wg,
-      gln, dw, total;
+      gln, dw, gq, gxm, tac, total;
   int dec_rows;
 };
 
@@ -99,22 +105,35 @@ static ScratchLayout scratch_layout(const srf_plan* p) {
     if (b > wg) wg = b;
   };
   wgmax(B, N);
-  wgmax(C, B);
-  wgmax(B, C);
   wgmax(SAN, B);
   wgmax(SAN, s.dec_rows);
   wgmax(N, (int)enc_rows);
+  {
+    const size_t b1 = srf_pw_wgrad_scratch_bytes(p->Bg, p->nC, p->nB, p->L), b2 = srf_pw_wgrad_scratch_bytes(p->Bg, p->nB, p->nC, p->L);
+    if (b1 > wg) wg = b1;
+    if (b2 > wg) wg = b2;
+  }
   s.wg = take(wg);
-  s.gln = take(srf_gln_bwd_scratch_bytes(p->Bt, C > N ? C : N));
-  s.dw = take(srf_dwconv5_bwd_scratch_bytes(p->Bt, C));
+  s.gln = take(max3(srf_gln_bwd_scratch_bytes(p->Bg, p->nC), srf_gln_bwd_scratch_bytes(p->Bt, N),
+                    srf_gln_bwd_scratch_bytes(p->Bg, p->nB)));
+  s.dw = take(srf_dwconv5_bwd_scratch_bytes(p->Bg, p->nC));
+  const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;
+  s.gq = gc ? take(F * Bt * B * L) : 0;
+  s.gxm = gc ? take(F * Bt * B * L) : 0;
+  s.tac = gc ? take(srf_tac_bwd_scratch_bytes(p->Bt, c.group_size, p->nB, p->L)) : 0;
   s.total = off;
   return s;
 }
 
 static int train_check(const srf_plan* p, const char* who) {
-  if (p->cfg.variant != SRF_VARIANT_IMPROVED) {
-    srf_set_error("%s: the training step implements the Improved SuDoRM-RF (the GroupComm TAC has no backward yet)", who);
-    return SRF_EINVAL;
+  if (p->cfg.variant == SRF_VARIANT_GROUPCOMM) {
+    const int n = p->nB, G = p->cfg.group_size;
+    const bool n_ok = n == 2 || n == 4 || n == 8 || n == 16, g_ok = G == 2 || G == 4 || G == 8 || G == 16;
+    if (!n_ok || !g_ok) {
+      srf_set_error("%s: TAC backward supports out_channels/group_size in {2,4,8,16} and group_size in {2,4,8,16} "
+                    "(got %d, %d)", who, n, G);
+      return SRF_EINVAL;
+    }
   }
   if (p->L % 4 != 0) {
     srf_set_error("%s: L=%d must be a multiple of 4", who, p->L);
@@ -144,7 +163,7 @@ extern "C" int srf_forward_train(const srf_plan* p, const float* const* P, int n
   char* sc = (char*)scratch;
   hipStream_t st = (hipStream_t)stream;
   double* stats = (double*)(sv + t.stats);
-  auto slot = [&](int i) { return stats + (size_t)i * Bt * SRF_STAT_BUCKETS * 2; };
+  auto slot = [&](int i) { return stats + (size_t)i * p->Bg * SRF_STAT_BUCKETS * 2; };
   auto xbuf = [&](int i) { return (float*)(sv + t.x0 + t.x_stride * i); };
   SRF_CHECK_HIP(hipMemsetAsync(stats, 0, p->stats_bytes, st));
 
@@ -156,13 +175,29 @@ extern "C" int srf_forward_train(const srf_plan* p, const float* const* P, int n
     rc = srf_pw_conv(enc, P[3], P[4], xbuf(0), Bt, N, B, L, &ln, nullptr, nullptr, 0, nullptr, 0, stream);
     if (rc) return rc;
   }
+  const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;
+  const int G = gc ? c.group_size : 1, Bg = p->Bg, nB = p->nB, nC = p->nC;
   for (int i = 0; i < U; ++i) {
-    const float* const* Pu = P + p->p_block0 + (size_t)i * p->p_block_stride;
-    const int s0 = 1 + i * p->slots_per_block;
+    const float* const* Pb = P + p->p_block0 + (size_t)i * p->p_block_stride;
+    const float* const* Pu = Pb + p->p_ublock_off;
+    int s0 = 1 + i * p->slots_per_block;
     char* blk = sv + t.blk0 + t.blk_stride * i;
     float* y1 = (float*)(blk + t.y1);
     float* merged = (float*)(blk + t.merged);
-    rc = srf_pw_conv(xbuf(i), Pu[0], Pu[1], y1, Bt, B, C, L, nullptr, nullptr, slot(s0), 0, nullptr, 0, stream);
+    const float* xin = xbuf(i);
+    if (gc) {
+      // TAC: q = MLPs(x), u = x + GlobLN_(b,g)(q)                 groupcomm_sudormrf_v2.py:356-384
+      float* q = (float*)(blk + t.q);
+      float* u = (float*)(blk + t.u);
+      rc = srf_tac(xin, q, Pb, Bt, G, nB, 3 * nB, L, slot(s0), stream);
+      if (rc) return rc;
+      srf_norm tn{slot(s0), Pb[9], Pb[10], nullptr};
+      rc = srf_gln_apply_add(xin, q, u, &tn, Bg, nB, L, stream);
+      if (rc) return rc;
+      xin = u;
+      s0 += 1;
+    }
+    rc = srf_pw_conv(xin, Pu[0], Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0), 0, nullptr, 0, stream);
     if (rc) return rc;
     const float* levels[SRF_MAX_DEPTH];
     srf_norm norms[SRF_MAX_DEPTH];
@@ -184,16 +219,16 @@ extern "C" int srf_forward_train(const srf_plan* p, const float* const* P, int n
         Lin = L >> (k - 1);
         stride = 2;
       }
-      rc = srf_dwconv5(src, Pk[0], Pk[1], dk, Bt, C, Lin, stride, &in, slot(s0 + 1 + k), stream);
+      rc = srf_dwconv5(src, Pk[0], Pk[1], dk, Bg, nC, Lin, stride, &in, slot(s0 + 1 + k), stream);
       if (rc) return rc;
       levels[k] = dk;
       norms[k] = srf_norm{slot(s0 + 1 + k), Pk[2], Pk[3], nullptr};
     }
-    rc = srf_merge(levels, norms, D, merged, Bt, C, L, slot(s0 + 1 + D), stream);
+    rc = srf_merge(levels, norms, D, merged, Bg, nC, L, slot(s0 + 1 + D), stream);
     if (rc) return rc;
     const float* const* Pf = Pu + 5 + 4 * D;
     srf_norm fn{slot(s0 + 1 + D), Pf[0], Pf[1], Pf[2]};
-    rc = srf_pw_conv(merged, Pf[3], Pf[4], xbuf(i + 1), Bt, C, B, L, &fn, xbuf(i), nullptr, 0, nullptr, 0, stream);
+    rc = srf_pw_conv(merged, Pf[3], Pf[4], xbuf(i + 1), Bg, nC, nB, L, &fn, xin, nullptr, 0, nullptr, 0, stream);
     if (rc) return rc;
   }
   const float* const* Pt = P + p->p_tail;
@@ -227,7 +262,7 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
   char* sc = (char*)scratch;
   hipStream_t st = (hipStream_t)stream;
   double* stats = (double*)(sv + t.stats);
-  auto slot = [&](int i) { return stats + (size_t)i * Bt * SRF_STAT_BUCKETS * 2; };
+  auto slot = [&](int i) { return stats + (size_t)i * p->Bg * SRF_STAT_BUCKETS * 2; };
   auto xbuf = [&](int i) { return (const float*)(sv + t.x0 + t.x_stride * i); };
   auto fp = [&](size_t o) { return (float*)(sc + o); };
   const float* enc = (const float*)(sv + t.enc);
@@ -271,33 +306,37 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     rc = srf_prelu_bwd(gx, xbuf(U), P[pt], gx, G[pt], (long)Bt * B * L, stream);
     if (rc) return rc;
   }
-  // ---- U-ConvBlocks in reverse                                  :198-220
+  // ---- blocks in reverse: U-ConvBlock :198-220 (GroupComm: on the folded tensor, preceded by TAC)
+  const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;
+  const int G_ = gc ? c.group_size : 1, Bg = p->Bg, nB = p->nB, nC = p->nC;
   float* gf = fp(s.gf);
   float* go = fp(s.go);
   float* gd = fp(s.gd);
   for (int i = U - 1; i >= 0; --i) {
-    const int pu = p->p_block0 + i * p->p_block_stride;
+    const int pb = p->p_block0 + i * p->p_block_stride;
+    const int pu = pb + p->p_ublock_off;
     const float* const* Pu = P + pu;
     float* const* Gu = G + pu;
-    const int s0 = 1 + i * p->slots_per_block;
+    const int s0 = 1 + i * p->slots_per_block + (gc ? 1 : 0);
     const char* blk = sv + t.blk0 + t.blk_stride * i;
     const float* y1 = (const float*)(blk + t.y1);
     const float* merged = (const float*)(blk + t.merged);
+    const float* xin = gc ? (const float*)(blk + t.u) : xbuf(i);   // the U-ConvBlock's input
     const int pf = 5 + 4 * D;   // final_norm.gamma, .beta, act.weight, res_conv.weight, .bias
-    // res_conv: x_{i+1} = W_r PReLU(GlobLN(merged)) + b_r + x_i
+    // res_conv: x_{i+1} = W_r PReLU(GlobLN(merged)) + b_r + xin
     srf_norm fn{slot(s0 + 1 + D), Pu[pf], Pu[pf + 1], Pu[pf + 2]};
-    rc = srf_pw_wgrad(gx, merged, &fn, Bt, C, B, L, Gu[pf + 3], Gu[pf + 4], 1, wg, stream);
+    rc = srf_pw_wgrad(gx, merged, &fn, Bg, nC, nB, L, Gu[pf + 3], Gu[pf + 4], 1, wg, stream);
     if (rc) return rc;
-    rc = srf_transpose_launch(Pu[pf + 3], wt, B, C, st);    // [B][C] -> [C][B]
+    rc = srf_transpose_launch(Pu[pf + 3], wt, nB, nC, st);    // [nB][nC] -> [nC][nB]
     if (rc) return rc;
-    rc = srf_pw_conv(gx, wt, zeros, gf, Bt, B, C, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+    rc = srf_pw_conv(gx, wt, zeros, gf, Bg, nB, nC, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
     if (rc) return rc;
-    rc = srf_gln_bwd(gf, nullptr, merged, &fn, Bt, C, L, gf, 0, Gu[pf], Gu[pf + 1], Gu[pf + 2], sc + s.gln, stream);
+    rc = srf_gln_bwd(gf, nullptr, merged, &fn, Bg, nC, L, gf, 0, Gu[pf], Gu[pf + 1], Gu[pf + 2], sc + s.gln, stream);
     if (rc) return rc;                                       // gf now holds g_merged = g_n_0 (merge part)
     float* gn[SRF_MAX_DEPTH];
     gn[0] = gf;
     for (int k = 1; k < D; ++k) gn[k] = fp(s.gn[k]);
-    rc = srf_merge_bwd(gf, gn, D, (long)Bt * C, L, stream);
+    rc = srf_merge_bwd(gf, gn, D, (long)Bg * nC, L, stream);
     if (rc) return rc;
     for (int k = D - 1; k >= 0; --k) {
       const float* const* Pk = Pu + 5 + 4 * k;   // conv.weight, conv.bias, norm.gamma, norm.beta
@@ -305,9 +344,9 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
       const float* dk = (const float*)(blk + t.lv[k]);
       const int Lk = L >> k;
       srf_norm nk{slot(s0 + 1 + k), Pk[2], Pk[3], nullptr};
-      const float* gu_in = (k < D - 1) ? (k == 0 ? go : fp(s.gu[k])) : nullptr;   // from level k+1's conv
-      // careful: for k == 0 the contribution of level 1's conv lives in gu0 (see below)
-      rc = srf_gln_bwd(gn[k], gu_in, dk, &nk, Bt, C, Lk, gd, 0, Gk[2], Gk[3], nullptr, sc + s.gln, stream);
+      // gradient w.r.t. the normalised level k: merge part (gn[k]) + what level k+1's conv sent down
+      const float* gu_in = (k < D - 1) ? (k == 0 ? go : fp(s.gu[k])) : nullptr;
+      rc = srf_gln_bwd(gn[k], gu_in, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, sc + s.gln, stream);
       if (rc) return rc;
       srf_norm in;
       const float* src;
@@ -318,7 +357,7 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
         src = y1;
         Lin = L;
         stride = 1;
-        gin = go;       // gradient w.r.t. o = PReLU(GlobLN(y1)); (go was consumed as gu_in above)
+        gin = go;       // gradient w.r.t. o = PReLU(GlobLN(y1)) (go was consumed as gu_in just above)
       } else {
         const float* const* Pprev = Pu + 5 + 4 * (k - 1);
         in = srf_norm{slot(s0 + k), Pprev[2], Pprev[3], nullptr};
@@ -327,22 +366,37 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
         stride = 2;
         gin = (k - 1 == 0) ? go : fp(s.gu[k - 1]);   // gradient w.r.t. normalised level k-1
       }
-      rc = srf_dwconv5_bwd(gd, src, &in, Pk[0], Bt, C, Lin, stride, gin, Gk[0], Gk[1], sc + s.dw, stream);
+      rc = srf_dwconv5_bwd(gd, src, &in, Pk[0], Bg, nC, Lin, stride, gin, Gk[0], Gk[1], sc + s.dw, stream);
       if (rc) return rc;
     }
-    // proj_1x1: y1 = W_p x_i + b_p, o = PReLU(GlobLN(y1))
+    // proj_1x1: y1 = W_p xin + b_p, o = PReLU(GlobLN(y1))
     srf_norm pn{slot(s0), Pu[2], Pu[3], Pu[4]};
-    rc = srf_gln_bwd(go, nullptr, y1, &pn, Bt, C, L, go, 0, Gu[2], Gu[3], Gu[4], sc + s.gln, stream);   // go = g_y1
+    rc = srf_gln_bwd(go, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], sc + s.gln, stream);   // go = g_y1
     if (rc) return rc;
-    rc = srf_pw_wgrad(go, xbuf(i), nullptr, Bt, B, C, L, Gu[0], Gu[1], 1, wg, stream);
+    rc = srf_pw_wgrad(go, xin, nullptr, Bg, nB, nC, L, Gu[0], Gu[1], 1, wg, stream);
     if (rc) return rc;
-    rc = srf_transpose_launch(Pu[0], wt, C, B, st);          // [C][B] -> [B][C]
+    rc = srf_transpose_launch(Pu[0], wt, nC, nB, st);          // [nC][nB] -> [nB][nC]
     if (rc) return rc;
-    rc = srf_pw_conv(go, wt, zeros, gx_other, Bt, C, B, L, nullptr, gx, nullptr, 0, nullptr, 0, stream);   // + skip
+    rc = srf_pw_conv(go, wt, zeros, gx_other, Bg, nC, nB, L, nullptr, gx, nullptr, 0, nullptr, 0, stream);   // + skip
     if (rc) return rc;
     float* tmp = gx;
     gx = gx_other;
     gx_other = tmp;
+    if (gc) {
+      // gx = g_u.  u = x + GlobLN_(b,g)(q), q = TAC_MLP(x):  g_x = g_u + MLP^T(GlobLN^T(g_u))
+      const float* const* Pb = P + pb;
+      float* const* Gb = G + pb;
+      const float* q = (const float*)(blk + t.q);
+      float* gq = fp(s.gq);
+      float* gxm = fp(s.gxm);
+      srf_norm tn{slot(s0 - 1), Pb[9], Pb[10], nullptr};
+      rc = srf_gln_bwd(gx, nullptr, q, &tn, Bg, nB, L, gq, 0, Gb[9], Gb[10], nullptr, sc + s.gln, stream);
+      if (rc) return rc;
+      rc = srf_tac_bwd(xbuf(i), gq, Pb, Gb, Bt, G_, nB, 3 * nB, L, gxm, sc + s.tac, stream);
+      if (rc) return rc;
+      rc = srf_accumulate_launch(gx, gxm, (long)Bt * B * L, st);
+      if (rc) return rc;
+    }
   }
   // ---- bottleneck: x_0 = W_b GlobLN(enc) + b_b                  :256-259,292
   {

@@ -186,12 +186,8 @@ class ModelEngine:
         wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
         # model.train() + grad mode = the training step (what the reference's runner does before its loop,
         # run_improved_sudormrf.py:144); model.eval() always takes the fused inference path
-        if wants_grad and module.training and type(module).__name__ == "SuDORMRF":
+        if wants_grad and module.training:
             return self._run_train(module, wav, expected_channels)
-        if wants_grad and module.training and not self._warned_grad:
-            self._warned_grad = True
-            warnings.warn("sudo_rm_rf_amd: the training step (autograd) is implemented for the Improved SuDoRM-RF; "
-                          "this model's output does not carry autograd history.", stacklevel=3)
         params = [p.detach() for p in module.state_dict(keep_vars=True).values()]
         for p in params:
             if p.device != wav.device or p.dtype != torch.float32 or not p.is_contiguous():

@@ -12,8 +12,10 @@ DEV = "cuda:0"
 
 
 def build(cfg, sd):
+    import sudo_rm_rf.dnn.models.groupcomm_sudormrf_v2 as sudormrf_gc_v2
     import sudo_rm_rf.dnn.models.improved_sudormrf as improved_sudormrf
-    m = improved_sudormrf.SuDORMRF(**cfg.ctor_kwargs())
+    cls = improved_sudormrf.SuDORMRF if cfg.variant == "improved" else sudormrf_gc_v2.GroupCommSudoRmRf
+    m = cls(**cfg.ctor_kwargs())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return m.to(DEV)
 
@@ -22,6 +24,8 @@ CASES = [
     ("tiny", ModelConfig("improved", 16, 32, 2, 3, 21, 24, 2), 2, 517),
     ("tiny_d2_s3", ModelConfig("improved", 8, 16, 1, 2, 11, 8, 3), 3, 160),
     ("mfma_shapes", ModelConfig("improved", 64, 128, 2, 4, 21, 64, 2), 2, 2400),
+    ("groupcomm", ModelConfig("groupcomm", 32, 64, 2, 3, 21, 24, 2, 1, 4), 2, 700),
+    ("groupcomm_g16_a2", ModelConfig("groupcomm", 64, 128, 1, 2, 11, 16, 2, 2, 16), 2, 330),
 ]
 
 
@@ -29,8 +33,9 @@ CASES = [
 def test_forward_train_and_backward_match_autograd(name, cfg, Bt, T):
     sd = weights.make_state_dict(cfg, seed=11)
     model = build(cfg, sd).train()
-    wav = torch.from_numpy(weights.make_mixture(Bt, T, seed=12))
-    S = cfg.num_sources
+    A = cfg.in_audio_channels if cfg.variant == "groupcomm" else 1
+    wav = torch.from_numpy(weights.make_mixture(Bt, T, seed=12, channels=A))
+    S = cfg.num_sources * A
     gout = torch.randn(Bt, S, T, generator=torch.Generator().manual_seed(13), dtype=torch.float64)
 
     # fp64 reference: autograd through the oracle's ATen op sequence
