@@ -65,6 +65,7 @@ _PROTOS = {
     "srf_pit_sisdr_backward": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "srf_pw_wgrad_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "srf_pw_wgrad_cols": (_i, [_vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "srf_pw_wgrad_ld": (_i, [_vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "srf_pw_wgrad": (_i, [_vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "srf_gln_bwd_scratch_bytes": (_sz, [_i, _i]),
     "srf_gln_bwd": (_i, [_vp, _vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),

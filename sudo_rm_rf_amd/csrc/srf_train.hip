@@ -158,7 +158,7 @@ extern "C" int srf_forward_train(const srf_plan* p, const float* const* P, int n
   SRF_CHECK_ARG(((((size_t)saved) | ((size_t)scratch)) & 255) == 0, "srf_forward_train: buffers must be 256-byte aligned");
   const srf_config& c = p->cfg;
   const int D = c.upsampling_depth, U = c.num_blocks, N = c.enc_num_basis, K = c.enc_kernel_size;
-  const int Bt = p->Bt, L = p->L, B = c.out_channels, C = c.in_channels;
+  const int Bt = p->Bt, L = p->L, B = c.out_channels;
   char* sv = (char*)saved;
   char* sc = (char*)scratch;
   hipStream_t st = (hipStream_t)stream;
