@@ -304,6 +304,15 @@ int srf_backward(const srf_plan* plan, const float* const* params, float* const*
                  const float* wav, const float* grad_out, const void* saved, size_t saved_bytes, void* scratch,
                  size_t scratch_bytes, void* stream);
 
+/* On-GPU online remix augmentation of the training loop (experiments/run_improved_sudormrf.py:150-164): new source j
+ * of example b = clean[src_b[j][b], src_s[j]] re-scaled to the energy of clean[b, j]; mix = normalize(sum_j),
+ * out[:, j] = normalize(new source j), normalize = (x - mean)/(std + eps) with the unbiased std (:127-131).
+ * clean, out: [B,S,T] (out must not alias clean), mix: [B,T], src_b: [S][B] and src_s: [S] int32 on the device,
+ * S <= 4; scratch: srf_online_remix_scratch_bytes(B, S). */
+size_t srf_online_remix_scratch_bytes(int B, int S);
+int srf_online_remix(const float* clean, const int* src_b, const int* src_s, int B, int S, int T, float eps, float* mix,
+                     float* out, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,8 @@ _PROTOS = {
     "srf_backward": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "srf_tac_bwd_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "srf_tac_bwd": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "srf_online_remix_scratch_bytes": (_sz, [_i, _i]),
+    "srf_online_remix": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
     "srf_wav_normalize": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "srf_wav_denormalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srf_dwconv5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp]),

@@ -85,3 +85,46 @@ def test_training_loop_like_the_reference_runner():
     model.eval()
     with torch.no_grad():
         assert torch.isfinite(model(mix)).all()
+
+
+def test_mixture_consistency_is_differentiable():
+    """run_sudormrf_gc_v2.py:154-160 puts mixture_consistency.apply between the model and the loss."""
+    import sudo_rm_rf.dnn.experiments.utils.mixture_consistency as mixture_consistency
+    g = torch.Generator().manual_seed(3)
+    pr = torch.randn(3, 2, 501, generator=g, dtype=torch.float64, requires_grad=True)
+    mix = torch.randn(3, 1, 501, generator=g, dtype=torch.float64)
+    go = torch.randn(3, 2, 501, generator=g, dtype=torch.float64)
+    want = pr + (mix - pr.sum(1, keepdim=True)) / 2
+    want.backward(go)
+    pr32 = pr.detach().float().to(DEV).requires_grad_(True)
+    out = mixture_consistency.apply(pr32, mix.float().to(DEV))
+    out.backward(go.float().to(DEV))
+    assert (out.detach().cpu().double() - want.detach()).abs().max() <= 1e-6
+    assert (pr32.grad.cpu().double() - pr.grad).abs().max() <= 1e-6
+
+
+@pytest.mark.parametrize("B,S,T", [(8, 2, 4000), (5, 3, 1001), (32, 2, 32000)])
+def test_online_remix_matches_the_runner_lines(B, S, T):
+    """run_improved_sudormrf.py:150-164 (S = 2; run_fuss_separation.py:195-215 for n sources), same RNG draws."""
+    from sudo_rm_rf_amd import augment
+    g = torch.Generator().manual_seed(5)
+    clean = torch.randn(B, S, T, generator=g) * torch.rand(B, S, 1, generator=g) * 2 + 0.1
+
+    def normalize_tensor_wav(w, eps=1e-8):
+        return (w - w.mean(-1, keepdim=True)) / (w.std(-1, keepdim=True) + eps)
+
+    torch.manual_seed(77)
+    c64 = clean.double()
+    energies = torch.sum(c64 ** 2, dim=-1, keepdim=True)
+    random_wavs = c64[:, torch.randperm(S)]
+    news = []
+    for j in range(S):
+        n = random_wavs[torch.randperm(B), j, :]
+        news.append(n * torch.sqrt(energies[:, j] / (n ** 2).sum(-1, keepdims=True)))
+    want_mix = normalize_tensor_wav(sum(news))
+    want_src = torch.stack([normalize_tensor_wav(n) for n in news], 1)
+
+    torch.manual_seed(77)
+    mix, src = augment.online_remix(clean.to(DEV))
+    assert (mix.cpu().double() - want_mix).abs().max() <= 2e-5
+    assert (src.cpu().double() - want_src).abs().max() <= 2e-5
