@@ -8,14 +8,16 @@
 // Same sites / prologue / epilogue as srf_pwconv.hip (reference: improved_sudormrf.py:256-259, :174,
 // :196,:220, :268-269,:295-298).
 //
-// Tiling: block 128(M) x 128(N=time) x 32(K), 4 wavefronts x (2x2 MFMA tiles of 32x32), 64 fp32
-// accumulators per lane.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive-k bf16 per lane for BOTH
-// operands (A: row l&31, B: column l&31, k = 8*(l>>5)+j), but X_b is [k][time] with time contiguous:
-// the transposition happens in registers while staging -- each thread loads 8 k-rows x 2 time steps
-// (coalesced 512-B row segments per wavefront), applies the GlobLN/PReLU prologue, splits, and writes
-// the 8-k packets as 16-B ds_write_b128 into [time][k] LDS images (row pitch 80 B: conflict-free
-// ds_read_b128 fragment fetches).  W is [m][k] row-major already.  LDS: 4 images x 2 stages = 80 KB
-// -> 2 blocks per CU; next k-tile's global loads are issued before the current tile's MFMAs.
+// Tiling: block 128(M) x 128(N=time) x 32(K), 8 wavefronts (4 x 2), each owning 32(M) x 64(time) = two 32x32
+// MFMA tiles (32 fp32 accumulators per lane).  v_mfma_f32_32x32x16_bf16 wants 8 consecutive-k bf16 per lane
+// for BOTH operands (A: row l&31, B: column l&31, k = 8*(l>>5)+j), but X_b is [k][time] with time contiguous:
+// the transposition happens in registers while staging -- each thread loads 8 k-rows x 1 time step (coalesced
+// 256-B row segments per wavefront), applies the GlobLN/PReLU prologue, splits, and writes the 8-k packets as
+// 16-B ds_write_b128 into [time][k] LDS images (row pitch 80 B: conflict-free ds_read_b128 fragment fetches).
+// W is [m][k] row-major already.  LDS: 4 images x 2 stages = 80 KB -> 2 blocks = 16 wavefronts per CU; global
+// loads run two k-tiles ahead of their use.  Two kernels: one tile per block (srf_pw_bf16x3_w8_kernel, also the
+// carrier of the ablation / timeline diagnostics) and the persistent one (srf_pw_bf16x3_p8_kernel, default for
+// >= 3 tiles per block slot).
 #include "srf_pw.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -35,176 +37,18 @@ __device__ __forceinline__ void srf_split8(const float (&v)[8], bf16x8& hi, bf16
 }
 
 // PRO: 0 = identity, 1 = GlobLN, 2 = GlobLN + PReLU, 3 = PReLU only
-template <int PRO>
-__global__ __launch_bounds__(256, 2) void srf_pw_bf16x3_kernel(PwArgs a, int nMt, int nLt, int total) {
-  // exactly 80 KB so that two blocks share a CU's 160 KB; the statistics scratch reuses it at the end
-  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];
-
-  const int v = srf_xcd_remap(blockIdx.x, total);
-  const int mt = v % nMt;
-  const int lt = (v / nMt) % nLt;
-  const long b = v / (nMt * nLt);
-  const int m0 = mt * X3_BM, l0 = lt * X3_BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  float mean = 0.f, rstd = 1.f, slope = 1.f;
-  if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
-  if (PRO == 2 || PRO == 3) slope = a.nrm.prelu[0];
-
-  const int Cin = a.Cin, L = a.L, Cout = a.Cout;
-  const int nk_ = Cin / X3_BK;   // even (host checks Cin % 64 == 0)
-  const float* xb = a.x + (size_t)b * Cin * L;
-
-  // ---- staging assignment
-  // A (weights [m][k]): thread -> row m = tid>>1, k-half kh = tid&1 (16 consecutive k = 4 float4)
-  const int a_m = tid >> 1, a_kh = (tid & 1) * 16;
-  const bool a_ok = (m0 + a_m) < Cout;
-  const float* a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_kh;
-  // B (X_b [k][time]): thread -> time pair n = 2*(tid&63), k-group kg = tid>>6 (8 consecutive k rows)
-  // b_kg is wave-uniform: readfirstlane makes that provable, so the per-channel gamma/beta of the
-  // prologue become scalar (SMEM) loads instead of VMEM loads that would perturb the vmcnt pipeline
-  const int b_n = 2 * (tid & 63), b_kg = __builtin_amdgcn_readfirstlane(tid >> 6) * 8;
-  const bool b_ok = (l0 + b_n) < L;   // L % 4 == 0 and n even -> both elements in range
-  // NOTE: loads are UNCONDITIONAL from clamped (always valid) addresses and masked afterwards: a
-  // "cond ? load : 0" select makes hipcc branch around every load and drain vmcnt(0) behind it, which
-  // serialises the whole prefetch pipeline (cdna_hip_programming.md "register or load" trap).
-  const float* b_src = xb + (size_t)b_kg * L + (b_ok ? (l0 + b_n) : 0);
-  const float a_msk = a_ok ? 1.f : 0.f;   // (out-of-range time columns are simply never stored)
-
-  // Two register sets: tile t lives in set t&1.  Global loads are issued TWO k-tiles ahead of their
-  // use, so that a full MFMA phase plus a conversion phase of latency hiding covers every load (with
-  // one-tile prefetch the kernel measured latency-bound at ~7 % of the matrix pipe).
-  struct Regs {
-    float4 a[4];
-    float2 b[8];
-  };
-  Regs r0, r1;
-  auto gload = [&](Regs& r, int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      r.a[i] = *reinterpret_cast<const float4*>(a_src + k0 + 4 * i);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r.b[j] = *reinterpret_cast<const float2*>(b_src + (size_t)(k0 + j) * L);
-  };
-  auto lds_store = [&](const Regs& r, int stage, int k0) {
-    char* base = smem + stage * X3_STAGE;
-    // A: two 8-k packets per thread
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const float va[8] = {r.a[2 * p].x * a_msk,     r.a[2 * p].y * a_msk,     r.a[2 * p].z * a_msk,
-                           r.a[2 * p].w * a_msk,     r.a[2 * p + 1].x * a_msk, r.a[2 * p + 1].y * a_msk,
-                           r.a[2 * p + 1].z * a_msk, r.a[2 * p + 1].w * a_msk};
-      bf16x8 hi, lo;
-      srf_split8(va, hi, lo);
-      const int off = a_m * X3_PITCH + (a_kh + 8 * p) * 2;
-      *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + off) = hi;
-      *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + off) = lo;
-    }
-    // B: prologue, then one 8-k packet for each of the two time steps
-    float v0[8], v1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float x0 = r.b[j].x, x1 = r.b[j].y;
-      if (PRO == 1 || PRO == 2) {
-        const int k = k0 + b_kg + j;
-        const float sc = a.nrm.gamma[k] * rstd;
-        const float sh = a.nrm.beta[k] - mean * sc;
-        x0 = fmaf(x0, sc, sh);
-        x1 = fmaf(x1, sc, sh);
-      }
-      if (PRO == 2 || PRO == 3) {
-        x0 = srf_prelu(x0, slope);
-        x1 = srf_prelu(x1, slope);
-      }
-      v0[j] = x0;
-      v1[j] = x1;
-    }
-    bf16x8 hi, lo;
-    srf_split8(v0, hi, lo);
-    int off = b_n * X3_PITCH + b_kg * 2;
-    *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + off) = hi;
-    *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + off) = lo;
-    srf_split8(v1, hi, lo);
-    off += X3_PITCH;
-    *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + off) = hi;
-    *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + off) = lo;
-  };
-
-  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-  // fragment addresses: row (lane&31) of the wave's 64-row slab, 16-B k-packet (lane>>5)
-  const int frag = (lane & 31) * X3_PITCH + (lane >> 5) * 16;
-  const int a_row0 = (wm * 64) * X3_PITCH + frag, a_row1 = a_row0 + 32 * X3_PITCH;
-  const int b_row0 = (wn * 64) * X3_PITCH + frag, b_row1 = b_row0 + 32 * X3_PITCH;
-  auto mma_tile = [&](int stage) {
-    const char* base = smem + stage * X3_STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {   // two K=16 MFMA steps per 32-deep tile
-      const int ko = ks * 32;          // 16 bf16 = 32 bytes
-      const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row0 + ko);
-      const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row1 + ko);
-      const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row0 + ko);
-      const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row1 + ko);
-      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row0 + ko);
-      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
-      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
-      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
-    }
-  };
-  // one pipeline step for tile kt (stage kt&1): first convert + store tile kt+1 (already in `nx`,
-  // loaded two steps ago) into the other stage and re-arm `nx` with tile kt+3, then the MFMAs of kt.
-  auto step = [&](Regs& nx, int kt) {
-    // loads are issued unconditionally (clamped to the last tile: a conditional load would make the
-    // compiler's vmcnt bookkeeping conservative and drain the younger register set as well)
-    if (kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
-    gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
-    mma_tile(kt & 1);
-    __syncthreads();
-  };
-
-  gload(r0, 0);
-  gload(r1, X3_BK);           // nk >= 2 (host guarantees Cin % 64 == 0)
-  lds_store(r0, 0, 0);
-  gload(r0, min(2, nk_ - 1) * X3_BK);
-  __syncthreads();
-  for (int kt = 0; kt < nk_; kt += 2) {
-    step(r1, kt);              // tile kt+1 lives in r1, tile kt+2 (in flight) in r0
-    step(r0, kt + 1);          // tile kt+2 lives in r0
-  }
-
-  // ---- epilogue: every wave stages its 64x64 tile through two private LDS strips (the operand
-  // images are dead after the loop's last barrier) and streams rows out as float4
-  float s = 0.f, q = 0.f;
-  const int mb = m0 + wm * 64, lb = l0 + wn * 64;
-  float* strip = reinterpret_cast<float*>(smem) + wave * (2 * 32 * SRF_EPI_PITCH);
-  srf_pw_epilogue_strip(a, acc00, acc01, strip, b, mb, lb, lane, s, q);
-  srf_pw_epilogue_strip(a, acc10, acc11, strip + 32 * SRF_EPI_PITCH, b, mb + 32, lb, lane, s, q);
-  __syncthreads();  // strips are re-used as reduction scratch below
-  // all LDS reads finished at the loop's last barrier: reuse the first bytes as reduction scratch
-  if (a.out_sums)
-    srf_block_stats_atomic<4>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
-                              reinterpret_cast<double*>(smem));
-}
+//
+// Variants that were built, measured on proj_1x1 (cfg 2) and removed again (git history has them):
+//   * 4 wavefronts x (2x2 MFMA tiles): 164 us vs 152 us -- too few co-resident waves to overlap the split (VALU)
+//     and MFMA phases (PMC: matrix pipe 21 % busy);
+//   * wave-specialised (4 loader + 4 MMA wavefronts per block): 165 us -- the loader side is the bottleneck;
+//   * activation prefetch 4 k-tiles ahead (separate register rings): no gain, spills with a prologue;
+//   * 256x128 tile at 1 block per CU with pre-packed weights and sched_group_barrier interleave: slower;
+//   * start-up stagger of every block of the one-tile-per-block kernel: slower (it only pays once per persistent
+//     block, see below).
 
 // ---------------------------------------------------------------------------------------------
-// 8-wavefront variant of the same 128x128x32 tile: each wave owns 32(M) x 64(time) (two 32x32 MFMA
-// tiles, 32 accumulators), 512 threads stage the tile (8 + 8 values per thread, full 128-B lines on
-// both operands).  Same 80 KB of LDS -> 2 blocks per CU, but 16 waves (4 per SIMD) instead of 8: the
-// PMC profile of the 4-wave kernel showed the waves serialising their own VALU (split/convert) and
-// MFMA phases with too few co-resident waves to overlap them (MFMA pipe 21 % busy); a 256x128 /
-// 1-block-per-CU variant with explicit instruction interleaving measured slower still.
+// One tile per block.
 // ---------------------------------------------------------------------------------------------
 // ABL (ablation, diagnostics only; results are wrong when != 0): 1 = no A loads, 2 = no B loads,
 // 4 = no MFMAs, 8 = no conversion / LDS stores
@@ -394,303 +238,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
   }
 }
 
-// 8-wave kernel with a deeper activation prefetch (see RA/RB below); used when Cin % 128 == 0.
-template <int PRO>
-__global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8d_kernel(PwArgs a, int nMt, int nLt, int total) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
-
-  const int v = srf_xcd_remap(blockIdx.x, total);
-  const int mt = v % nMt;
-  const int lt = (v / nMt) % nLt;
-  const long b = v / (nMt * nLt);
-  const int m0 = mt * X3_BM, l0 = lt * X3_BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves, 32 x 64 each
-
-  float mean = 0.f, rstd = 1.f, slope = 1.f;
-  if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
-  if (PRO == 2 || PRO == 3) slope = a.nrm.prelu[0];
-
-  const int Cin = a.Cin, L = a.L, Cout = a.Cout;
-  const int nk_ = Cin / X3_BK;   // even (host checks Cin % 64 == 0)
-  const float* xb = a.x + (size_t)b * Cin * L;
-
-  // A (weights [m][k]): thread -> row m = tid>>2, 8-k packet pk = tid&3 (2 float4 = 32 B; a wavefront
-  // covers 16 rows x 128 B = whole cache lines)
-  const int a_m = tid >> 2, a_pk = tid & 3;
-  const bool a_ok = (m0 + a_m) < Cout;
-  const float* a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_pk * 8;
-  const float a_msk = a_ok ? 1.f : 0.f;
-  const int a_lds = a_m * X3_PITCH + a_pk * 16;
-  // B (X_b [k][time]): thread -> time step n = tid&127, k-group kg = tid>>7 (wave-uniform), 8 k rows
-  const int b_n = tid & 127, b_kg = (wave >> 1) * 8;
-  const bool b_ok = (l0 + b_n) < L;
-  const float* b_src = xb + (size_t)b_kg * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
-  const int b_lds = b_n * X3_PITCH + b_kg * 2;
-
-  // A (weights, L2-resident) is prefetched 2 k-tiles ahead, B (activations, first touch comes from
-  // HBM) 4 k-tiles ahead: separate register rings (2 x 8 + 4 x 8 VGPRs)
-  struct RA {
-    float4 a[2];
-  };
-  struct RB {
-    float b[8];
-  };
-  RA ra0, ra1;
-  RB rb0, rb1, rb2, rb3;
-  auto gload_a = [&](RA& r, int k0) {
-    r.a[0] = *reinterpret_cast<const float4*>(a_src + k0);
-    r.a[1] = *reinterpret_cast<const float4*>(a_src + k0 + 4);
-  };
-  auto gload_b = [&](RB& r, int k0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r.b[j] = b_src[(size_t)(k0 + j) * L];
-  };
-  auto lds_store = [&](const RA& ra, const RB& rb, int stage, int k0) {
-    char* base = smem + stage * X3_STAGE;
-    const float va[8] = {ra.a[0].x * a_msk, ra.a[0].y * a_msk, ra.a[0].z * a_msk, ra.a[0].w * a_msk,
-                         ra.a[1].x * a_msk, ra.a[1].y * a_msk, ra.a[1].z * a_msk, ra.a[1].w * a_msk};
-    bf16x8 hi, lo;
-    srf_split8(va, hi, lo);
-    *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + a_lds) = hi;
-    *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + a_lds) = lo;
-    float vb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float x0 = rb.b[j];
-      if (PRO == 1 || PRO == 2) {
-        const int k = k0 + b_kg + j;
-        const float sc = a.nrm.gamma[k] * rstd;
-        x0 = fmaf(x0, sc, a.nrm.beta[k] - mean * sc);
-      }
-      if (PRO == 2 || PRO == 3) x0 = srf_prelu(x0, slope);
-      vb[j] = x0;
-    }
-    srf_split8(vb, hi, lo);
-    *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + b_lds) = hi;
-    *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + b_lds) = lo;
-  };
-
-  f32x16 acc0 = {0}, acc1 = {0};
-  const int frag = (lane & 31) * X3_PITCH + (lane >> 5) * 16;
-  const int a_row = (wm * 32) * X3_PITCH + frag;
-  const int b_row0 = (wn * 64) * X3_PITCH + frag, b_row1 = b_row0 + 32 * X3_PITCH;
-  auto mma_tile = [&](int stage) {
-    const char* base = smem + stage * X3_STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ko = ks * 32;
-      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row + ko);
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row + ko);
-      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row0 + ko);
-      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
-      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
-      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
-    }
-  };
-  auto step = [&](RA& na, RB& nb, int kt) {   // na/nb hold tile kt+1
-    if (kt + 1 < nk_) lds_store(na, nb, (kt + 1) & 1, (kt + 1) * X3_BK);
-    gload_a(na, min(kt + 3, nk_ - 1) * X3_BK);
-    gload_b(nb, min(kt + 5, nk_ - 1) * X3_BK);
-    mma_tile(kt & 1);
-    __syncthreads();
-  };
-
-  gload_a(ra0, 0);
-  gload_b(rb0, 0);
-  gload_a(ra1, X3_BK);
-  gload_b(rb1, X3_BK);
-  gload_b(rb2, min(2, nk_ - 1) * X3_BK);
-  gload_b(rb3, min(3, nk_ - 1) * X3_BK);
-  lds_store(ra0, rb0, 0, 0);
-  gload_a(ra0, min(2, nk_ - 1) * X3_BK);
-  gload_b(rb0, min(4, nk_ - 1) * X3_BK);
-  __syncthreads();
-  for (int kt = 0; kt < nk_; kt += 4) {   // host guarantees nk % 4 == 0
-    step(ra1, rb1, kt);
-    step(ra0, rb2, kt + 1);
-    step(ra1, rb3, kt + 2);
-    step(ra0, rb0, kt + 3);
-  }
-
-  float s = 0.f, q = 0.f;
-  float* strip = reinterpret_cast<float*>(smem) + wave * (32 * SRF_EPI_PITCH);
-  srf_pw_epilogue_strip(a, acc0, acc1, strip, b, m0 + wm * 32, l0 + wn * 64, lane, s, q);
-  __syncthreads();
-  if (a.out_sums)
-    srf_block_stats_atomic<8>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
-                              reinterpret_cast<double*>(smem));
-}
-
-// ---------------------------------------------------------------------------------------------
-// Wave-specialised variant (debug flag 4; measured 165 us vs 152 us for the symmetric 8-wave kernel on
-// the proj_1x1 shape -- kept for A/B): the ablation of the kernels above showed time ~ SUM of
-// {operand loads, split/convert + LDS stores, MFMAs, epilogue} -- the barrier-synchronised waves of a
-// block are always in the same phase, so the matrix pipe idles while they convert and vice versa.
-// Here a 512-thread block splits into 4 MMA wavefronts (64x64 accumulator tile each: only ds_read +
-// MFMA) and 4 LOADER wavefronts (global loads two k-tiles ahead, GlobLN/PReLU prologue, bf16 hi/lo
-// split, ds_write of the next stage): per k-tile the block costs max(convert, MFMA) instead of their
-// sum, and every SIMD always holds one wave of each kind per resident block.
-// ---------------------------------------------------------------------------------------------
-template <int PRO>
-__global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_ws_kernel(PwArgs a, int nMt, int nLt, int total) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB -> 2 blocks / CU
-
-  const int v = srf_xcd_remap(blockIdx.x, total);
-  const int mt = v % nMt;
-  const int lt = (v / nMt) % nLt;
-  const long b = v / (nMt * nLt);
-  const int m0 = mt * X3_BM, l0 = lt * X3_BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int Cin = a.Cin, L = a.L, Cout = a.Cout;
-  const int nk_ = Cin / X3_BK;   // even (host checks Cin % 64 == 0)
-
-  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-  const int wm = (wave >> 1) & 1, wn = wave & 1;   // MMA waves 0..3: 2 x 2, 64 x 64 each
-
-  if (wave >= 4) {
-    // =========================== LOADER wavefronts ===========================
-    float mean = 0.f, rstd = 1.f, slope = 1.f;
-    if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
-    if (PRO == 2 || PRO == 3) slope = a.nrm.prelu[0];
-    const int t = tid - 256;
-    const float* xb = a.x + (size_t)b * Cin * L;
-    // A (weights [m][k]): rows (t>>2) and (t>>2)+64, 8-k packet pk = t&3 -> whole 128-B lines per row
-    const int a_m = t >> 2, a_pk = t & 3;
-    const bool a_ok0 = (m0 + a_m) < Cout, a_ok1 = (m0 + a_m + 64) < Cout;
-    const float* a_src0 = a.w + (size_t)(a_ok0 ? (m0 + a_m) : 0) * Cin + a_pk * 8;
-    const float* a_src1 = a.w + (size_t)(a_ok1 ? (m0 + a_m + 64) : 0) * Cin + a_pk * 8;
-    const float a_msk0 = a_ok0 ? 1.f : 0.f, a_msk1 = a_ok1 ? 1.f : 0.f;
-    const int a_lds = a_m * X3_PITCH + a_pk * 16;
-    // B (X_b [k][time]): time step n = t&127, k-half kh = t>>7 (wave-uniform): 16 k rows x 1 time step
-    const int b_n = t & 127, b_kh = ((wave - 4) >> 1) * 16;
-    const bool b_ok = (l0 + b_n) < L;
-    const float* b_src = xb + (size_t)b_kh * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
-    const int b_lds = b_n * X3_PITCH + b_kh * 2;
-
-    struct Regs {
-      float4 a[4];
-      float b[16];
-    };
-    Regs r0, r1;
-    auto gload = [&](Regs& r, int k0) {
-      r.a[0] = *reinterpret_cast<const float4*>(a_src0 + k0);
-      r.a[1] = *reinterpret_cast<const float4*>(a_src0 + k0 + 4);
-      r.a[2] = *reinterpret_cast<const float4*>(a_src1 + k0);
-      r.a[3] = *reinterpret_cast<const float4*>(a_src1 + k0 + 4);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) r.b[j] = b_src[(size_t)(k0 + j) * L];
-    };
-    auto lds_store = [&](const Regs& r, int stage, int k0) {
-      char* base = smem + stage * X3_STAGE;
-      bf16x8 hi, lo;
-      {
-        const float va[8] = {r.a[0].x * a_msk0, r.a[0].y * a_msk0, r.a[0].z * a_msk0, r.a[0].w * a_msk0,
-                             r.a[1].x * a_msk0, r.a[1].y * a_msk0, r.a[1].z * a_msk0, r.a[1].w * a_msk0};
-        srf_split8(va, hi, lo);
-        *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + a_lds) = hi;
-        *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + a_lds) = lo;
-      }
-      {
-        const float va[8] = {r.a[2].x * a_msk1, r.a[2].y * a_msk1, r.a[2].z * a_msk1, r.a[2].w * a_msk1,
-                             r.a[3].x * a_msk1, r.a[3].y * a_msk1, r.a[3].z * a_msk1, r.a[3].w * a_msk1};
-        srf_split8(va, hi, lo);
-        *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + 64 * X3_PITCH + a_lds) = hi;
-        *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + 64 * X3_PITCH + a_lds) = lo;
-      }
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        float vb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float x0 = r.b[8 * p + j];
-          if (PRO == 1 || PRO == 2) {
-            const int k = k0 + b_kh + 8 * p + j;
-            const float sc = a.nrm.gamma[k] * rstd;
-            x0 = fmaf(x0, sc, a.nrm.beta[k] - mean * sc);
-          }
-          if (PRO == 2 || PRO == 3) x0 = srf_prelu(x0, slope);
-          vb[j] = x0;
-        }
-        srf_split8(vb, hi, lo);
-        *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + b_lds + 16 * p) = hi;
-        *reinterpret_cast<bf16x8*>(base + 3 * X3_IMG + b_lds + 16 * p) = lo;
-      }
-    };
-    auto step = [&](Regs& nx, int kt) {
-      if (kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
-      gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
-      __syncthreads();
-    };
-    gload(r0, 0);
-    gload(r1, X3_BK);
-    lds_store(r0, 0, 0);
-    gload(r0, min(2, nk_ - 1) * X3_BK);
-    __syncthreads();
-    for (int kt = 0; kt < nk_; kt += 2) {
-      step(r1, kt);
-      step(r0, kt + 1);
-    }
-    asm volatile("" ::"v"(r0.b[0]), "v"(r1.b[0]));   // surplus clamped prefetches stay well-defined
-  } else {
-    // ============================= MMA wavefronts =============================
-    const int frag = (lane & 31) * X3_PITCH + (lane >> 5) * 16;
-    const int a_row0 = (wm * 64) * X3_PITCH + frag, a_row1 = a_row0 + 32 * X3_PITCH;
-    const int b_row0 = (wn * 64) * X3_PITCH + frag, b_row1 = b_row0 + 32 * X3_PITCH;
-    __syncthreads();   // stage 0 ready
-    for (int kt = 0; kt < nk_; ++kt) {
-      const char* base = smem + (kt & 1) * X3_STAGE;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int ko = ks * 32;
-        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row0 + ko);
-        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row1 + ko);
-        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row0 + ko);
-        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row1 + ko);
-        const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row0 + ko);
-        const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
-        const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
-        const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
-      }
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue: MMA waves stream their tiles out through private LDS strips (operand stages dead)
-  float s = 0.f, q = 0.f;
-  if (wave < 4) {
-    const int mb = m0 + wm * 64, lb = l0 + wn * 64;
-    float* strip = reinterpret_cast<float*>(smem) + wave * (2 * 32 * SRF_EPI_PITCH);
-    srf_pw_epilogue_strip(a, acc00, acc01, strip, b, mb, lb, lane, s, q);
-    srf_pw_epilogue_strip(a, acc10, acc11, strip + 32 * SRF_EPI_PITCH, b, mb + 32, lb, lane, s, q);
-  }
-  __syncthreads();
-  if (a.out_sums)
-    srf_block_stats_atomic<8>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
-                              reinterpret_cast<double*>(smem));
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // Persistent 8-wave kernel.  In-kernel timeline of the kernel above (tools/gemm_timeline.py, proj_1x1):
 // a block spends ~14 % of its life in the prologue (first operands from HBM), ~60 % in the k-loop and
@@ -763,7 +310,7 @@ __device__ __forceinline__ void srf_pw_epilogue_half(const PwArgs& a, const f32x
 }
 
 template <int PRO>
-__global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int nMt, int nLt, int total) {
+__global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int nMt, int nLt, int total, int nhalf) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -772,7 +319,14 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   const int Cin = a.Cin, L = a.L, Cout = a.Cout;
   const int nk_ = Cin / X3_BK;   // even (host checks Cin % 64 == 0)
   const int nblk = gridDim.x;
-  const int ntile = (total - (int)blockIdx.x + nblk - 1) / nblk;   // >= 1 (host: grid <= total)
+  // Tail: total = rounds * nblk + R tiles.  With 0 < R <= nblk/2 the leftover round would run R blocks against
+  // nblk slots (res_conv: 1600 tiles on 512 slots = 3 rounds + 64 tiles = the cost of 4); instead the R leftover
+  // tiles are dealt as nhalf = 2R half tiles (128 x 64 columns) to the first 2R blocks: twice the blocks, half
+  // the MFMA work each.  A half tile still stages the whole 128-column operand tile (simplest; its loads and
+  // split are wasted for the other half) but every wavefront computes one 32x32 accumulator instead of two.
+  const int rounds = nhalf ? total / nblk : 0;
+  const int ntile = nhalf ? rounds + ((int)blockIdx.x < nhalf ? 1 : 0)
+                          : (total - (int)blockIdx.x + nblk - 1) / nblk;   // >= 1 (host: grid <= total)
   const int nsteps = ntile * nk_;
   const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
   // experiment (epi_mask bits 8..): delay every other block once, by roughly half a tile, so that the
@@ -785,8 +339,15 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
 
   // tile i of this block -> virtual tile id (XCD-contiguous runs, see srf_xcd_remap; nblk % 8 == 0 keeps
   // every tile of a block on the block's own XCD)
-  auto tile_of = [&](int i, int& m0, int& l0, long& b) {
-    const int v = srf_xcd_remap(blockIdx.x + i * nblk, total);
+  // half: -1 = full tile, 0 / 1 = the half tile covering columns [64 half, 64 half + 64) of its parent tile
+  auto tile_of = [&](int i, int& m0, int& l0, long& b, int& half) {
+    int q = blockIdx.x + i * nblk;
+    half = -1;
+    if (nhalf && i == rounds) {
+      q = rounds * nblk + ((int)blockIdx.x >> 1);
+      half = blockIdx.x & 1;
+    }
+    const int v = srf_xcd_remap(q, total);
     m0 = (v % nMt) * X3_BM;
     l0 = ((v / nMt) % nLt) * X3_BN;
     b = v / (nMt * nLt);
@@ -803,9 +364,9 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   const float* a_src;
   const float* b_src;
   auto ld_tile = [&](int i) {
-    int m0, l0;
+    int m0, l0, hf;
     long b;
-    tile_of(i, m0, l0, b);
+    tile_of(i, m0, l0, b, hf);
     const bool a_ok = (m0 + a_m) < Cout;
     a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_pk * 8;
     const bool b_ok = (l0 + b_n) < L;
@@ -832,9 +393,9 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   int cv_i = 0, cv_k = 0;
   float a_msk = 0.f, mean = 0.f, rstd = 1.f;
   auto cv_tile = [&](int i) {
-    int m0, l0;
+    int m0, l0, hf;
     long b;
-    tile_of(i, m0, l0, b);
+    tile_of(i, m0, l0, b, hf);
     a_msk = (m0 + a_m) < Cout ? 1.f : 0.f;
     if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
   };
@@ -872,24 +433,29 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   f32x16 acc0 = {0}, acc1 = {0};
   const int frag = (lane & 31) * X3_PITCH + (lane >> 5) * 16;
   const int a_row = (wm * 32) * X3_PITCH + frag;
-  const int b_row0 = (wn * 64) * X3_PITCH + frag, b_row1 = b_row0 + 32 * X3_PITCH;
+  const int b_row0 = (wn * 64) * X3_PITCH + frag;
+  int cur_half = -1;   // mode of the tile whose k-loop is running (wave-uniform)
+  int br0 = b_row0;    // B fragment rows of the first accumulator for the running tile
   auto mma_tile = [&](int stage) {
     const char* base = smem + stage * X3_STAGE;
+    const bool full = cur_half < 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ko = ks * 32;
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + 0 * X3_IMG + a_row + ko);
       const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + 1 * X3_IMG + a_row + ko);
-      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row0 + ko);
-      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
-      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
-      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
+      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + br0 + ko);
+      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + br0 + ko);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
+      if (full) {
+        const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + br0 + 32 * X3_PITCH + ko);
+        const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + br0 + 32 * X3_PITCH + ko);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
+      }
     }
   };
   auto step = [&](Regs& nx, int g) {
@@ -908,6 +474,8 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   float* strip = reinterpret_cast<float*>(smem + X3_STAGE) + wave * (32 * SRF_EPI_PITCH_H);   // stage 1
   int g = 0;
   for (int i = 0; i < ntile; ++i) {
+    cur_half = (nhalf && i == rounds) ? (int)(blockIdx.x & 1) : -1;
+    br0 = cur_half < 0 ? b_row0 : (cur_half * 64 + wn * 32) * X3_PITCH + frag;
     for (int kt = 0; kt < nk_; kt += 2) {
       step(r1, g);
       step(r0, g + 1);
@@ -915,16 +483,20 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
     }
     // the tile's last k-tile sat in stage 1, which every wave has finished reading (barrier above);
     // stage 0 already holds the next tile's first k-tile
-    int m0, l0;
+    int m0, l0, hf;
     long b;
-    const int v = tile_of(i, m0, l0, b);
+    const int v = tile_of(i, m0, l0, b, hf);
     float s = 0.f, q = 0.f;
-    srf_pw_epilogue_half(a, acc0, strip, b, m0 + wm * 32, l0 + wn * 64, lane, s, q);
-    srf_pw_epilogue_half(a, acc1, strip, b, m0 + wm * 32, l0 + wn * 64 + 32, lane, s, q);
+    if (cur_half < 0) {
+      srf_pw_epilogue_half(a, acc0, strip, b, m0 + wm * 32, l0 + wn * 64, lane, s, q);
+      srf_pw_epilogue_half(a, acc1, strip, b, m0 + wm * 32, l0 + wn * 64 + 32, lane, s, q);
+    } else {
+      srf_pw_epilogue_half(a, acc0, strip, b, m0 + wm * 32, l0 + cur_half * 64 + wn * 32, lane, s, q);
+    }
     if (a.out_sums) {
       const double ds = srf_wave_sum((double)s), dq = srf_wave_sum((double)q);
       if (lane == 0) {
-        double* dst = srf_stat_slot(a.out_sums, b, (long)v * 8 + wave);
+        double* dst = srf_stat_slot(a.out_sums, b, (long)v * 16 + wave + (cur_half > 0 ? 8 : 0));
         atomicAdd(dst, ds);
         atomicAdd(dst + 1, dq);
       }
@@ -939,18 +511,7 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
   const int nMt = (a.Cout + X3_BM - 1) / X3_BM, nLt = (a.L + X3_BN - 1) / X3_BN;
   const long total = (long)a.Bt * nMt * nLt;
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
-  if ((srf_debug_flags() & 4) != 0) {   // flag 4: wave-specialised variant (measured no faster: the loader side is the bottleneck)
-    dim3 gridw((unsigned)total), blockw(512);
-    switch (pro) {
-      case 0: hipLaunchKernelGGL(srf_pw_bf16x3_ws_kernel<0>, gridw, blockw, 0, st, a, nMt, nLt, (int)total); break;
-      case 1: hipLaunchKernelGGL(srf_pw_bf16x3_ws_kernel<1>, gridw, blockw, 0, st, a, nMt, nLt, (int)total); break;
-      case 2: hipLaunchKernelGGL(srf_pw_bf16x3_ws_kernel<2>, gridw, blockw, 0, st, a, nMt, nLt, (int)total); break;
-      default: hipLaunchKernelGGL(srf_pw_bf16x3_ws_kernel<3>, gridw, blockw, 0, st, a, nMt, nLt, (int)total); break;
-    }
-    SRF_CHECK_LAUNCH("pw_conv_bf16x3_ws", st);
-    return SRF_OK;
-  }
-  if ((srf_debug_flags() & 2) == 0) {   // default: 8-wave variant (flag 2: 4-wave variant)
+  {
     dim3 grid8((unsigned)total), block8(512);
     const int abl = (srf_debug_flags() >> 16) & 15;   // diagnostics: ablated pipelines (PRO 0 only)
     // Persistent blocks (2 per CU) whenever every block gets >= 3 tiles; fewer tiles and the idle slots
@@ -972,11 +533,14 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
       // bit 12 selects 2 phases)
       const int su = (srf_debug_flags() >> 20) & 15;
       ap.epi_mask |= ((su == 15 ? 0 : (su ? su : 1)) << 8) | ((((srf_debug_flags() >> 12) & 1) ^ 1) << 12);
+      // leftover tiles of the last round as half tiles when they fill at most half of it (debug flag 256: off)
+      const long rem = total % nb;
+      const int nhalf = (rem > 0 && 2 * rem <= nb && !(srf_debug_flags() & 256)) ? (int)(2 * rem) : 0;
       switch (pro) {
-        case 0: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<0>, gridp, block8, 0, st, ap, nMt, nLt, (int)total); break;
-        case 1: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<1>, gridp, block8, 0, st, ap, nMt, nLt, (int)total); break;
-        case 2: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<2>, gridp, block8, 0, st, ap, nMt, nLt, (int)total); break;
-        default: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<3>, gridp, block8, 0, st, ap, nMt, nLt, (int)total); break;
+        case 0: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<0>, gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
+        case 1: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<1>, gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
+        case 2: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<2>, gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
+        default: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<3>, gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
       }
       SRF_CHECK_LAUNCH("pw_conv_bf16x3_p8", st);
       return SRF_OK;
@@ -1001,16 +565,6 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
       SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8_ablated", st);
       return SRF_OK;
     }
-    if ((a.Cin % 128) == 0 && (srf_debug_flags() & 1024)) {   // deeper activation prefetch: measured no gain
-      switch (pro) {
-        case 0: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<0>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 1: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<1>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 2: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<2>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        default: hipLaunchKernelGGL(srf_pw_bf16x3_w8d_kernel<3>, grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-      }
-      SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8", st);
-      return SRF_OK;
-    }
     PwArgs aw = a;
     aw.epi_mask |= (((srf_debug_flags() >> 20) & 15) << 8) | (((srf_debug_flags() >> 12) & 1) << 12);
     switch (pro) {
@@ -1022,13 +576,4 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
     SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8", st);
     return SRF_OK;
   }
-  dim3 grid((unsigned)total), block(256);
-  switch (pro) {
-    case 0: hipLaunchKernelGGL(srf_pw_bf16x3_kernel<0>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
-    case 1: hipLaunchKernelGGL(srf_pw_bf16x3_kernel<1>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
-    case 2: hipLaunchKernelGGL(srf_pw_bf16x3_kernel<2>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
-    default: hipLaunchKernelGGL(srf_pw_bf16x3_kernel<3>, grid, block, 0, st, a, nMt, nLt, (int)total); break;
-  }
-  SRF_CHECK_LAUNCH("pw_conv_bf16x3", st);
-  return SRF_OK;
 }

@@ -18,7 +18,7 @@ SHAPES = {  # name: (Bt, Cin, Cout, L, prologue, residual, stats, mask)
 
 
 def main():
-    modes = sys.argv[1:] or ["0u", "2"]   # 0u 8-wave split-bf16 (default), 0w wave-specialised, 0v 4-wave, 2 exact fp32 MFMA
+    modes = sys.argv[1:] or ["0u", "0p", "2"]   # 0u split-bf16 default (persistent), 0p one tile per block, 2 exact fp32 MFMA
     out = {}
     only = os.environ.get("GEMM_SHAPES")
     iters = int(os.environ.get("GEMM_ITERS", "20"))
@@ -43,13 +43,13 @@ def main():
         ref = None
         for mode in modes:
             ops.set_kernel_mode(int(mode[0]))
-            ops.set_debug_flags({"n": 1, "v": 2, "w": 4, "e": 10 << 16, "p": 2048, "q": 2048 | (2 << 20), "r": 2048 | (4 << 20), "s": 2048 | (6 << 20), "t": 2048 | 4096 | (1 << 20), "x": 2048 | 4096 | (2 << 20), "y": 2048 | 4096 | (3 << 20), "z": 2048 | 4096 | (4 << 20), "a": 4096 | (1 << 20), "b": 4096 | (2 << 20), "c": 4096 | (4 << 20), "d": (2 << 20), "f": (4 << 20)}.get(mode[-1], 0))
+            ops.set_debug_flags({"p": 2048, "h": 256, "e": 10 << 16}.get(mode[-1], 0))   # p: one tile per block, h: no half-tile tail, e: no epilogue stores
             kw["packed"] = ops.pack_pw_weight(w) if mode in ("0", "0n") else torch.zeros(0, device=DEV)
             if kw["packed"] is None or kw["packed"].numel() == 0:
                 kw["packed"] = None
                 if mode in ("0", "0n"):
                     continue
-            if mode in ("0u", "0v", "0w", "0e", "0p", "0q", "0r", "0s", "0t", "0x", "0y", "0z", "0a", "0b", "0c", "0d", "0f"):
+            if mode[0] == "0" and len(mode) == 2:
                 import sudo_rm_rf_amd.ops as _o
                 _pack = _o.pack_pw_weight
                 _o.pack_pw_weight = lambda w_: None
@@ -69,7 +69,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / n
             tf = 2.0 * Bt * Cin * Cout * L / (us * 1e-6) / 1e12
-            if mode in ("0u", "0v", "0w", "0e", "0p", "0q", "0r", "0s", "0t", "0x", "0y", "0z", "0a", "0b", "0c", "0d", "0f"):
+            if mode[0] == "0" and len(mode) == 2:
                 _o.pack_pw_weight = _pack
             out[f"{name}/mode{mode}"] = {"us": round(us, 1), "TFLOPs_fp32_equiv": round(tf, 1),
                                          "max_abs_diff_vs_first_mode": err}
