@@ -10,6 +10,9 @@ cp $R/bench.json profiles/${T}_cfg2_bs32_bench.json
 [ -s $R/bench_cfg3_groupcomm_u8.json ] && cp $R/bench_cfg3_groupcomm_u8.json profiles/${T}_cfg3_groupcomm_bs32_bench.json
 [ -s $R/bench_cfg4_improved_u36_n2048.json ] && cp $R/bench_cfg4_improved_u36_n2048.json profiles/${T}_cfg4_u36_n2048_bs32_bench.json
 [ -s $R/bench_cfg5_improved_u36_n4096.json ] && cp $R/bench_cfg5_improved_u36_n4096.json profiles/${T}_cfg5_u36_n4096_8s16k_bs16_bench.json
+for w in cfg2_improved_u16 cfg4_improved_u36_n2048; do
+  [ -s $R/train_$w.json ] && cp $R/train_$w.json profiles/${T}_${w}_train_step_bs32.json
+done
 f=$(find $R/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && grep -v "at::native" "$f" > profiles/${T}_cfg2_bs32_rocprofv3_kernel_stats.csv
 [ -d $R/pmc1 ] && python tools/pmc_summary.py $R profiles/${T}_cfg2_bs32_pmc_hbm_traffic.csv > /dev/null

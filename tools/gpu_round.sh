@@ -30,6 +30,14 @@ for w in ${EXTRA_WORKLOADS:-}; do
   timeout 600 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
   cat "$OUT/bench_$w.json"; tail -2 "$OUT/bench_$w.err"
 done
+for w in ${TRAIN_WORKLOADS:-}; do
+  timeout 600 python tools/train_bench.py $w 32 5 > "$OUT/train_$w.json" 2> "$OUT/train_$w.err"
+  python - "$OUT/train_$w.json" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print({k: v for k, v in d.items() if k != "kernels_ms"})
+PY
+done
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   echo "== rocprofv3 kernel trace"
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- \
