@@ -23,7 +23,14 @@ void srf_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-int srf_kernel_mode() { return g_kernel_mode; }
+// per-thread override (srf_forward_train runs its GEMMs in exact fp32 by default, see srf_train.hip)
+static thread_local int g_kernel_mode_override = -1;
+int srf_kernel_mode() { return g_kernel_mode_override >= 0 ? g_kernel_mode_override : g_kernel_mode; }
+int srf_kernel_mode_override(int mode) {
+  const int prev = g_kernel_mode_override;
+  g_kernel_mode_override = mode;
+  return prev;
+}
 static int g_debug_flags = 0;
 int srf_debug_flags() { return g_debug_flags; }
 extern "C" void srf_set_debug_flags(int f) { g_debug_flags = f; }

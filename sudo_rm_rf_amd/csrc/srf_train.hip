@@ -145,8 +145,27 @@ static int train_check(const srf_plan* p, const char* who) {
 extern "C" size_t srf_train_saved_bytes(const srf_plan* p) { return p ? train_layout(p).total : 0; }
 extern "C" size_t srf_train_scratch_bytes(const srf_plan* p) { return p ? scratch_layout(p).total : 0; }
 
+static int forward_train_impl(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
+                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
+// The training forward runs its 1x1 convolutions on the EXACT fp32 MFMA path unless debug flag 1<<28 is set.
+// The split-bf16 GEMMs are accurate to ~2^-17 of sum|terms| per output -- far inside the 1e-4 forward bar -- but
+// the gradients of the first blocks' parameters are ill-conditioned with respect to exactly that rounding:
+// injecting 2^-17 noise into the bottleneck GEMM's output alone moves d loss / d sm.0.proj_1x1.conv.weight by 5 %
+// in an fp64 autograd experiment (2^-24 noise: 3e-6), and the HIP step reproduces both numbers against the
+// reference's own gradients (tests/golden/train_*).  The backward GEMMs (data / weight gradients) stay
+// split-bf16: with an exact forward every parameter gradient is within 2e-5 of the reference's.
 extern "C" int srf_forward_train(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
                                  void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  const bool exact = srf_kernel_mode() == 0 && !(srf_debug_flags() & (1 << 28));
+  const int prev = exact ? srf_kernel_mode_override(2) : -1;
+  const int rc = forward_train_impl(p, P, num_params, wav, out, saved, saved_bytes, scratch, scratch_bytes, stream);
+  if (exact) srf_kernel_mode_override(prev);
+  return rc;
+}
+
+static int forward_train_impl(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
+                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
   SRF_CHECK_ARG(p && P && wav && out && saved && scratch, "srf_forward_train: null pointer");
   SRF_CHECK_ARG(num_params == p->n_params, "srf_forward_train: expected %d parameter tensors, got %d", p->n_params,
                 num_params);

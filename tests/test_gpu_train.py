@@ -128,3 +128,51 @@ def test_online_remix_matches_the_runner_lines(B, S, T):
     mix, src = augment.online_remix(clean.to(DEV))
     assert (mix.cpu().double() - want_mix).abs().max() <= 2e-5
     assert (src.cpu().double() - want_src).abs().max() <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["train_tiny_improved", "train_improved_mfma", "train_tiny_groupcomm"])
+def test_training_step_matches_reference_golden(name):
+    """The runner's step (model.train(); loss = clamp(PIT-SI-SDR(model(mix)[, mixture consistency], clean));
+    backward) through the reference's import paths against gradients the reference itself produced
+    (tools/make_golden_train.py)."""
+    import sudo_rm_rf.dnn.experiments.utils.mixture_consistency as mixture_consistency
+    import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib
+    from test_oracle_golden import check_grads_against_golden, train_case
+    cfg, sd, mix, tgt, z = train_case(name)
+    model = build(cfg, sd).train()
+    loss_fn = sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_mtx')
+    rec = model(mix.to(DEV))
+    if cfg.variant == "groupcomm":
+        rec = mixture_consistency.apply(rec, mix.to(DEV))
+    l = torch.clamp(loss_fn(rec, tgt.to(DEV)), min=-30., max=+30.)
+    l.backward()
+    assert abs(l.item() - float(z["loss"])) <= 1e-3
+    # the training forward runs its GEMMs in exact fp32 (srf_train.hip): every gradient within 2e-4 of the
+    # reference's own fp32 backward (measured <= 7e-6 on the MFMA-shaped case)
+    check_grads_against_golden([(k, p.grad.cpu().numpy()) for k, p in model.state_dict(keep_vars=True).items()],
+                               z, 2e-4)
+
+
+def test_fast_training_forward_flag():
+    """Debug flag 1<<28 keeps the split-bf16 GEMMs in the training forward: still a valid step, but the
+    ill-conditioned early-layer gradients move by a few percent (documented in srf_train.hip)."""
+    import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib
+    from sudo_rm_rf_amd import ops
+    from test_oracle_golden import train_case
+    cfg, sd, mix, tgt, z = train_case("train_improved_mfma")
+    model = build(cfg, sd).train()
+    loss_fn = sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_mtx')
+    ops.set_debug_flags(1 << 28)
+    try:
+        l = torch.clamp(loss_fn(model(mix.to(DEV)), tgt.to(DEV)), min=-30., max=+30.)
+        l.backward()
+    finally:
+        ops.set_debug_flags(0)
+    assert abs(l.item() - float(z["loss"])) <= 1e-3
+    num = den = 0.0
+    for k, p in model.state_dict(keep_vars=True).items():
+        g = p.grad.cpu().numpy().astype(np.float64)
+        smp = g.reshape(-1)[::int(z["n:" + k][0])][:z["g:" + k].shape[0]]
+        num += ((smp - z["g:" + k]) ** 2).sum()
+        den += (z["g:" + k].astype(np.float64) ** 2).sum()
+    assert (num / den) ** 0.5 <= 2e-2          # whole-gradient relative error (measured 3e-3)

@@ -104,3 +104,58 @@ def test_loss_oracle_matches_reference_golden(name):
     assert np.abs(grad[..., :k] - z["grad_prefix"]).max() <= 2e-5 * scale
     assert np.abs(grad.sum(-1) - z["grad_sum"]).max() <= 1e-5
     assert np.abs((grad ** 2).sum(-1) - z["grad_sqsum"]).max() <= 1e-4 * max(z["grad_sqsum"].max(), 1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# one training step's gradients: oracle forward + oracle loss under torch autograd (fp64) vs the reference's own
+# fp32 backward (tools/make_golden_train.py)
+# ---------------------------------------------------------------------------------------------
+def _train_manifest():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "TRAIN_MANIFEST.json")))
+
+
+def train_case(name):
+    """(cfg, state dict (numpy), mixture, targets, golden npz) of a training fixture."""
+    import os
+    from oracle import loss_oracle
+    from oracle.schema import ModelConfig
+    from oracle.weights import make_state_dict
+    c = _train_manifest()[name]
+    cfg = ModelConfig(**c["config"])
+    sd = make_state_dict(cfg, c["weight_seed"])
+    _, tgt = loss_oracle.make_loss_case(c["batch"], cfg.num_sources, c["T"], c["data_seed"], 5.0, "random")
+    tgt = torch.from_numpy(tgt)
+    mix = tgt.sum(1, keepdim=True)
+    mix = (mix - mix.mean(-1, keepdim=True)) / (mix.std(-1, keepdim=True) + 1e-8)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    return cfg, sd, mix, tgt, z
+
+
+def check_grads_against_golden(named_grads, z, tol):
+    worst = ("", 0.0)
+    for k, g in named_grads:
+        g = np.asarray(g, dtype=np.float64)
+        step, gmax, gsum, gsq = z["n:" + k]
+        smp = g.reshape(-1)[::int(step)][:z["g:" + k].shape[0]]
+        scale = max(gmax, 1e-12)
+        rel = np.abs(smp - z["g:" + k]).max() / scale
+        rel = max(rel, abs(np.sqrt((g ** 2).sum()) - np.sqrt(gsq)) / max(np.sqrt(gsq), 1e-12))
+        if rel > worst[1]:
+            worst = (k, float(rel))
+    assert worst[1] <= tol, worst
+
+
+@pytest.mark.parametrize("name", sorted(_train_manifest()))
+def test_training_gradients_oracle_matches_reference_golden(name):
+    from oracle import loss_oracle, torch_oracle
+    cfg, sd, mix, tgt, z = train_case(name)
+    sd64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd.items()}
+    rec = torch_oracle.forward(cfg, sd64, mix.double())
+    if cfg.variant == "groupcomm":
+        rec = rec + (mix.double() - rec.sum(1, keepdim=True)) / rec.shape[1]     # mixture_consistency.py:14-36
+    l, _, _, _ = loss_oracle.pit_sisdr_loss(rec, tgt.double())
+    l.backward()
+    assert abs(float(l.detach()) - float(z["loss"])) <= 1e-3
+    check_grads_against_golden([(k, v.grad.numpy()) for k, v in sd64.items()], z, 5e-3)
