@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--kernel-mode", type=int, default=0,
                     help="0 fast (split-bf16x3 MFMA GEMMs), 1 generic kernels only, 2 fast with exact-fp32 MFMA GEMMs")
     ap.add_argument("--debug-flags", type=int, default=0, help="library debug flags (A/B of kernel variants)")
+    ap.add_argument("--train", action="store_true",
+                    help="time one TRAINING step (forward, PIT-SI-SDR, backward, gradient all-reduce, clip, Adam -- "
+                         "run_improved_sudormrf.py:146-177) instead of the inference forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -148,6 +151,62 @@ def cpu_baseline_subprocess(args):
         return {"value": None, "kind": "port", "error": "cpu baseline exceeded %.0f s" % args.cpu_timeout}
 
 
+def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
+    """SURVEY.md §8 cfg 4 style measurement: the reference runner's loop body on `batch` examples per GPU, gradients
+    all-reduced over RCCL when world > 1 (replaces DataParallel), weak scaling.  One JSON line on rank 0."""
+    import torch
+    import torch.distributed as dist
+    import sudo_rm_rf.dnn.experiments.utils.mixture_consistency as mixture_consistency
+    import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib
+    from sudo_rm_rf_amd import distributed as D
+    model = cls(**kw).to(dev).train()
+    loss_fn = sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_mtx')
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    clean = torch.randn(batch, kw["num_sources"], T, generator=g).to(dev)
+    mix = clean.sum(1, keepdim=True)
+    mix = (mix - mix.mean(-1, keepdim=True)) / (mix.std(-1, keepdim=True) + 1e-9)
+
+    def step():
+        opt.zero_grad()
+        rec = model(mix)
+        if variant == "groupcomm":
+            rec = mixture_consistency.apply(rec, mix)
+        l = torch.clamp(loss_fn(rec, clean), min=-30., max=+30.)
+        l.backward()
+        D.allreduce_gradients(model.parameters())
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        return l
+
+    for _ in range(args.warmup):
+        l = step()
+    D.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        l = step()
+    torch.cuda.synchronize(dev)
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        plan = model._engine().last_plan
+        saved, scratch = plan.train_sizes()
+        print(json.dumps({
+            "metric": "trained-seconds/sec (training step: forward, PIT-SI-SDR, backward, all-reduce, clip, Adam), "
+                      + args.workload,
+            "value": world * batch * (T / fs) * args.steps / dt, "unit": "trained-seconds/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (forward GEMMs exact fp32 MFMA; backward GEMMs split-bf16 x3, fp32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": "%s training step, batch %d per GPU, T=%d" % (args.workload, batch, T),
+                       "global_batch": batch * world, "parallelism": "data-parallel x%d, one gradient all-reduce" % world},
+            "loss": float(l.detach()), "saved_activations_GB": saved / 2 ** 30, "scratch_GB": scratch / 2 ** 30,
+            "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -177,6 +236,8 @@ def main():
     batch = args.batch or def_batch
     torch.manual_seed(0)
     cls = improved_sudormrf.SuDORMRF if variant == "improved" else sudormrf_gc_v2.GroupCommSudoRmRf
+    if args.train:
+        return train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev)
     model = cls(**kw).to(dev).eval()
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)           # a different shard per rank
     wav = torch.randn(batch, 1, T, generator=g)
