@@ -45,7 +45,10 @@ __device__ __forceinline__ void srf_split8(const float (&v)[8], bf16x8& hi, bf16
 //   * activation prefetch 4 k-tiles ahead (separate register rings): no gain, spills with a prologue;
 //   * 256x128 tile at 1 block per CU with pre-packed weights and sched_group_barrier interleave: slower;
 //   * start-up stagger of every block of the one-tile-per-block kernel: slower (it only pays once per persistent
-//     block, see below).
+//     block, see below);
+//   * the activation tile as 2 coalesced dwordx4 loads per thread instead of 8 dword loads (what a [k][time] LDS
+//     image read back with ds_read_b64_tr_b16 would issue; tools/probes/tr_probe.hip documents that instruction):
+//     timing-only experiment inside the forward, 132 vs 137 us -- the VMEM instruction count is not the limiter.
 
 // ---------------------------------------------------------------------------------------------
 // One tile per block.
