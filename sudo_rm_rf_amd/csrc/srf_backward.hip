@@ -82,27 +82,48 @@ __global__ __launch_bounds__(256) void srf_gln_bwd_reduce_kernel(GlnBwdArgs a) {
   }
 }
 
-// per channel: dgamma[c] += sum_b rowpart[b][c][1], dbeta[c] += sum_b rowpart[b][c][0]; slope: one atomic per block
+// Sums of the per-row partials over the batch.  Block = 32 channels x 8 group slices over a chunk of 64 groups
+// (GroupComm folds 512 groups onto 16 channels: one thread per channel walking all groups took 130 us); results are
+// atomically added to the parameter gradients.
+// GlobLN: rowpart[.][0] -> dbeta, [1] -> dgamma, [2] -> slope (all channels into one scalar)
 __global__ __launch_bounds__(256) void srf_gln_bwd_params_kernel(const float* __restrict__ rowpart, int groups, int C,
                                                                  float* dgamma, float* dbeta, float* dslope) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  double sg = 0.0, sb = 0.0, ss = 0.0;
+  __shared__ float red[8][32][3];
+  const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int g0 = blockIdx.y * 64, g1 = min(g0 + 64, groups);
+  float sb = 0.f, sg = 0.f, ss = 0.f;
   if (c < C) {
-    for (int g = 0; g < groups; ++g) {
+    for (int g = g0 + slice; g < g1; g += 8) {
       const float* rp = rowpart + ((long)g * C + c) * 4;
-      sb += (double)rp[0];
-      sg += (double)rp[1];
-      ss += (double)rp[2];
+      sb += rp[0];
+      sg += rp[1];
+      ss += rp[2];
     }
-    if (dgamma) dgamma[c] += (float)sg;
-    if (dbeta) dbeta[c] += (float)sb;
   }
-  if (dslope) {
-    __shared__ double red[4];
-    ss = srf_wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dslope, (float)((red[0] + red[1]) + (red[2] + red[3])));
+  red[slice][cl][0] = sb;
+  red[slice][cl][1] = sg;
+  red[slice][cl][2] = ss;
+  __syncthreads();
+  if (slice == 0) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      t0 += red[sidx][cl][0];
+      t1 += red[sidx][cl][1];
+      t2 += red[sidx][cl][2];
+    }
+    if (c < C) {
+      if (dbeta) atomicAdd(dbeta + c, t0);
+      if (dgamma) atomicAdd(dgamma + c, t1);
+    }
+    if (dslope) {
+      // the 32 channels of this block -> one atomic (lanes 0..31 of wavefront 0; lanes 32..63 hold slice 1: excluded)
+      t2 = c < C ? t2 : 0.f;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) t2 += __shfl_xor(t2, o, 64);
+      if (cl == 0 && t2 != 0.f) atomicAdd(dslope, t2);
+    }
   }
 }
 
@@ -170,8 +191,8 @@ extern "C" int srf_gln_bwd(const float* gout, const float* gout2, const float* x
   hipLaunchKernelGGL(srf_gln_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, a);
   SRF_CHECK_LAUNCH("gln_bwd_reduce", st);
   if (dgamma || dbeta || (dslope && norm->prelu)) {
-    hipLaunchKernelGGL(srf_gln_bwd_params_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, a.rowpart, groups,
-                       C, dgamma, dbeta, norm->prelu ? dslope : nullptr);
+    hipLaunchKernelGGL(srf_gln_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
+                       dim3(256), 0, st, a.rowpart, groups, C, dgamma, dbeta, norm->prelu ? dslope : nullptr);
     SRF_CHECK_LAUNCH("gln_bwd_params", st);
   }
   hipLaunchKernelGGL(srf_gln_bwd_apply_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, st, a, chunks);
@@ -478,21 +499,37 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_fast_kernel(DwBwdArgs a) 
   }
 }
 
+// dw[c][t] += sum_g rowpart[g][c][t] (t < 5), dbias[c] += sum_g rowpart[g][c][5]; same blocking as above
 __global__ __launch_bounds__(256) void srf_dwconv5_bwd_params_kernel(const float* __restrict__ rowpart, int groups, int C,
                                                                      float* dw, float* dbias) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s[6] = {0, 0, 0, 0, 0, 0};
-  for (int g = 0; g < groups; ++g) {
-    const float* rp = rowpart + ((long)g * C + c) * 8;
+  __shared__ float red[8][32][6];
+  const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int g0 = blockIdx.y * 64, g1 = min(g0 + 64, groups);
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    for (int g = g0 + slice; g < g1; g += 8) {
+      const float* rp = rowpart + ((long)g * C + c) * 8;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) s[k] += (double)rp[k];
+      for (int k = 0; k < 6; ++k) acc[k] += rp[k];
+    }
   }
-  if (dw) {
 #pragma unroll
-    for (int t = 0; t < 5; ++t) dw[c * 5 + t] += (float)s[t];
+  for (int k = 0; k < 6; ++k) red[slice][cl][k] = acc[k];
+  __syncthreads();
+  if (slice == 0 && c < C) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float t = 0.f;
+#pragma unroll
+      for (int sidx = 0; sidx < 8; ++sidx) t += red[sidx][cl][k];
+      if (k < 5) {
+        if (dw) atomicAdd(dw + c * 5 + k, t);
+      } else if (dbias) {
+        atomicAdd(dbias + c, t);
+      }
+    }
   }
-  if (dbias) dbias[c] += (float)s[5];
 }
 
 extern "C" size_t srf_dwconv5_bwd_scratch_bytes(int groups, int C) {
@@ -539,8 +576,8 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
     hipLaunchKernelGGL(srf_dwconv5_bwd_kernel<2>, grid, dim3(256), 0, st, a);
   SRF_CHECK_LAUNCH("dwconv5_bwd", st);
   if (dw || dbias) {
-    hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, a.rowpart,
-                       groups, C, dw, dbias);
+    hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
+                       dim3(256), 0, st, a.rowpart, groups, C, dw, dbias);
     SRF_CHECK_LAUNCH("dwconv5_bwd_params", st);
   }
   return SRF_OK;

@@ -182,6 +182,121 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_kernel(WgArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-channel variant (GroupComm's per-group convs: Cout, Cin <= 64 with the batch folded to Bt*G = 512): the
+// 128x128 MFMA tile above would be 97 % padding and the op is a stream (2*M*N flops against 4*(M+N) bytes per
+// column).  A block stages [M+N][LC] columns of one folded example in LDS; thread = (4x4 output tile, column
+// slice): per float4 column it reads 4+4 float4 and does 64 FMAs; slices are summed through LDS, blocks write
+// partial [M][N] tiles that the same reduction kernel sums.
+// ---------------------------------------------------------------------------------------------
+template <int PRO>
+__global__ __launch_bounds__(256) void srf_pw_wgrad_small_kernel(WgArgs a, int LC, int npiece_l) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  const int M = a.M, N = a.N, L = a.L;
+  const int pitch = LC + 4;
+  float* sg = wsm;                  // [M][pitch]
+  float* sx = wsm + M * pitch;      // [N][pitch]
+  const int tilesN = N >> 2, ntile = (M >> 2) * tilesN;
+  const int nslice = 256 / ntile;   // host guarantees ntile <= 256; threads beyond nslice * ntile only help staging
+  const int tile = threadIdx.x % ntile, slice = threadIdx.x / ntile;
+  const bool worker = slice < nslice;
+  const int tm = tile / tilesN, tn = tile - tm * tilesN;
+  const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
+  float acc[4][4] = {{0.f}};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const int pieces = a.Bt * npiece_l;
+  for (int pc = blockIdx.x; pc < pieces; pc += gridDim.x) {
+    const int b = pc / npiece_l, l0 = (pc - b * npiece_l) * LC;
+    float mean = 0.f, rstd = 1.f;
+    if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
+    __syncthreads();   // previous piece fully consumed
+    // ---- stage: rows of G then rows of X, float4 along time, zero beyond L
+    const int nf4 = LC >> 2;
+    for (int e = threadIdx.x; e < (M + N) * nf4; e += 256) {
+      const int row = e / nf4, c4 = e - row * nf4;
+      const int l = l0 + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (l < L) {
+        if (row < M) {
+          v = *reinterpret_cast<const float4*>(a.g + ((size_t)b * M + row) * L + l);
+        } else {
+          const int n = row - M;
+          v = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + n) * L + l);
+          if (PRO == 1 || PRO == 2) {
+            const float sc = a.nrm.gamma[n] * rstd, sh = a.nrm.beta[n] - mean * sc;
+            v.x = fmaf(v.x, sc, sh);
+            v.y = fmaf(v.y, sc, sh);
+            v.z = fmaf(v.z, sc, sh);
+            v.w = fmaf(v.w, sc, sh);
+          }
+          if (PRO == 2 || PRO == 3) {
+            v.x = srf_prelu(v.x, slope);
+            v.y = srf_prelu(v.y, slope);
+            v.z = srf_prelu(v.z, slope);
+            v.w = srf_prelu(v.w, slope);
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(wsm + row * pitch + c4 * 4) = v;
+    }
+    __syncthreads();
+    if (worker) {
+      for (int c4 = slice; c4 < nf4; c4 += nslice) {
+        float4 gv[4], xv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gv[r] = *reinterpret_cast<const float4*>(sg + (tm * 4 + r) * pitch + c4 * 4);
+          xv[r] = *reinterpret_cast<const float4*>(sx + (tn * 4 + r) * pitch + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[i][j] = fmaf(gv[i].x, xv[j].x, acc[i][j]);
+            acc[i][j] = fmaf(gv[i].y, xv[j].y, acc[i][j]);
+            acc[i][j] = fmaf(gv[i].z, xv[j].z, acc[i][j]);
+            acc[i][j] = fmaf(gv[i].w, xv[j].w, acc[i][j]);
+          }
+          if (tn == 0) bsum[i] += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
+        }
+      }
+    }
+  }
+  // ---- sum the column slices (LDS), write this block's partial tile
+  __syncthreads();
+  float* red = wsm;   // [nslice][M*N + M]
+  const int per = M * N + M;
+  if (worker) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[slice * per + (tm * 4 + i) * N + tn * 4 + j] = acc[i][j];
+      if (tn == 0) red[slice * per + M * N + tm * 4 + i] = bsum[i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < per; e += 256) {
+    float t = 0.f;
+    for (int sidx = 0; sidx < nslice; ++sidx) t += red[sidx * per + e];
+    if (e < M * N)
+      a.part[(size_t)blockIdx.x * M * N + e] = t;
+    else if (a.bias_part)
+      a.bias_part[(size_t)blockIdx.x * M + (e - M * N)] = t;
+  }
+}
+
+static bool wg_small_ok(int M, int N, int L) {
+  if (M > 64 || N > 64 || (M & 3) || (N & 3) || (L & 3)) return false;
+  const int ntile = (M >> 2) * (N >> 2);
+  return ntile <= 256;
+}
+static int wg_small_lc(int M, int N) { return (M + N) <= 48 ? 256 : ((M + N) <= 96 ? 128 : 64); }
+static int wg_small_blocks(int Bt, int M, int N, int L) {
+  const int LC = wg_small_lc(M, N);
+  const long pieces = (long)Bt * ((L + LC - 1) / LC);
+  return (int)(pieces < 1024 ? pieces : 1024);
+}
+
 // out[m][n] (n < cols_out) = sum_p part[p][m][n]   (part rows have `cols` entries)
 __global__ __launch_bounds__(256) void srf_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                                int rows, int cols, int cols_out, int ld_out, int P,
@@ -190,9 +305,31 @@ __global__ __launch_bounds__(256) void srf_wgrad_reduce_kernel(const float* __re
   if (i >= (long)rows * cols_out) return;
   const int m = (int)(i / cols_out), n = (int)(i - (long)m * cols_out);
   const size_t src = (size_t)m * cols + n, stride = (size_t)rows * cols, dst = (size_t)m * ld_out + n;
+  // gridDim.y > 1: the partials are split over blockIdx.y and atomically added (the host pre-zeroes `out` unless
+  // it accumulates) -- a small output with many partials would otherwise be summed by a handful of threads
+  const int per = (P + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(p0 + per, P);
   float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(size_t)p * stride + src];
-  out[dst] = beta != 0.f ? fmaf(beta, out[dst], s) : s;
+  for (int p = p0; p < p1; ++p) s += part[(size_t)p * stride + src];
+  if (gridDim.y > 1)
+    atomicAdd(out + dst, s);
+  else
+    out[dst] = beta != 0.f ? fmaf(beta, out[dst], s) : s;
+}
+
+// dst [rows][ld] <- sum over P partials [P][rows][cols] (first cols_out columns)
+static int wg_reduce_launch(const float* part, float* out, int rows, int cols, int cols_out, int ld_out, int P,
+                            int accumulate, hipStream_t st) {
+  const long nw = (long)rows * cols_out;
+  int psplit = 1;
+  if (P >= 64 && nw * 4 <= 65536) psplit = P / 16;   // >= 16 partials per thread
+  if (psplit > 64) psplit = 64;
+  if (psplit > 1 && !accumulate)
+    SRF_CHECK_HIP(hipMemset2DAsync(out, sizeof(float) * ld_out, 0, sizeof(float) * cols_out, rows, st));
+  dim3 grid((unsigned)((nw + 255) / 256), (unsigned)psplit);
+  hipLaunchKernelGGL(srf_wgrad_reduce_kernel, grid, dim3(256), 0, st, part, out, rows, cols, cols_out, ld_out, P,
+                     accumulate ? 1.f : 0.f);
+  return SRF_OK;
 }
 
 static int wg_pick_partials(int ntiles, int nchunks) {
@@ -216,7 +353,12 @@ extern "C" size_t srf_pw_wgrad_scratch_bytes(int Bt, int Cout, int Cin, int L) {
   if (Bt <= 0 || Cout <= 0 || Cin <= 0 || L <= 0) return 0;
   WgArgs a;
   wg_geometry(Cout, Cin, L, Bt, &a);
-  return sizeof(float) * (size_t)a.P * ((size_t)Cout * Cin + Cout);
+  size_t P = a.P;
+  if (wg_small_ok(Cout, Cin, L)) {
+    const size_t ps = wg_small_blocks(Bt, Cout, Cin, L);
+    if (ps > P) P = ps;
+  }
+  return sizeof(float) * P * ((size_t)Cout * Cin + Cout);
 }
 
 // g: [Bt,Cout,L] gradient w.r.t. the conv output; x: [Bt,Cin,L] the conv's (pre-prologue) input;
@@ -255,6 +397,23 @@ extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* i
   if (a.nrm.sums) SRF_CHECK_ARG(a.nrm.gamma && a.nrm.beta, "srf_pw_wgrad: norm without gamma/beta");
   hipStream_t st = (hipStream_t)stream;
   const int pro = a.nrm.sums ? (a.nrm.prelu ? 2 : 1) : (a.nrm.prelu ? 3 : 0);
+  if (wg_small_ok(Cout, Cin, L) && srf_kernel_mode() != 1) {
+    const int LC = wg_small_lc(Cout, Cin), npl = (L + LC - 1) / LC;
+    a.P = wg_small_blocks(Bt, Cout, Cin, L);
+    a.bias_part = dbias ? a.part + (size_t)a.P * Cout * Cin : nullptr;
+    size_t lds = sizeof(float) * (size_t)(Cout + Cin) * (LC + 4);
+    const int ntile = (Cout >> 2) * (Cin >> 2);
+    const size_t redb = sizeof(float) * (size_t)(256 / ntile) * ((size_t)Cout * Cin + Cout);
+    if (redb > lds) lds = redb;
+    dim3 gs((unsigned)a.P), bs(256);
+    switch (pro) {
+      case 0: hipLaunchKernelGGL(srf_pw_wgrad_small_kernel<0>, gs, bs, lds, st, a, LC, npl); break;
+      case 1: hipLaunchKernelGGL(srf_pw_wgrad_small_kernel<1>, gs, bs, lds, st, a, LC, npl); break;
+      case 2: hipLaunchKernelGGL(srf_pw_wgrad_small_kernel<2>, gs, bs, lds, st, a, LC, npl); break;
+      default: hipLaunchKernelGGL(srf_pw_wgrad_small_kernel<3>, gs, bs, lds, st, a, LC, npl); break;
+    }
+    SRF_CHECK_LAUNCH("pw_wgrad_small", st);
+  } else {
   dim3 grid((unsigned)(a.nMt * a.nNt * a.P)), block(512);
   switch (pro) {
     case 0: hipLaunchKernelGGL(srf_pw_wgrad_kernel<0>, grid, block, 0, st, a); break;
@@ -263,12 +422,13 @@ extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* i
     default: hipLaunchKernelGGL(srf_pw_wgrad_kernel<3>, grid, block, 0, st, a); break;
   }
   SRF_CHECK_LAUNCH("pw_wgrad", st);
-  const long nw = (long)Cout * dw_cols;
-  hipLaunchKernelGGL(srf_wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout,
-                     Cin, dw_cols, dw_ld, a.P, accumulate ? 1.f : 0.f);
-  if (dbias)
-    hipLaunchKernelGGL(srf_wgrad_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, st, a.bias_part,
-                       dbias, Cout, 1, 1, 1, a.P, accumulate ? 1.f : 0.f);
+  }
+  int rc = wg_reduce_launch(a.part, dw, Cout, Cin, dw_cols, dw_ld, a.P, accumulate, st);
+  if (rc) return rc;
+  if (dbias) {
+    rc = wg_reduce_launch(a.bias_part, dbias, Cout, 1, 1, 1, a.P, accumulate, st);
+    if (rc) return rc;
+  }
   SRF_CHECK_LAUNCH("pw_wgrad_reduce", st);
   return SRF_OK;
 }

@@ -362,7 +362,9 @@ template <int NN, int G>
 __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, const float* __restrict__ wi,
                                                                 const float* __restrict__ bi,
                                                                 const float* __restrict__ wo,
-                                                                const float* __restrict__ bo) {
+                                                                const float* __restrict__ bo,
+                                                                const float* __restrict__ wi2,
+                                                                const float* __restrict__ wo2) {
   constexpr int HH = 3 * NN, CW = 64 / G, JPL = (HH + G - 1) / G;
   constexpr int PM = HH + 4, PO = NN + 4;
   __shared__ __attribute__((aligned(16))) float s_wm[HH * PM];   // Wm[j][i]
@@ -451,13 +453,17 @@ __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, co
       gs[i] = srf_group_allsum<G>(gpo[i]);
       if (valid && g == 0) a.GS[((size_t)b * NN + i) * L + l] = gs[i];
     }
+    // Second use of Wo / Wi: through opaque copies of the pointers, so that the compiler RE-LOADS the weights
+    // (scalar loads, cheap) instead of keeping all 2300 of them alive from their first use -- which it did by
+    // spilling ~1450 SGPRs into VGPR lanes (256 VGPRs, occupancy 1).
+    // (wo2 / wi2 are the same arrays passed a second time as separate noalias kernel arguments.)
     // g_z (direct part) = Wo[:, :H]^T g_po
     float gz[HH];
 #pragma unroll
     for (int j = 0; j < HH; ++j) {
       float t = 0.f;
 #pragma unroll
-      for (int i = 0; i < NN; ++i) t = fmaf(wo[i * 2 * HH + j], gpo[i], t);
+      for (int i = 0; i < NN; ++i) t = fmaf(wo2[i * 2 * HH + j], gpo[i], t);
       gz[j] = t;
     }
     // this lane's slice of g_pq = PReLU'(pq) * (Wo[:, H:]^T sum_g g_po)
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, co
         a.GPZ[(rowg * HH + j) * L + l] = gp;
       }
 #pragma unroll
-      for (int i = 0; i < NN; ++i) gx[i] = fmaf(wi[j * NN + i], gp, gx[i]);
+      for (int i = 0; i < NN; ++i) gx[i] = fmaf(wi2[j * NN + i], gp, gx[i]);
     }
     if (valid) {
 #pragma unroll
@@ -534,7 +540,7 @@ static bool srf_tac_bwd_g(const TacBwdArgs& a, const float* const* P, int Bt, hi
   {                                                                                                          \
     constexpr int CW = 64 / GG;                                                                              \
     dim3 grid((a.L + 4 * CW - 1) / (4 * CW), Bt);                                                            \
-    hipLaunchKernelGGL((srf_tac_bwd_lanes_kernel<NN, GG>), grid, dim3(256), 0, st, a, P[0], P[1], P[6], P[7]); \
+    hipLaunchKernelGGL((srf_tac_bwd_lanes_kernel<NN, GG>), grid, dim3(256), 0, st, a, P[0], P[1], P[6], P[7], P[0], P[6]); \
     return true;                                                                                             \
   }
   switch (a.G) {

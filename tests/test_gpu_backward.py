@@ -35,7 +35,8 @@ def sums64(x):
 
 
 @pytest.mark.parametrize("Bt,Cin,Cout,L", [(3, 256, 512, 3200), (2, 512, 256, 832), (2, 64, 42, 200), (5, 48, 160, 132),
-                                           (1, 16, 32, 36), (32, 256, 512, 3200)])
+                                           (1, 16, 32, 36), (32, 256, 512, 3200), (64, 16, 32, 400), (24, 32, 16, 3200),
+                                           (8, 16, 48, 200), (5, 48, 16, 76), (4, 64, 64, 132), (3, 8, 8, 20)])
 @pytest.mark.parametrize("pro", [0, 1, 2, 3])
 def test_pw_wgrad(Bt, Cin, Cout, L, pro):
     from sudo_rm_rf_amd import ops

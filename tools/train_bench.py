@@ -12,6 +12,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib  # noqa: E402
+import sudo_rm_rf.dnn.experiments.utils.mixture_consistency as mixture_consistency  # noqa: E402
+import sudo_rm_rf.dnn.models.groupcomm_sudormrf_v2 as sudormrf_gc_v2  # noqa: E402
 import sudo_rm_rf.dnn.models.improved_sudormrf as improved_sudormrf  # noqa: E402
 from oracle.schema import CONFIGS  # noqa: E402
 from sudo_rm_rf_amd import _lib  # noqa: E402
@@ -26,7 +28,8 @@ def main():
     cfg = CONFIGS[name]
     T = 32000
     torch.manual_seed(0)
-    model = improved_sudormrf.SuDORMRF(**cfg.ctor_kwargs()).to(DEV)
+    gc = cfg.variant == "groupcomm"
+    model = (sudormrf_gc_v2.GroupCommSudoRmRf if gc else improved_sudormrf.SuDORMRF)(**cfg.ctor_kwargs()).to(DEV)
     loss_fn = sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_mtx')
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     g = torch.Generator().manual_seed(1)
@@ -39,6 +42,8 @@ def main():
     def step():
         opt.zero_grad()
         rec = model(mix)
+        if gc:
+            rec = mixture_consistency.apply(rec, mix)
         l = torch.clamp(loss_fn(rec, clean), min=-30., max=+30.)
         l.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
