@@ -10,7 +10,7 @@ cp $R/bench.json profiles/${T}_cfg2_bs32_bench.json
 [ -s $R/bench_cfg3_groupcomm_u8.json ] && cp $R/bench_cfg3_groupcomm_u8.json profiles/${T}_cfg3_groupcomm_bs32_bench.json
 [ -s $R/bench_cfg4_improved_u36_n2048.json ] && cp $R/bench_cfg4_improved_u36_n2048.json profiles/${T}_cfg4_u36_n2048_bs32_bench.json
 [ -s $R/bench_cfg5_improved_u36_n4096.json ] && cp $R/bench_cfg5_improved_u36_n4096.json profiles/${T}_cfg5_u36_n4096_8s16k_bs16_bench.json
-for w in cfg2_improved_u16 cfg4_improved_u36_n2048; do
+for w in cfg2_improved_u16 cfg3_groupcomm_u8 cfg4_improved_u36_n2048; do
   [ -s $R/train_$w.json ] && cp $R/train_$w.json profiles/${T}_${w}_train_step_bs32.json
 done
 f=$(find $R/prof -name "*kernel_stats.csv" | head -1)
