@@ -279,7 +279,8 @@ def main():
         "config": {"workload": "%s forward, batch %d per GPU, T=%d (%.0f s @ %d Hz), inference" %
                                (args.workload, batch, T, T / fs, fs),
                    "global_batch": batch * n_gpus, "parallelism": "batch-sharded replicas x%d" % n_gpus,
-                   "kernel_mode": args.kernel_mode},
+                   "kernel_mode": args.kernel_mode,
+                   "stream_split": list(model._engine()._split_choice.get((dev.index, batch, T), (batch,)))},
         "forward_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fwd_gbs / roofline.HBM_PEAK_GBS,
                              "algorithmic_bytes_per_forward": alg_bytes,
@@ -293,11 +294,13 @@ def main():
         stream = _lib.current_stream(dev)
         psteps = min(args.steps, 10)
         with torch.no_grad():
+            model._engine().multi_stream = False      # the profiler's events live on one stream
             lib.srf_profile_begin(stream)
             for _ in range(psteps):
                 model(wav)
             cnt = C.c_int(0)
             _lib.check(lib.srf_profile_end(stream, C.byref(cnt)), "srf_profile_end")
+            model._engine().multi_stream = True
         launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, **dims)
         per = {}
         name, ms = C.c_char_p(), C.c_float()

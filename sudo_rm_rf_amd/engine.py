@@ -3,6 +3,7 @@
 Python owns tensors and module structure only; all arithmetic happens in libsudormrf_hip.so.
 """
 import ctypes as C
+import os
 import threading
 import warnings
 from collections import OrderedDict
@@ -11,7 +12,11 @@ import torch
 
 from . import _lib
 
-_MAX_PLANS = 4
+_MAX_PLANS = 8
+# Inference batches are split over two HIP streams when that measures faster (see ModelEngine._splits):
+#   SRF_STREAM_SPLIT = auto (default) | off | half | 5:3
+_SPLIT_MODE = os.environ.get("SRF_STREAM_SPLIT", "auto")
+_SPLIT_MIN_BATCH = 8
 
 
 def _config_struct(variant, in_audio_channels, out_channels, in_channels, num_blocks, upsampling_depth,
@@ -137,9 +142,13 @@ class ModelEngine:
         self._lock = threading.Lock()
         self._warned_grad = False
         self.last_plan = None
+        self.multi_stream = True          # bench.py switches it off for its per-kernel profiling pass
+        self._side_streams = {}
+        self._split_choice = {}
 
-    def plan_for(self, batch, T, device):
-        key = (device.index if device.index is not None else torch.cuda.current_device(), batch, T)
+    def plan_for(self, batch, T, device, lane=0):
+        """lane: plans of different stream lanes never share a workspace, even for equal sub-batch sizes."""
+        key = (device.index if device.index is not None else torch.cuda.current_device(), batch, T, lane)
         with self._lock:
             plan = self._plans.get(key)
             if plan is None:
@@ -204,6 +213,71 @@ class ModelEngine:
                                     (len(params), plan.num_params))
             out_ch = module.num_sources * expected_channels
             out = torch.empty((batch, out_ch, T), dtype=torch.float32, device=x.device)
-            plan.forward(self._param_table(params, x.device), x, out)
+            table = self._param_table(params, x.device)
+            self._forward_split(self._splits(batch, T, x, out, table), x, out, table)
             self.last_plan = plan
         return out
+
+    # ---- batch split over two streams ---------------------------------------------------------------
+    # Examples are independent, so a batch may run as two sub-batches on two HIP streams: the tail
+    # of one stream's kernel (partial last round of GEMM tiles, the 32-block finalize kernels, epilogue write
+    # bursts) is filled with the other's blocks.  Measured on one MI355X: cfg 2 batch 32 8.20 -> 7.72 ms (16+16),
+    # cfg 3 4.97 -> 4.73 ms (20+12), cfg 5 65.2 -> 63.7 ms (10+6), cfg 4 29.5 -> 29.3 ms (20+12; 16+16 loses 3 %).
+    # Which split wins depends on how the tile counts quantise, so the first call of a (batch, length) times the
+    # candidates (2 forwards each, all produce the correct output) and keeps the fastest.
+    def _split_candidates(self, batch):
+        if _SPLIT_MODE == "off" or batch < _SPLIT_MIN_BATCH or not self.multi_stream:
+            return [(batch,)]
+        half = (batch - batch // 2, batch // 2)
+        skew = (batch - (3 * batch) // 8, (3 * batch) // 8)
+        if _SPLIT_MODE == "half":
+            return [half]
+        if _SPLIT_MODE == "5:3":
+            return [skew]
+        return [(batch,), half, skew] if skew != half else [(batch,), half]
+
+    def _forward_split(self, parts, x, out, table):
+        dev = x.device
+        if len(parts) == 1:
+            self.plan_for(parts[0], x.shape[-1], dev).forward(table, x, out)
+            return
+        cur = torch.cuda.current_stream(dev)
+        streams = self._side_streams.setdefault(dev.index, [torch.cuda.Stream(dev) for _ in range(2)])
+        lo = 0
+        for lane, n in enumerate(parts):
+            st = streams[lane]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self.plan_for(n, x.shape[-1], dev, lane=lane + 1).forward(table, x[lo:lo + n], out[lo:lo + n])
+            x.record_stream(st)
+            out.record_stream(st)
+            lo += n
+        for st in streams[:len(parts)]:
+            cur.wait_stream(st)
+
+    def _splits(self, batch, T, x, out, table):
+        if not self.multi_stream:
+            return (batch,)
+        key = (x.device.index, batch, T)
+        choice = self._split_choice.get(key)
+        if choice is not None:
+            return choice
+        cands = self._split_candidates(batch)
+        if len(cands) == 1:
+            choice = cands[0]
+        else:
+            best = None
+            for parts in cands:
+                self._forward_split(parts, x, out, table)          # warm-up (plan creation, first-touch)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(2):
+                    self._forward_split(parts, x, out, table)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if best is None or ms < best[0] * 0.985:            # a split must win by > 1.5 % to be chosen
+                    best = (ms, parts)
+            choice = best[1]
+        self._split_choice[key] = choice
+        return choice

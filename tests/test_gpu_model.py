@@ -181,3 +181,28 @@ def test_separate_pipeline_matches_reference_recipe(variant):
     got = pipeline.separate(model, mix.to(DEV))
     err = (got.cpu() - want).abs().max().item()
     assert err <= 1e-4, err
+
+
+@pytest.mark.gpu
+def test_two_stream_split_is_bit_identical(manifest):
+    """The engine may run a batch as two sub-batches on two streams (examples are independent): whatever split its
+    auto-tuner picks, the output equals the single-stream forward bit for bit."""
+    from oracle.schema import ModelConfig
+    from oracle import weights
+    cfg = ModelConfig("improved", 32, 64, 2, 4, 21, 64, 2)
+    model = build(cfg, weights.make_state_dict(cfg, seed=3))
+    wav = torch.from_numpy(weights.make_mixture(24, 6400, seed=4)).to(DEV)
+    eng = model._engine()
+    with torch.no_grad():
+        eng.multi_stream = False
+        ref = model(wav)
+        eng.multi_stream = True
+        for parts in [(24,), (12, 12), (15, 9)]:
+            out = torch.empty_like(ref)
+            params = [p.detach() for p in model.state_dict(keep_vars=True).values()]
+            eng._forward_split(parts, wav, out, eng._param_table(params, wav.device))
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), parts
+        auto = model(wav)          # auto-tuned path
+        assert torch.equal(auto, ref)
+        assert eng._split_choice
