@@ -7,6 +7,9 @@ import sudo_rm_rf.dnn.models.improved_sudormrf as improved_sudormrf
 import sudo_rm_rf.dnn.models.groupcomm_sudormrf_v2 as gcm
 from oracle.schema import CONFIGS
 DEV = "cuda:0"
+from sudo_rm_rf_amd import ops
+ops.set_debug_flags(int(os.environ.get("SRF_FLAGS", "0")))
+os.environ["SRF_STREAM_SPLIT"] = "off"
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_improved_u16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 cfg = CONFIGS[name]
