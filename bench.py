@@ -337,6 +337,9 @@ def main():
                   "unit": "GB/s", "frac": kd["algorithmic_GBps"] / roofline.HBM_PEAK_GBS, "traffic": None}
         rl.update(pmc_traffic(dom, args.workload))
         rl["avg_launch_us"] = kd["avg_launch_us"]
+        rl["measured"] = ("per-kernel durations from a single-stream pass (SRF_STREAM_SPLIT=off equivalent); the timed "
+                          "region above runs the auto-tuned two-stream split " +
+                          str(result["config"].get("stream_split")))
         rl["share_of_forward"] = kd["ms_per_forward"] / sum(v["ms_per_forward"] for v in kernels.values())
         result["roofline"] = rl
         result["kernels"] = kernels

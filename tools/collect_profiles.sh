@@ -15,6 +15,8 @@ for w in cfg2_improved_u16 cfg3_groupcomm_u8 cfg4_improved_u36_n2048; do
 done
 f=$(find $R/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && grep -v "at::native" "$f" > profiles/${T}_cfg2_bs32_rocprofv3_kernel_stats.csv
+f2=$(find $R/prof2s -name "*kernel_stats.csv" 2>/dev/null | head -1)
+[ -n "$f2" ] && grep -v "at::native" "$f2" > profiles/${T}_cfg2_bs32_rocprofv3_kernel_stats_two_streams.csv
 [ -d $R/pmc1 ] && python tools/pmc_summary.py $R profiles/${T}_cfg2_bs32_pmc_hbm_traffic.csv > /dev/null
 grep -E "passed|failed" $R/pytest_gpu.log | tail -1 > profiles/${T}_pytest_gpu_summary.txt
 cat $R/smoke.log | grep -E "smoke|build" >> profiles/${T}_pytest_gpu_summary.txt

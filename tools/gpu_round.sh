@@ -39,21 +39,24 @@ print({k: v for k, v in d.items() if k != "kernels_ms"})
 PY
 done
 if [ "${SKIP_PROF:-0}" != "1" ]; then
-  echo "== rocprofv3 kernel trace"
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- \
+  echo "== rocprofv3 kernel trace (single stream: the per-kernel durations bench.py's roofline block reports)"
+  ( cd /tmp && SRF_STREAM_SPLIT=off timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- \
       python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile ) > "$OUT/rocprof.log" 2>&1
   echo "rocprof rc=$?"
-  find "$OUT/prof" -name "*kernel_stats*" | head -3
-  f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
-  # keep the merged-back payload small: the raw kernel trace can be large
-  find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
+  f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f" | cut -c1-160
+  echo "== rocprofv3 kernel trace (default: auto-tuned two-stream split)"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof2s" -o bench -- \
+      python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile ) > "$OUT/rocprof2s.log" 2>&1
+  echo "rocprof(2 streams) rc=$?"
+  # keep the merged-back payload small: the raw kernel traces can be large
+  find "$OUT/prof" "$OUT/prof2s" -name "*kernel_trace.csv" -delete
 fi
 # PMC passes: counters in their own runs (kernel-trace only), one counter group per pass
 i=0
 for grp in ${PMC_GROUPS:-}; do
   i=$((i+1))
   echo "== rocprofv3 pmc pass $i: $grp"
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc ${grp//,/ } -d "$GRAFT_REPO_ROOT/$OUT/pmc$i" -o bench -- \
+  ( cd /tmp && SRF_STREAM_SPLIT=off timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc ${grp//,/ } -d "$GRAFT_REPO_ROOT/$OUT/pmc$i" -o bench -- \
       python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile ) > "$OUT/pmc$i.log" 2>&1
   echo "pmc rc=$?"; ls "$OUT/pmc$i" | head -5
   find "$OUT/pmc$i" -name "*.csv" -size +30M -delete
