@@ -39,11 +39,21 @@ __device__ __forceinline__ void srf_zero(float (&v)[N]) {
   for (int i = 0; i < N; ++i) v[i] = 0.f;
 }
 
+// Neighbour-lane exchange as DPP wavefront shifts (VALU, full rate) instead of __shfl_up/down, which lower to
+// ds_bpermute_b32 (LDS pipe, ~100 cycles of latency on every level's critical path).  Lane 0 / lane 63 receive 0:
+// their chunks are halo chunks whose results are discarded, exactly as the clamped shuffle's were.
+__device__ __forceinline__ float srf_lane_up(float v) {     // lane l <- lane l-1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));   // wave_shr:1
+}
+__device__ __forceinline__ float srf_lane_down(float v) {   // lane l <- lane l+1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));   // wave_shl:1
+}
+
 // stride-1 k=5 conv over a lane's chunk: out[i] = b + sum_t w[t] * x[i + t - 2], halo from neighbours
 template <int N>
 __device__ __forceinline__ void srf_conv_s1(const float (&x)[N], float (&out)[N], const float* w, float b) {
-  const float l2 = __shfl_up(x[N - 2], 1, 64), l1 = __shfl_up(x[N - 1], 1, 64);
-  const float r0 = __shfl_down(x[0], 1, 64), r1 = __shfl_down(x[1], 1, 64);
+  const float l2 = srf_lane_up(x[N - 2]), l1 = srf_lane_up(x[N - 1]);
+  const float r0 = srf_lane_down(x[0]), r1 = srf_lane_down(x[1]);
   float e[N + 4];
   e[0] = l2;
   e[1] = l1;
@@ -59,8 +69,8 @@ __device__ __forceinline__ void srf_conv_s1(const float (&x)[N], float (&out)[N]
 // stride-2 k=5 conv: out[j] = b + sum_t w[t] * x[2j + t - 2]
 template <int N>
 __device__ __forceinline__ void srf_conv_s2(const float (&x)[N], float (&out)[N / 2], const float* w, float b) {
-  const float l2 = __shfl_up(x[N - 2], 1, 64), l1 = __shfl_up(x[N - 1], 1, 64);
-  const float r0 = __shfl_down(x[0], 1, 64);
+  const float l2 = srf_lane_up(x[N - 2]), l1 = srf_lane_up(x[N - 1]);
+  const float r0 = srf_lane_down(x[0]);
   float e[N + 3];
   e[0] = l2;
   e[1] = l1;
