@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--train", action="store_true",
                     help="time one TRAINING step (forward, PIT-SI-SDR, backward, gradient all-reduce, clip, Adam -- "
                          "run_improved_sudormrf.py:146-177) instead of the inference forward")
+    ap.add_argument("--torch-optim", action="store_true",
+                    help="with --train: torch's clip_grad_norm_ + Adam instead of the fused HIP clip+Adam step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -161,7 +163,10 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
     from sudo_rm_rf_amd import distributed as D
     model = cls(**kw).to(dev).train()
     loss_fn = sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_mtx')
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    from sudo_rm_rf_amd import optim
+    fused = not args.torch_optim
+    opt = (optim.FusedClipAdam(model.parameters(), lr=1e-3, clip_grad_norm=5.0) if fused
+           else torch.optim.Adam(model.parameters(), lr=1e-3))
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     clean = torch.randn(batch, kw["num_sources"], T, generator=g).to(dev)
     mix = clean.sum(1, keepdim=True)
@@ -175,7 +180,8 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
         l = torch.clamp(loss_fn(rec, clean), min=-30., max=+30.)
         l.backward()
         D.allreduce_gradients(model.parameters())
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        if not fused:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
         opt.step()
         return l
 
@@ -200,6 +206,7 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
             "data": "synthetic",
             "config": {"workload": "%s training step, batch %d per GPU, T=%d" % (args.workload, batch, T),
                        "global_batch": batch * world, "parallelism": "data-parallel x%d, one gradient all-reduce" % world},
+            "optimizer": "fused HIP clip_grad_norm + Adam" if fused else "torch clip_grad_norm_ + torch.optim.Adam",
             "loss": float(l.detach()), "saved_activations_GB": saved / 2 ** 30, "scratch_GB": scratch / 2 ** 30,
             "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}))
     if world > 1:

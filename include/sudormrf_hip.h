@@ -313,6 +313,15 @@ size_t srf_online_remix_scratch_bytes(int B, int S);
 int srf_online_remix(const float* clean, const int* src_b, const int* src_s, int B, int S, int T, float eps, float* mix,
                      float* out, void* scratch, void* stream);
 
+/* Fused clip_grad_norm_ + Adam step over all parameters (run_improved_sudormrf.py:172-176; torch.optim.Adam without
+ * amsgrad / weight decay).  tensors: device array of {float* p; const float* g; float* m; float* v; long n;};
+ * chunks: device array of {int tensor, int chunk} covering every tensor in srf_opt_chunk_size()-element pieces;
+ * buckets: SRF_STAT_BUCKETS doubles of device scratch; step: 1-based step count; max_norm <= 0: no clipping;
+ * norm_out: optional device float receiving the total gradient norm before clipping. */
+int srf_opt_chunk_size(void);
+int srf_clip_adam_step(const void* tensors, const void* chunks, int n_chunks, double* buckets, float max_norm, float lr,
+                       float beta1, float beta2, float eps, int step, float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

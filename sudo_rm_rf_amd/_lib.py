@@ -84,6 +84,8 @@ _PROTOS = {
     "srf_tac_bwd": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "srf_online_remix_scratch_bytes": (_sz, [_i, _i]),
     "srf_online_remix": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
+    "srf_opt_chunk_size": (_i, []),
+    "srf_clip_adam_step": (_i, [_vp, _vp, _i, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp, _vp]),
     "srf_wav_normalize": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "srf_wav_denormalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srf_dwconv5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp]),

@@ -1,0 +1,77 @@
+"""Fused gradient clipping + Adam: the last two lines of the reference runner's step,
+``torch.nn.utils.clip_grad_norm_(model.parameters(), clip); opt.step()`` (run_improved_sudormrf.py:172-176), as two
+HIP launches over every parameter at once (csrc/srf_optim.hip), without the host sync clip_grad_norm_ needs."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class FusedClipAdam(torch.optim.Optimizer):
+    """Drop-in for ``torch.optim.Adam(params, lr, betas, eps)`` (no weight decay / amsgrad) that also applies
+    ``clip_grad_norm_(params, clip_grad_norm)`` inside ``step()``.  State (``exp_avg``, ``exp_avg_sq``, ``step``) uses
+    torch's names, so ``state_dict()`` is interchangeable with torch.optim.Adam's."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_grad_norm=0.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, clip_grad_norm=clip_grad_norm)
+        super().__init__(params, defaults)
+        self._tables = {}
+        self.last_grad_norm = None          # device scalar: total gradient norm before clipping (last step)
+
+    def _table(self, gi, group, plist):
+        key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist))
+        cached = self._tables.get(gi)
+        if cached is not None and cached[0] == key:
+            return cached[1:]
+        dev = plist[0].device
+        chunk = _lib.load().srf_opt_chunk_size()
+        desc = np.zeros((len(plist), 5), dtype=np.int64)
+        chunks = []
+        for i, p in enumerate(plist):
+            st = self.state[p]
+            desc[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+            chunks += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
+        tens = torch.from_numpy(desc).to(dev)
+        chs = torch.tensor(chunks, dtype=torch.int32).to(dev)
+        buckets = torch.empty(_lib.STAT_BUCKETS, dtype=torch.float64, device=dev)
+        norm = torch.empty(1, dtype=torch.float32, device=dev)
+        self._tables[gi] = (key, tens, chs, buckets, norm)
+        return tens, chs, buckets, norm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            dev = plist[0].device
+            for p in plist:
+                if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous() or p.device.type != "cuda":
+                    raise _lib.SrfError("FusedClipAdam: parameters must be contiguous float32 tensors on one MI355X")
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+            step = self.state[plist[0]]["step"] + 1
+            for p in plist:
+                self.state[p]["step"] = step
+            tens, chs, buckets, norm = self._table(gi, group, plist)
+            b1, b2 = group["betas"]
+            with torch.cuda.device(dev):
+                rc = lib.srf_clip_adam_step(_lib.ptr(tens), _lib.ptr(chs), chs.shape[0], _lib.ptr(buckets),
+                                            C.c_float(group["clip_grad_norm"]), C.c_float(group["lr"]), C.c_float(b1),
+                                            C.c_float(b2), C.c_float(group["eps"]), step, _lib.ptr(norm),
+                                            _lib.current_stream(dev))
+            _lib.check(rc, "srf_clip_adam_step")
+            self.last_grad_norm = norm
+        return loss

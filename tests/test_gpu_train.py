@@ -176,3 +176,32 @@ def test_fast_training_forward_flag():
         num += ((smp - z["g:" + k]) ** 2).sum()
         den += (z["g:" + k].astype(np.float64) ** 2).sum()
     assert (num / den) ** 0.5 <= 2e-2          # whole-gradient relative error (measured 3e-3)
+
+
+@pytest.mark.parametrize("clip", [5.0, 0.05, 0.0])
+def test_fused_clip_adam_matches_torch(clip):
+    """optim.FusedClipAdam == clip_grad_norm_ + torch.optim.Adam (run_improved_sudormrf.py:172-176) over 3 steps."""
+    from sudo_rm_rf_amd import optim
+    g = torch.Generator().manual_seed(7)
+    shapes = [(512, 256, 1), (512,), (1,), (37, 5), (4097,), (3, 4096)]
+    pa = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    ref = torch.optim.Adam(pa, lr=1e-3)
+    fused = optim.FusedClipAdam(pb, lr=1e-3, clip_grad_norm=clip)
+    for it in range(3):
+        grads = [torch.randn(*s, generator=g).to(DEV) * (0.1 + it) for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad = gr.clone()
+            q.grad = gr.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_(pa, clip) if clip > 0 else None
+        ref.step()
+        fused.step()
+        if want_norm is not None:
+            assert abs(fused.last_grad_norm.item() - want_norm.item()) <= 1e-5 * want_norm.item()
+        for p, q in zip(pa, pb):
+            assert (p - q).abs().max().item() <= 2e-6, it
+    sa, sb = ref.state_dict()["state"], fused.state_dict()["state"]
+    for k in sa:
+        for name in ("exp_avg", "exp_avg_sq"):
+            a, b = sa[k][name], sb[k][name]
+            assert ((a - b).abs() <= 1e-7 + 1e-4 * a.abs()).all(), name
