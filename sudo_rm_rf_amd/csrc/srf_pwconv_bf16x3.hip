@@ -58,7 +58,9 @@ __device__ __forceinline__ void srf_split8(const float (&v)[8], bf16x8& hi, bf16
 // (An instruction-interleave variant -- unconditional store + sched_group_barrier(MFMA 1 / VALU 7) -- was
 // measured: 131 us vs 151 us on proj_1x1 but slower on the prologue variants and miscompiled for PRO 0;
 // dropped.)
-template <int PRO, int ABL = 0>
+// BUF: operand loads as buffer loads (see the persistent kernel); false = 64-bit pointer form for tensors whose
+// byte offsets do not fit 32 bits.
+template <int PRO, int ABL = 0, bool BUF = true>
 __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int nMt, int nLt, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
 
@@ -107,13 +109,21 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
   const int a_m = tid >> 2, a_pk = tid & 3;
   const bool a_ok = (m0 + a_m) < Cout;
   const float* a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_pk * 8;
-  const float a_msk = a_ok ? 1.f : 0.f;
+  const float a_msk = (BUF || a_ok) ? 1.f : 0.f;   // BUF: rows beyond Cout read 0 from the descriptor
   const int a_lds = a_m * X3_PITCH + a_pk * 16;
   // B (X_b [k][time]): thread -> time step n = tid&127, k-group kg = tid>>7 (wave-uniform), 8 k rows
   const int b_n = tid & 127, b_kg = (wave >> 1) * 8;
   const bool b_ok = (l0 + b_n) < L;
   const float* b_src = xb + (size_t)b_kg * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
   const int b_lds = b_n * X3_PITCH + b_kg * 2;
+  __amdgpu_buffer_rsrc_t a_rs, b_rs;
+  int a_vo = 0, b_vo = 0;
+  if (BUF) {
+    a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, Cout * Cin * 4, 0x00020000);
+    b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, Cin * L * 4, 0x00020000);
+    a_vo = ((m0 + a_m) * Cin + a_pk * 8) * 4;
+    b_vo = (b_kg * L + min(l0 + b_n, L - 1)) * 4;
+  }
 
   struct Regs {
     float4 a[2];
@@ -127,12 +137,21 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
   }
   auto gload = [&](Regs& r, int k0) {
     if (!(ABL & 1)) {
-      r.a[0] = *reinterpret_cast<const float4*>(a_src + k0);
-      r.a[1] = *reinterpret_cast<const float4*>(a_src + k0 + 4);
+      if (BUF) {
+        const auto w0 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo, k0 * 4, 0);
+        const auto w1 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo, k0 * 4 + 16, 0);
+        r.a[0] = make_float4(__uint_as_float(w0[0]), __uint_as_float(w0[1]), __uint_as_float(w0[2]), __uint_as_float(w0[3]));
+        r.a[1] = make_float4(__uint_as_float(w1[0]), __uint_as_float(w1[1]), __uint_as_float(w1[2]), __uint_as_float(w1[3]));
+      } else {
+        r.a[0] = *reinterpret_cast<const float4*>(a_src + k0);
+        r.a[1] = *reinterpret_cast<const float4*>(a_src + k0 + 4);
+      }
     }
     if (!(ABL & 2)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r.b[j] = b_src[(size_t)(k0 + j) * L];
+      for (int j = 0; j < 8; ++j)
+        r.b[j] = BUF ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, b_vo, (k0 + j) * L * 4, 0))
+                     : b_src[(size_t)(k0 + j) * L];
     }
   };
   auto lds_store = [&](const Regs& r, int stage, int k0) {
@@ -312,7 +331,10 @@ __device__ __forceinline__ void srf_pw_epilogue_half(const PwArgs& a, const f32x
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int PRO>
+// BUF: operand loads as buffer loads -- SGPR descriptor + per-lane byte offset fixed per tile + a SCALAR offset that
+// walks the k rows, so the k-loop does no per-load 64-bit address arithmetic on the VALU (11 v_lshl_add_u64 per
+// k-tile in the pointer form) and rows / columns beyond the tensor simply read 0 (no clamp, no row mask).
+template <int PRO, bool BUF = false>
 __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int nMt, int nLt, int total, int nhalf) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
 
@@ -366,14 +388,23 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   int ld_i = 0, ld_k = 0;
   const float* a_src;
   const float* b_src;
+  __amdgpu_buffer_rsrc_t a_rs, b_rs;     // BUF: descriptors of W and of the tile's example X_b
+  int a_vo = 0, b_vo = 0;                // BUF: per-lane byte offsets inside them
+  if (BUF) a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, Cout * Cin * 4, 0x00020000);
   auto ld_tile = [&](int i) {
     int m0, l0, hf;
     long b;
     tile_of(i, m0, l0, b, hf);
-    const bool a_ok = (m0 + a_m) < Cout;
-    a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_pk * 8;
-    const bool b_ok = (l0 + b_n) < L;
-    b_src = a.x + ((size_t)b * Cin + b_kg) * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
+    if (BUF) {
+      a_vo = ((m0 + a_m) * Cin + a_pk * 8) * 4;                         // rows >= Cout land beyond the descriptor: 0
+      b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * Cin * L, 0, Cin * L * 4, 0x00020000);
+      b_vo = (b_kg * L + min(l0 + b_n, L - 1)) * 4;                     // columns >= L are never stored
+    } else {
+      const bool a_ok = (m0 + a_m) < Cout;
+      a_src = a.w + (size_t)(a_ok ? (m0 + a_m) : 0) * Cin + a_pk * 8;
+      const bool b_ok = (l0 + b_n) < L;
+      b_src = a.x + ((size_t)b * Cin + b_kg) * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
+    }
   };
   ld_tile(0);
   struct Regs {
@@ -381,10 +412,20 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
     float b[8];
   };
   auto gload = [&](Regs& r) {
-    r.a[0] = *reinterpret_cast<const float4*>(a_src + ld_k);
-    r.a[1] = *reinterpret_cast<const float4*>(a_src + ld_k + 4);
+    if (BUF) {
+      const auto w0 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo, ld_k * 4, 0);
+      const auto w1 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo, ld_k * 4 + 16, 0);
+      r.a[0] = make_float4(__uint_as_float(w0[0]), __uint_as_float(w0[1]), __uint_as_float(w0[2]), __uint_as_float(w0[3]));
+      r.a[1] = make_float4(__uint_as_float(w1[0]), __uint_as_float(w1[1]), __uint_as_float(w1[2]), __uint_as_float(w1[3]));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.b[j] = b_src[(size_t)(ld_k + j) * L];
+      for (int j = 0; j < 8; ++j)
+        r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, b_vo, (ld_k + j) * L * 4, 0));
+    } else {
+      r.a[0] = *reinterpret_cast<const float4*>(a_src + ld_k);
+      r.a[1] = *reinterpret_cast<const float4*>(a_src + ld_k + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.b[j] = b_src[(size_t)(ld_k + j) * L];
+    }
     ld_k += X3_BK;
     if (ld_k == Cin) {   // wave-uniform; past the last tile the cursor re-reads that tile (harmless)
       ld_k = 0;
@@ -399,7 +440,7 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
     int m0, l0, hf;
     long b;
     tile_of(i, m0, l0, b, hf);
-    a_msk = (m0 + a_m) < Cout ? 1.f : 0.f;
+    a_msk = (BUF || (m0 + a_m) < Cout) ? 1.f : 0.f;
     if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
   };
   cv_tile(0);
@@ -510,6 +551,11 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   }
 }
 
+// buffer loads need 32-bit byte offsets inside W and inside one example of X (debug flag 1<<27 forces the pointer form)
+static bool srf_pw_buffer_ok(const PwArgs& a) {
+  return (long)a.Cout * a.Cin * 4 < (1L << 31) && (long)a.Cin * a.L * 4 < (1L << 31) && !(srf_debug_flags() & (1 << 27));
+}
+
 int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
   const int nMt = (a.Cout + X3_BM - 1) / X3_BM, nLt = (a.L + X3_BN - 1) / X3_BN;
   const long total = (long)a.Bt * nMt * nLt;
@@ -539,6 +585,14 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
       // leftover tiles of the last round as half tiles when they fill at most half of it (debug flag 256: off)
       const long rem = total % nb;
       const int nhalf = (rem > 0 && 2 * rem <= nb && !(srf_debug_flags() & 256)) ? (int)(2 * rem) : 0;
+      if (srf_pw_buffer_ok(a)) {
+        switch (pro) {
+          case 0: hipLaunchKernelGGL((srf_pw_bf16x3_p8_kernel<0, true>), gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
+          case 1: hipLaunchKernelGGL((srf_pw_bf16x3_p8_kernel<1, true>), gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
+          case 2: hipLaunchKernelGGL((srf_pw_bf16x3_p8_kernel<2, true>), gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
+          default: hipLaunchKernelGGL((srf_pw_bf16x3_p8_kernel<3, true>), gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
+        }
+      } else
       switch (pro) {
         case 0: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<0>, gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
         case 1: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<1>, gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
@@ -570,6 +624,14 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
     }
     PwArgs aw = a;
     aw.epi_mask |= (((srf_debug_flags() >> 20) & 15) << 8) | (((srf_debug_flags() >> 12) & 1) << 12);
+    if (!srf_pw_buffer_ok(a)) {
+      switch (pro) {
+        case 0: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 0, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+        case 1: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<1, 0, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+        case 2: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<2, 0, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+        default: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<3, 0, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+      }
+    } else
     switch (pro) {
       case 0: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<0>, grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
       case 1: hipLaunchKernelGGL(srf_pw_bf16x3_w8_kernel<1>, grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;

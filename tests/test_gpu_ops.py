@@ -140,6 +140,31 @@ def test_pw_conv(mode, Bt, Cin, Cout, L, pro):
     check_sums(osums, want, "pw_conv sums")
 
 
+@pytest.mark.parametrize("Bt,Cin,Cout,L", [(32, 64, 200, 3300),   # 1664 tiles: persistent kernel, partial M and N tiles
+                                          (3, 128, 72, 333)])     # one tile per block
+@pytest.mark.parametrize("pro", [0, 2])
+def test_pw_conv_buffer_and_pointer_loads_agree(Bt, Cin, Cout, L, pro):
+    """The split-bf16 GEMMs fetch their operands with buffer loads (out-of-range rows read 0); debug flag 1<<27 selects
+    the 64-bit pointer form kept for tensors beyond 2 GB.  Same arithmetic -> bit-identical results."""
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+    x, w, bias = dev32(rnd(Bt, Cin, L, seed=30)), dev32(rnd(Cout, Cin, 1, seed=31, scale=0.1)), dev32(rnd(Cout, seed=32))
+    kw = {}
+    if pro == 2:
+        kw = dict(in_sums=sums64(x.double().cpu()).to(DEV), in_gamma=dev32(rnd(Cin, seed=33, shift=1.0)),
+                  in_beta=dev32(rnd(Cin, seed=34)), in_prelu=dev32(torch.tensor([0.2], dtype=torch.float64)))
+    want = F.conv1d(x.double().cpu(), w.double().cpu(), bias.double().cpu()) if pro == 0 else None
+    a = ops.pw_conv(x, w, bias, **kw)
+    try:
+        ops.set_debug_flags(1 << 27)
+        b = ops.pw_conv(x, w, bias, **kw)
+    finally:
+        ops.set_debug_flags(0)
+    assert torch.equal(a, b)
+    if want is not None:
+        check(a, want, 5e-5, "pw_conv buffer loads")
+
+
 def test_pw_conv_mask_epilogue(mode):
     from sudo_rm_rf_amd import ops
     Bt, Cin, N, S, L = 2, 64, 48, 2, 260
