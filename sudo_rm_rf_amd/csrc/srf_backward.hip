@@ -157,6 +157,152 @@ __global__ __launch_bounds__(256) void srf_gln_bwd_apply_kernel(GlnBwdArgs a, in
   }
 }
 
+// Fast variants (L % 4 == 0, 16-byte aligned tensors): ONE WAVEFRONT PER ROW, 16-byte accesses, four float4 per lane
+// and tensor in flight per trip, the row sums reduced with DPP (no LDS, no barrier).  The dword kernels above ran at
+// 2.7 (reduce) / 3.1 TB/s (apply) on cfg 2 and remain the fallback for odd lengths.
+__device__ __forceinline__ void srf_gln_bwd_elem(float gv, float x, float mean, float rstd, float gam, float bet,
+                                                 bool act, float slope, float& xh, float& gz, float& sneg) {
+  xh = (x - mean) * rstd;
+  const float z = fmaf(gam, xh, bet);
+  const bool neg = act && z < 0.f;
+  sneg = fmaf(neg ? gv : 0.f, z, sneg);
+  gz = neg ? gv * slope : gv;
+}
+
+__global__ __launch_bounds__(256) void srf_gln_bwd_reduce_v4_kernel(GlnBwdArgs a, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;   // wave-uniform
+  const int c = (int)(row % a.C);
+  const long g = row / a.C;
+  const int L4 = a.L >> 2;
+  const float4* go = reinterpret_cast<const float4*>(a.gout + row * (long)a.L);
+  const float4* go2 = a.gout2 ? reinterpret_cast<const float4*>(a.gout2 + row * (long)a.L) : nullptr;
+  const float4* xr = reinterpret_cast<const float4*>(a.x + row * (long)a.L);
+  float mean, rstd;
+  srf_finalize_stats(a.nrm.sums, g, a.inv_count, mean, rstd);
+  const float gam = a.nrm.gamma[c], bet = a.nrm.beta[c];
+  const bool act = a.nrm.prelu != nullptr;
+  const float slope = act ? a.nrm.prelu[0] : 1.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int f0 = 0; f0 < L4; f0 += 256) {
+    float4 gv[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int fc = min(f0 + u * 64 + lane, L4 - 1);   // clamped: loads unconditional
+      gv[u] = go[fc];
+      xv[u] = xr[fc];
+    }
+    if (go2) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 t = go2[min(f0 + u * 64 + lane, L4 - 1)];
+        gv[u].x += t.x;
+        gv[u].y += t.y;
+        gv[u].z += t.z;
+        gv[u].w += t.w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = f0 + u * 64 + lane < L4;
+      const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+      const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xh, gz;
+        srf_gln_bwd_elem(ok ? ge[e] : 0.f, xe[e], mean, rstd, gam, bet, act, slope, xh, gz, s2);
+        s0 += gz;
+        s1 = fmaf(gz, xh, s1);
+      }
+    }
+  }
+  s0 = srf_dpp_wave_sum(s0);
+  s1 = srf_dpp_wave_sum(s1);
+  s2 = srf_dpp_wave_sum(s2);
+  if (lane == 63) {
+    float* rp = a.rowpart + row * 4;
+    rp[0] = s0;
+    rp[1] = s1;
+    rp[2] = s2;
+    double* dst = srf_stat_slot(a.bsums, g, c);
+    atomicAdd(dst, (double)gam * (double)s0);
+    atomicAdd(dst + 1, (double)gam * (double)s1);
+  }
+}
+
+__global__ __launch_bounds__(256) void srf_gln_bwd_apply_v4_kernel(GlnBwdArgs a, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;   // wave-uniform
+  const int c = (int)(row % a.C);
+  const long g = row / a.C;
+  const int L4 = a.L >> 2;
+  const float4* go = reinterpret_cast<const float4*>(a.gout + row * (long)a.L);
+  const float4* go2 = a.gout2 ? reinterpret_cast<const float4*>(a.gout2 + row * (long)a.L) : nullptr;
+  const float4* xr = reinterpret_cast<const float4*>(a.x + row * (long)a.L);
+  float4* gx = reinterpret_cast<float4*>(a.gx + row * (long)a.L);
+  // the first trip's operands are requested before the statistics are finalised
+  float4 gv[4], xv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int fc = min(u * 64 + lane, L4 - 1);
+    gv[u] = go[fc];
+    xv[u] = xr[fc];
+  }
+  float mean, rstd;
+  srf_finalize_stats(a.nrm.sums, g, a.inv_count, mean, rstd);
+  const double2 bk = reinterpret_cast<const double2*>(a.bsums)[g * SRF_STAT_BUCKETS + lane];
+  const float m1 = (float)(srf_wave_sum(bk.x) * a.inv_count), m2 = (float)(srf_wave_sum(bk.y) * a.inv_count);
+  const float gam = a.nrm.gamma[c], bet = a.nrm.beta[c];
+  const bool act = a.nrm.prelu != nullptr;
+  const float slope = act ? a.nrm.prelu[0] : 1.f;
+  for (int f0 = 0; f0 < L4; f0 += 256) {
+    if (f0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int fc = min(f0 + u * 64 + lane, L4 - 1);
+        gv[u] = go[fc];
+        xv[u] = xr[fc];
+      }
+    }
+    if (go2) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 t = go2[min(f0 + u * 64 + lane, L4 - 1)];
+        gv[u].x += t.x;
+        gv[u].y += t.y;
+        gv[u].z += t.z;
+        gv[u].w += t.w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = f0 + u * 64 + lane;
+      if (f < L4) {
+        const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+        const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xh, gz, unused = 0.f;
+          srf_gln_bwd_elem(ge[e], xe[e], mean, rstd, gam, bet, act, slope, xh, gz, unused);
+          r[e] = rstd * (gam * gz - m1 - xh * m2);
+        }
+        float4 o = make_float4(r[0], r[1], r[2], r[3]);
+        if (a.accumulate) {
+          const float4 t = gx[f];
+          o.x += t.x;
+          o.y += t.y;
+          o.z += t.z;
+          o.w += t.w;
+        }
+        gx[f] = o;
+      }
+    }
+  }
+}
+
 extern "C" size_t srf_gln_bwd_scratch_bytes(int groups, int C) {
   if (groups <= 0 || C <= 0) return 0;
   return sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2 + sizeof(float) * (size_t)groups * C * 4;
@@ -188,14 +334,23 @@ extern "C" int srf_gln_bwd(const float* gout, const float* gout2, const float* x
   a.L = L;
   a.accumulate = accumulate_gx;
   SRF_CHECK_HIP(hipMemsetAsync(a.bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
-  hipLaunchKernelGGL(srf_gln_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, a);
+  const bool v4 = (L % 4) == 0 && srf_aligned16(gout) && srf_aligned16(x) && srf_aligned16(gx) &&
+                  (!gout2 || srf_aligned16(gout2)) && srf_kernel_mode() != 1 && !(srf_debug_flags() & (1 << 30));
+  const dim3 grid4((unsigned)((rows + 3) / 4));
+  if (v4)
+    hipLaunchKernelGGL(srf_gln_bwd_reduce_v4_kernel, grid4, dim3(256), 0, st, a, rows);
+  else
+    hipLaunchKernelGGL(srf_gln_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, a);
   SRF_CHECK_LAUNCH("gln_bwd_reduce", st);
   if (dgamma || dbeta || (dslope && norm->prelu)) {
     hipLaunchKernelGGL(srf_gln_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
                        dim3(256), 0, st, a.rowpart, groups, C, dgamma, dbeta, norm->prelu ? dslope : nullptr);
     SRF_CHECK_LAUNCH("gln_bwd_params", st);
   }
-  hipLaunchKernelGGL(srf_gln_bwd_apply_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, st, a, chunks);
+  if (v4)
+    hipLaunchKernelGGL(srf_gln_bwd_apply_v4_kernel, grid4, dim3(256), 0, st, a, rows);
+  else
+    hipLaunchKernelGGL(srf_gln_bwd_apply_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, st, a, chunks);
   SRF_CHECK_LAUNCH("gln_bwd_apply", st);
   return SRF_OK;
 }
@@ -499,6 +654,149 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_fast_kernel(DwBwdArgs a) 
   }
 }
 
+// Row-per-wavefront variant of the fast kernel (same preconditions; rows that fit 32-bit float4 counts): the
+// wavefront walks its row 64 float4 at a time, keeps the six parameter sums in registers across the row and reduces
+// them once with DPP -- no LDS, no barrier, no atomics, no memset of rowpart, the statistics finalised once per row
+// instead of once per 1024 positions.  Halos between neighbouring lanes are DPP wavefront shifts; the two edge lanes
+// fetch theirs with one 8-byte (4-byte) load issued together with the main loads.
+template <int S>
+__global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;   // wave-uniform
+  const int c = (int)(row % a.C);
+  const long g = row / a.C;
+  float sc = 1.f, sh = 0.f;
+  if (a.nrm.sums) {
+    float mean, rstd;
+    srf_finalize_stats(a.nrm.sums, g, a.inv_count, mean, rstd);
+    sc = a.nrm.gamma[c] * rstd;
+    sh = a.nrm.beta[c] - mean * sc;
+  }
+  const bool act = a.nrm.prelu != nullptr;
+  const float slope = act ? a.nrm.prelu[0] : 1.f;
+  float w[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) w[t] = a.w[c * 5 + t];
+  const float* gd = a.gd + row * (long)a.Lout;
+  const float* xr = a.xin + row * (long)a.Lin;
+  float* gin = a.gin ? a.gin + row * (long)a.Lin : nullptr;
+  const int Lin = a.Lin, Lout = a.Lout, L4 = a.Lin >> 2;
+  auto pro = [&](float v) {
+    v = fmaf(v, sc, sh);
+    return act ? srf_prelu(v, slope) : v;
+  };
+  const bool edge = lane == 0 || lane == 63;
+  float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int f0 = 0; f0 < L4; f0 += 64) {
+    const int f = f0 + lane;
+    const bool valid = f < L4;
+    const int i0 = f * 4;
+    // ---- all loads of the trip first
+    const float4 xv = *reinterpret_cast<const float4*>(xr + (valid ? i0 : 0));
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 g2 = make_float2(0.f, 0.f);
+    if (S == 1)
+      g4 = *reinterpret_cast<const float4*>(gd + (valid ? i0 : 0));
+    else
+      g2 = *reinterpret_cast<const float2*>(gd + (valid ? (i0 >> 1) : 0));   // Lout = Lin/2: both outputs exist
+    // edge lanes: the two positions left of lane 0 / right of lane 63 (i0 % 4 == 0: in range together or not at all)
+    const int hi = lane == 0 ? i0 - 2 : i0 + 4;
+    const bool hok = edge && valid && hi >= 0 && hi < Lin;
+    float2 hx = make_float2(0.f, 0.f), hg = make_float2(0.f, 0.f);
+    if (hok) {
+      hx = *reinterpret_cast<const float2*>(xr + hi);
+      if (S == 1) {
+        hg = *reinterpret_cast<const float2*>(gd + hi);
+      } else {
+        const int hj = lane == 0 ? (i0 >> 1) - 1 : (i0 >> 1) + 2;   // in range exactly when hi is
+        hg.x = gd[hj];
+      }
+    }
+    // ---- prologue'd input window u[0..7] = positions i0-2 .. i0+5
+    float u[8];
+    u[2] = valid ? pro(xv.x) : 0.f;
+    u[3] = valid ? pro(xv.y) : 0.f;
+    u[4] = valid ? pro(xv.z) : 0.f;
+    u[5] = valid ? pro(xv.w) : 0.f;
+    u[0] = srf_lane_up(u[4]);
+    u[1] = srf_lane_up(u[5]);
+    u[6] = srf_lane_down(u[2]);
+    u[7] = srf_lane_down(u[3]);
+    const float e0 = hok ? pro(hx.x) : 0.f, e1 = hok ? pro(hx.y) : 0.f;
+    if (lane == 0) {
+      u[0] = e0;
+      u[1] = e1;
+    }
+    if (lane == 63) {
+      u[6] = e0;
+      u[7] = e1;
+    }
+    float gi[4];
+    if (S == 1) {
+      float gw[8];
+      gw[2] = valid ? g4.x : 0.f;
+      gw[3] = valid ? g4.y : 0.f;
+      gw[4] = valid ? g4.z : 0.f;
+      gw[5] = valid ? g4.w : 0.f;
+      gw[0] = srf_lane_up(gw[4]);
+      gw[1] = srf_lane_up(gw[5]);
+      gw[6] = srf_lane_down(gw[2]);
+      gw[7] = srf_lane_down(gw[3]);
+      if (lane == 0) {
+        gw[0] = hg.x;
+        gw[1] = hg.y;
+      }
+      if (lane == 63) {
+        gw[6] = hg.x;
+        gw[7] = hg.y;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gv = gw[e + 2];
+        p[5] += gv;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) p[t] = fmaf(gv, u[e + t], p[t]);
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc = fmaf(w[t], gw[e + 4 - t], acc);
+        gi[e] = acc;
+      }
+    } else {
+      float gq[4];
+      gq[1] = valid ? g2.x : 0.f;
+      gq[2] = valid ? g2.y : 0.f;
+      gq[0] = srf_lane_up(gq[2]);
+      gq[3] = srf_lane_down(gq[1]);
+      if (lane == 0) gq[0] = hg.x;
+      if (lane == 63) gq[3] = hg.x;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float gv = gq[q + 1];
+        p[5] += gv;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) p[t] = fmaf(gv, u[2 * q + t], p[t]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          if (((e + 2 - t) & 1) == 0) acc = fmaf(w[t], gq[(e + 2 - t) / 2 + 1], acc);   // (e+2-t) in [-2, 5]
+        }
+        gi[e] = acc;
+      }
+    }
+    if (gin && valid) *reinterpret_cast<float4*>(gin + i0) = make_float4(gi[0], gi[1], gi[2], gi[3]);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) p[k] = srf_dpp_wave_sum(p[k]);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.rowpart[row * 8 + k] = p[k];
+  }
+}
+
 // dw[c][t] += sum_g rowpart[g][c][t] (t < 5), dbias[c] += sum_g rowpart[g][c][5]; same blocking as above
 __global__ __launch_bounds__(256) void srf_dwconv5_bwd_params_kernel(const float* __restrict__ rowpart, int groups, int C,
                                                                      float* dw, float* dbias) {
@@ -564,6 +862,16 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
                     srf_kernel_mode() != 1;
   const int per_block = fast ? 1024 : 2048;
   const int chunks = (Lin + per_block - 1) / per_block;
+  // stride 2 with an odd output count (Lin % 8 == 4) keeps the chunked kernel: its float2 loads assume Lout = Lin / 2
+  const bool rowwise = fast && (stride == 1 || (Lin % 2 == 0 && a.Lout * 2 == Lin)) && !(srf_debug_flags() & (1 << 29));
+  if (rowwise) {
+    const dim3 grid4((unsigned)((rows + 3) / 4));
+    if (stride == 1)
+      hipLaunchKernelGGL(srf_dwconv5_bwd_row_kernel<1>, grid4, dim3(256), 0, st, a, rows);
+    else
+      hipLaunchKernelGGL(srf_dwconv5_bwd_row_kernel<2>, grid4, dim3(256), 0, st, a, rows);
+    SRF_CHECK_LAUNCH("dwconv5_bwd", st);
+  } else {
   if (chunks > 1) SRF_CHECK_HIP(hipMemsetAsync(a.rowpart, 0, sizeof(float) * (size_t)rows * 8, st));
   dim3 grid((unsigned)chunks, (unsigned)C, (unsigned)groups);
   if (fast && stride == 1)
@@ -575,6 +883,7 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
   else
     hipLaunchKernelGGL(srf_dwconv5_bwd_kernel<2>, grid, dim3(256), 0, st, a);
   SRF_CHECK_LAUNCH("dwconv5_bwd", st);
+  }
   if (dw || dbias) {
     hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
                        dim3(256), 0, st, a.rowpart, groups, C, dw, dbias);

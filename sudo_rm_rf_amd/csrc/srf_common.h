@@ -124,6 +124,41 @@ __device__ __forceinline__ void srf_block_stats_atomic(double s, double q, doubl
   }
 }
 
+// Neighbour-lane exchange as DPP wavefront shifts (VALU, full rate) instead of __shfl_up/down, which lower to
+// ds_bpermute_b32 (LDS pipe, ~100 cycles of latency on every level's critical path).  Lane 0 / lane 63 receive 0:
+// their chunks are halo chunks whose results are discarded, exactly as the clamped shuffle's were.
+__device__ __forceinline__ float srf_lane_up(float v) {     // lane l <- lane l-1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));   // wave_shr:1
+}
+__device__ __forceinline__ float srf_lane_down(float v) {   // lane l <- lane l+1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));   // wave_shl:1
+}
+
+// Wavefront sum with DPP row operations (VALU only; __shfl_xor lowers to ds_bpermute, an LDS-pipe
+// instruction with ~50+ cycles of latency per step).  The total ends up in lane 63.
+__device__ __forceinline__ float srf_dpp_wave_sum(float v) {
+  auto dpp = [](float x, int ctrl_id) {
+    const int xi = __float_as_int(x);
+    int r;
+    switch (ctrl_id) {
+      case 0: r = __builtin_amdgcn_update_dpp(0, xi, 0x111, 0xf, 0xf, true); break;   // row_shr:1
+      case 1: r = __builtin_amdgcn_update_dpp(0, xi, 0x112, 0xf, 0xf, true); break;   // row_shr:2
+      case 2: r = __builtin_amdgcn_update_dpp(0, xi, 0x114, 0xf, 0xf, true); break;   // row_shr:4
+      case 3: r = __builtin_amdgcn_update_dpp(0, xi, 0x118, 0xf, 0xf, true); break;   // row_shr:8
+      case 4: r = __builtin_amdgcn_update_dpp(0, xi, 0x142, 0xa, 0xf, true); break;   // row_bcast:15 -> rows 1,3
+      default: r = __builtin_amdgcn_update_dpp(0, xi, 0x143, 0xc, 0xf, true); break;  // row_bcast:31 -> rows 2,3
+    }
+    return __int_as_float(r);
+  };
+  v += dpp(v, 0);
+  v += dpp(v, 1);
+  v += dpp(v, 2);
+  v += dpp(v, 3);   // lane 15 of every row holds its row sum
+  v += dpp(v, 4);   // lanes 31 / 63 hold the sum of rows 0-1 / 2-3
+  v += dpp(v, 5);   // lane 63 holds the wavefront sum
+  return v;
+}
+
 // PReLU_a(x) = x >= 0 ? x : a x, as ONE multiply and ONE v_med3_f32 for any slope: max(x, a x) when a <= 1,
 // min(x, a x) when a > 1, i.e. the median of {x, a x, +inf} resp. {x, a x, -inf}; the third operand depends on the
 // (wave-uniform, loop-invariant) slope only.  The compare + select form costs three VALU instructions per element
