@@ -311,9 +311,11 @@ extern "C" size_t srf_gln_bwd_scratch_bytes(int groups, int C) {
 // gout (+gout2): [groups,C,L] gradient w.r.t. PReLU(GlobLN(x)) (PReLU only if norm->prelu); x: the GlobLN input;
 // norm: statistics of x, gamma, beta, slope.  gx: [groups,C,L] (accumulate_gx != 0: added to).  dgamma/dbeta [C],
 // dslope [1] are ACCUMULATED into (NULL = skip).
-extern "C" int srf_gln_bwd(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
-                           int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope,
-                           void* scratch, void* stream) {
+// pre_reduced != 0: `scratch` already holds this norm's row partials and S1/S2 buckets (written by
+// srf_dwconv5_bwd_fused for exactly this gout/x pair): parameter sums and the apply pass only.
+int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
+                     int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch,
+                     int pre_reduced, void* stream) {
   SRF_CHECK_ARG(gout && x && norm && norm->sums && norm->gamma && norm->beta && gx && scratch,
                 "srf_gln_bwd: null pointer");
   SRF_CHECK_ARG(groups > 0 && C > 0 && L > 0, "srf_gln_bwd: bad sizes");
@@ -333,15 +335,17 @@ extern "C" int srf_gln_bwd(const float* gout, const float* gout2, const float* x
   a.C = C;
   a.L = L;
   a.accumulate = accumulate_gx;
-  SRF_CHECK_HIP(hipMemsetAsync(a.bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
+  if (!pre_reduced) SRF_CHECK_HIP(hipMemsetAsync(a.bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
   const bool v4 = (L % 4) == 0 && srf_aligned16(gout) && srf_aligned16(x) && srf_aligned16(gx) &&
                   (!gout2 || srf_aligned16(gout2)) && srf_kernel_mode() != 1 && !(srf_debug_flags() & (1 << 30));
   const dim3 grid4((unsigned)((rows + 3) / 4));
-  if (v4)
-    hipLaunchKernelGGL(srf_gln_bwd_reduce_v4_kernel, grid4, dim3(256), 0, st, a, rows);
-  else
-    hipLaunchKernelGGL(srf_gln_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, a);
-  SRF_CHECK_LAUNCH("gln_bwd_reduce", st);
+  if (!pre_reduced) {
+    if (v4)
+      hipLaunchKernelGGL(srf_gln_bwd_reduce_v4_kernel, grid4, dim3(256), 0, st, a, rows);
+    else
+      hipLaunchKernelGGL(srf_gln_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, a);
+    SRF_CHECK_LAUNCH("gln_bwd_reduce", st);
+  }
   if (dgamma || dbeta || (dslope && norm->prelu)) {
     hipLaunchKernelGGL(srf_gln_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
                        dim3(256), 0, st, a.rowpart, groups, C, dgamma, dbeta, norm->prelu ? dslope : nullptr);
@@ -353,6 +357,12 @@ extern "C" int srf_gln_bwd(const float* gout, const float* gout2, const float* x
     hipLaunchKernelGGL(srf_gln_bwd_apply_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, st, a, chunks);
   SRF_CHECK_LAUNCH("gln_bwd_apply", st);
   return SRF_OK;
+}
+
+extern "C" int srf_gln_bwd(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
+                           int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope,
+                           void* scratch, void* stream) {
+  return srf_gln_bwd_impl(gout, gout2, x, norm, groups, C, L, gx, accumulate_gx, dgamma, dbeta, dslope, scratch, 0, stream);
 }
 
 // =============================================================================================
@@ -399,6 +409,10 @@ struct DwBwdArgs {
   float* gin;
   float* rowpart;   // [rows][8]
   int C, Lin, Lout, stride;
+  // fused GlobLN-backward reduction of the prologue norm (row kernel only; see srf_dwconv5_bwd_fused)
+  const float* gadd;     // optional second contribution to the prologue-output gradient, added before the store
+  float* nrm_rowpart;    // [rows][4]
+  double* nrm_bsums;     // [groups][SRF_STAT_BUCKETS][2]
 };
 
 // Block = (row, chunk of 2048 input positions); a thread owns 8 consecutive input positions i0..i0+7 and the
@@ -659,19 +673,23 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_fast_kernel(DwBwdArgs a) 
 // them once with DPP -- no LDS, no barrier, no atomics, no memset of rowpart, the statistics finalised once per row
 // instead of once per 1024 positions.  Halos between neighbouring lanes are DPP wavefront shifts; the two edge lanes
 // fetch theirs with one 8-byte (4-byte) load issued together with the main loads.
-template <int S>
+// FUSE: the gradient written is (conv input gradient + gadd) = the complete gradient w.r.t. the prologue's output, and
+// the kernel also emits what srf_gln_bwd's reduce pass would compute for that prologue norm from it (row partials +
+// S1/S2 buckets): the input tensor is in registers anyway, so the norm's backward needs no reduce pass of its own.
+template <int S, bool FUSE>
 __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, long rows) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;   // wave-uniform
   const int c = (int)(row % a.C);
   const long g = row / a.C;
-  float sc = 1.f, sh = 0.f;
+  float sc = 1.f, sh = 0.f, mean = 0.f, rstd = 1.f, gam = 1.f, bet = 0.f;
   if (a.nrm.sums) {
-    float mean, rstd;
     srf_finalize_stats(a.nrm.sums, g, a.inv_count, mean, rstd);
-    sc = a.nrm.gamma[c] * rstd;
-    sh = a.nrm.beta[c] - mean * sc;
+    gam = a.nrm.gamma[c];
+    bet = a.nrm.beta[c];
+    sc = gam * rstd;
+    sh = bet - mean * sc;
   }
   const bool act = a.nrm.prelu != nullptr;
   const float slope = act ? a.nrm.prelu[0] : 1.f;
@@ -681,6 +699,8 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, l
   const float* gd = a.gd + row * (long)a.Lout;
   const float* xr = a.xin + row * (long)a.Lin;
   float* gin = a.gin ? a.gin + row * (long)a.Lin : nullptr;
+  const float* gadd = (FUSE && a.gadd) ? a.gadd + row * (long)a.Lin : nullptr;
+  float n0 = 0.f, n1 = 0.f, n2 = 0.f;   // FUSE: sum g_z, sum g_z xh, slope term of the prologue norm
   const int Lin = a.Lin, Lout = a.Lout, L4 = a.Lin >> 2;
   auto pro = [&](float v) {
     v = fmaf(v, sc, sh);
@@ -694,6 +714,8 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, l
     const int i0 = f * 4;
     // ---- all loads of the trip first
     const float4 xv = *reinterpret_cast<const float4*>(xr + (valid ? i0 : 0));
+    float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FUSE && gadd) ga = *reinterpret_cast<const float4*>(gadd + (valid ? i0 : 0));
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 g2 = make_float2(0.f, 0.f);
     if (S == 1)
@@ -787,13 +809,41 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, l
         gi[e] = acc;
       }
     }
+    if (FUSE) {
+      gi[0] += ga.x;
+      gi[1] += ga.y;
+      gi[2] += ga.z;
+      gi[3] += ga.w;
+      const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xh, gz;
+        srf_gln_bwd_elem(valid ? gi[e] : 0.f, xe[e], mean, rstd, gam, bet, act, slope, xh, gz, n2);
+        n0 += gz;
+        n1 = fmaf(gz, xh, n1);
+      }
+    }
     if (gin && valid) *reinterpret_cast<float4*>(gin + i0) = make_float4(gi[0], gi[1], gi[2], gi[3]);
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) p[k] = srf_dpp_wave_sum(p[k]);
+  if (FUSE) {
+    n0 = srf_dpp_wave_sum(n0);
+    n1 = srf_dpp_wave_sum(n1);
+    n2 = srf_dpp_wave_sum(n2);
+  }
   if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) a.rowpart[row * 8 + k] = p[k];
+    if (FUSE) {
+      float* rp = a.nrm_rowpart + row * 4;
+      rp[0] = n0;
+      rp[1] = n1;
+      rp[2] = n2;
+      double* dst = srf_stat_slot(a.nrm_bsums, g, c);
+      atomicAdd(dst, (double)gam * (double)n0);
+      atomicAdd(dst + 1, (double)gam * (double)n1);
+    }
   }
 }
 
@@ -837,9 +887,14 @@ extern "C" size_t srf_dwconv5_bwd_scratch_bytes(int groups, int C) {
 // gd: [groups,C,Lout]; xin: [groups,C,Lin] the PRE-norm input tensor of this conv, in_norm its prologue (NULL =
 // identity); gin: [groups,C,Lin] gradient w.r.t. the prologue's OUTPUT (overwritten; NULL = skip); dw [C,5] and
 // dbias [C] are ACCUMULATED into.
-extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups,
-                               int C, int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch,
-                               void* stream) {
+// gln_scratch != NULL asks for the fused form: gin <- conv input gradient + gadd (gadd may be NULL), and the reduce
+// pass of srf_gln_bwd for the prologue norm `in_norm` over that complete gradient written into gln_scratch (layout of
+// srf_gln_bwd's scratch).  *fused reports whether that happened (row kernel preconditions); when it did not, gin
+// holds the plain conv input gradient and the caller runs the unfused sequence.
+int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups, int C,
+                         int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch, const float* gadd,
+                         void* gln_scratch, int* fused, void* stream) {
+  if (fused) *fused = 0;
   SRF_CHECK_ARG(gd && xin && w && scratch, "srf_dwconv5_bwd: null pointer");
   SRF_CHECK_ARG(groups > 0 && C > 0 && Lin > 0 && (stride == 1 || stride == 2), "srf_dwconv5_bwd: bad sizes");
   const long rows = (long)groups * C;
@@ -856,6 +911,9 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
   a.Lin = Lin;
   a.Lout = (Lin - 1) / stride + 1;
   a.stride = stride;
+  a.gadd = nullptr;
+  a.nrm_rowpart = nullptr;
+  a.nrm_bsums = nullptr;
   hipStream_t st = (hipStream_t)stream;
   SRF_CHECK_ARG(groups <= 65535 && C <= 65535, "srf_dwconv5_bwd: groups / channels exceed 65535");
   const bool fast = (Lin % 4) == 0 && srf_aligned16(gd) && srf_aligned16(xin) && (!gin || srf_aligned16(gin)) &&
@@ -866,10 +924,23 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
   const bool rowwise = fast && (stride == 1 || (Lin % 2 == 0 && a.Lout * 2 == Lin)) && !(srf_debug_flags() & (1 << 29));
   if (rowwise) {
     const dim3 grid4((unsigned)((rows + 3) / 4));
-    if (stride == 1)
-      hipLaunchKernelGGL(srf_dwconv5_bwd_row_kernel<1>, grid4, dim3(256), 0, st, a, rows);
-    else
-      hipLaunchKernelGGL(srf_dwconv5_bwd_row_kernel<2>, grid4, dim3(256), 0, st, a, rows);
+    const bool fuse = gln_scratch && gin && in_norm && in_norm->sums && in_norm->gamma && in_norm->beta &&
+                      (!gadd || srf_aligned16(gadd)) && !(srf_debug_flags() & (1 << 30));
+    if (fuse) {
+      a.gadd = gadd;
+      a.nrm_bsums = reinterpret_cast<double*>(gln_scratch);
+      a.nrm_rowpart = reinterpret_cast<float*>(a.nrm_bsums + (size_t)groups * SRF_STAT_BUCKETS * 2);
+      SRF_CHECK_HIP(hipMemsetAsync(a.nrm_bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
+      if (stride == 1)
+        hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<1, true>), grid4, dim3(256), 0, st, a, rows);
+      else
+        hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<2, true>), grid4, dim3(256), 0, st, a, rows);
+      if (fused) *fused = 1;
+    } else if (stride == 1) {
+      hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<1, false>), grid4, dim3(256), 0, st, a, rows);
+    } else {
+      hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<2, false>), grid4, dim3(256), 0, st, a, rows);
+    }
     SRF_CHECK_LAUNCH("dwconv5_bwd", st);
   } else {
   if (chunks > 1) SRF_CHECK_HIP(hipMemsetAsync(a.rowpart, 0, sizeof(float) * (size_t)rows * 8, st));
@@ -890,6 +961,13 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
     SRF_CHECK_LAUNCH("dwconv5_bwd_params", st);
   }
   return SRF_OK;
+}
+
+extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups,
+                               int C, int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch,
+                               void* stream) {
+  return srf_dwconv5_bwd_impl(gd, xin, in_norm, w, groups, C, Lin, stride, gin, dw, dbias, scratch, nullptr, nullptr,
+                              nullptr, stream);
 }
 
 // =============================================================================================

@@ -18,6 +18,12 @@
 
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
 int srf_accumulate_launch(float* dst, const float* src, long n, hipStream_t st);
+int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
+                     int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch,
+                     int pre_reduced, void* stream);
+int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups, int C,
+                         int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch, const float* gadd,
+                         void* gln_scratch, int* fused, void* stream);
 
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -357,6 +363,10 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     for (int k = 1; k < D; ++k) gn[k] = fp(s.gn[k]);
     rc = srf_merge_bwd(gf, gn, D, (long)Bg * nC, L, stream);
     if (rc) return rc;
+    // Level k's conv backward also produces the COMPLETE gradient w.r.t. its (normalised) input -- its own input
+    // gradient + the merge part gn[k-1] -- and the reduce pass of that input's GlobLN backward (the input tensor
+    // is in its registers), so the norms below level D-1 and the proj norm run their apply pass only.
+    int pre_reduced = 0;
     for (int k = D - 1; k >= 0; --k) {
       const float* const* Pk = Pu + 5 + 4 * k;   // conv.weight, conv.bias, norm.gamma, norm.beta
       float* const* Gk = Gu + 5 + 4 * k;
@@ -365,7 +375,10 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
       srf_norm nk{slot(s0 + 1 + k), Pk[2], Pk[3], nullptr};
       // gradient w.r.t. the normalised level k: merge part (gn[k]) + what level k+1's conv sent down
       const float* gu_in = (k < D - 1) ? (k == 0 ? go : fp(s.gu[k])) : nullptr;
-      rc = srf_gln_bwd(gn[k], gu_in, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, sc + s.gln, stream);
+      if (pre_reduced)   // gu_in already holds the sum of both, its reduction is in the scratch
+        rc = srf_gln_bwd_impl(gu_in, nullptr, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, sc + s.gln, 1, stream);
+      else
+        rc = srf_gln_bwd(gn[k], gu_in, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, sc + s.gln, stream);
       if (rc) return rc;
       srf_norm in;
       const float* src;
@@ -385,12 +398,14 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
         stride = 2;
         gin = (k - 1 == 0) ? go : fp(s.gu[k - 1]);   // gradient w.r.t. normalised level k-1
       }
-      rc = srf_dwconv5_bwd(gd, src, &in, Pk[0], Bg, nC, Lin, stride, gin, Gk[0], Gk[1], sc + s.dw, stream);
+      rc = srf_dwconv5_bwd_impl(gd, src, &in, Pk[0], Bg, nC, Lin, stride, gin, Gk[0], Gk[1], sc + s.dw,
+                                k > 0 ? gn[k - 1] : nullptr, sc + s.gln, &pre_reduced, stream);
       if (rc) return rc;
     }
     // proj_1x1: y1 = W_p xin + b_p, o = PReLU(GlobLN(y1))
     srf_norm pn{slot(s0), Pu[2], Pu[3], Pu[4]};
-    rc = srf_gln_bwd(go, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], sc + s.gln, stream);   // go = g_y1
+    rc = srf_gln_bwd_impl(go, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], sc + s.gln, pre_reduced,
+                          stream);   // go = g_y1
     if (rc) return rc;
     rc = srf_pw_wgrad(go, xin, nullptr, Bg, nB, nC, L, Gu[0], Gu[1], 1, wg, stream);
     if (rc) return rc;
