@@ -311,12 +311,14 @@ extern "C" size_t srf_gln_bwd_scratch_bytes(int groups, int C) {
 // gout (+gout2): [groups,C,L] gradient w.r.t. PReLU(GlobLN(x)) (PReLU only if norm->prelu); x: the GlobLN input;
 // norm: statistics of x, gamma, beta, slope.  gx: [groups,C,L] (accumulate_gx != 0: added to).  dgamma/dbeta [C],
 // dslope [1] are ACCUMULATED into (NULL = skip).
-// pre_reduced != 0: `scratch` already holds this norm's row partials and S1/S2 buckets (written by
-// srf_dwconv5_bwd_fused for exactly this gout/x pair): parameter sums and the apply pass only.
+// mode bit 0 (pre-reduced): `scratch` already holds this norm's row partials and S1/S2 buckets (written by the fused
+// srf_dwconv5_bwd_impl for exactly this gout/x pair) -- no reduce pass.  mode bit 1: no apply pass (the consumer,
+// srf_dwconv5_bwd_impl in apply-on-load form, evaluates it from `scratch`; gx may be NULL).
 int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
                      int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch,
-                     int pre_reduced, void* stream) {
-  SRF_CHECK_ARG(gout && x && norm && norm->sums && norm->gamma && norm->beta && gx && scratch,
+                     int mode, void* stream) {
+  const int pre_reduced = mode & 1, no_apply = (mode >> 1) & 1;
+  SRF_CHECK_ARG(gout && x && norm && norm->sums && norm->gamma && norm->beta && (gx || no_apply) && scratch,
                 "srf_gln_bwd: null pointer");
   SRF_CHECK_ARG(groups > 0 && C > 0 && L > 0, "srf_gln_bwd: bad sizes");
   const long rows = (long)groups * C;
@@ -336,7 +338,7 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
   a.L = L;
   a.accumulate = accumulate_gx;
   if (!pre_reduced) SRF_CHECK_HIP(hipMemsetAsync(a.bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
-  const bool v4 = (L % 4) == 0 && srf_aligned16(gout) && srf_aligned16(x) && srf_aligned16(gx) &&
+  const bool v4 = (L % 4) == 0 && srf_aligned16(gout) && srf_aligned16(x) && (!gx || srf_aligned16(gx)) &&
                   (!gout2 || srf_aligned16(gout2)) && srf_kernel_mode() != 1 && !(srf_debug_flags() & (1 << 30));
   const dim3 grid4((unsigned)((rows + 3) / 4));
   if (!pre_reduced) {
@@ -351,6 +353,7 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
                        dim3(256), 0, st, a.rowpart, groups, C, dgamma, dbeta, norm->prelu ? dslope : nullptr);
     SRF_CHECK_LAUNCH("gln_bwd_params", st);
   }
+  if (no_apply) return SRF_OK;
   if (v4)
     hipLaunchKernelGGL(srf_gln_bwd_apply_v4_kernel, grid4, dim3(256), 0, st, a, rows);
   else
@@ -413,6 +416,12 @@ struct DwBwdArgs {
   const float* gadd;     // optional second contribution to the prologue-output gradient, added before the store
   float* nrm_rowpart;    // [rows][4]
   double* nrm_bsums;     // [groups][SRF_STAT_BUCKETS][2]
+  // apply-on-load (row kernel only): gd is the gradient w.r.t. the OUTPUT of this conv's own norm `anrm`, whose input
+  // (this conv's output) is ax and whose reduced sums are a_bsums; the apply pass of srf_gln_bwd runs on load
+  const float* ax;
+  SrfNormDev anrm;
+  double a_inv_count;
+  const double* a_bsums;
 };
 
 // Block = (row, chunk of 2048 input positions); a thread owns 8 consecutive input positions i0..i0+7 and the
@@ -676,7 +685,9 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_fast_kernel(DwBwdArgs a) 
 // FUSE: the gradient written is (conv input gradient + gadd) = the complete gradient w.r.t. the prologue's output, and
 // the kernel also emits what srf_gln_bwd's reduce pass would compute for that prologue norm from it (row partials +
 // S1/S2 buckets): the input tensor is in registers anyway, so the norm's backward needs no reduce pass of its own.
-template <int S, bool FUSE>
+// APPLY: a.gd holds the gradient w.r.t. the output of the GlobLN that FOLLOWS this conv; its apply pass
+// (srf_gln_bwd_apply: g_d = rstd (gamma g_z - S1/n - xh S2/n)) runs on the loaded values, so g_d never exists in HBM.
+template <int S, bool FUSE, bool APPLY>
 __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, long rows) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -700,6 +711,24 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, l
   const float* xr = a.xin + row * (long)a.Lin;
   float* gin = a.gin ? a.gin + row * (long)a.Lin : nullptr;
   const float* gadd = (FUSE && a.gadd) ? a.gadd + row * (long)a.Lin : nullptr;
+  const float* ax = APPLY ? a.ax + row * (long)a.Lout : nullptr;
+  float amean = 0.f, arstd = 1.f, agam = 1.f, abet = 0.f, am1 = 0.f, am2 = 0.f, aslope = 1.f;
+  bool aact = false;
+  if (APPLY) {
+    srf_finalize_stats(a.anrm.sums, g, a.a_inv_count, amean, arstd);
+    const double2 bk = reinterpret_cast<const double2*>(a.a_bsums)[g * SRF_STAT_BUCKETS + lane];
+    am1 = (float)(srf_wave_sum(bk.x) * a.a_inv_count);
+    am2 = (float)(srf_wave_sum(bk.y) * a.a_inv_count);
+    agam = a.anrm.gamma[c];
+    abet = a.anrm.beta[c];
+    aact = a.anrm.prelu != nullptr;
+    aslope = aact ? a.anrm.prelu[0] : 1.f;
+  }
+  auto gd_of = [&](float gv, float x) {   // APPLY: one element of the following norm's backward
+    float xh, gz, unused = 0.f;
+    srf_gln_bwd_elem(gv, x, amean, arstd, agam, abet, aact, aslope, xh, gz, unused);
+    return arstd * (agam * gz - am1 - xh * am2);
+  };
   float n0 = 0.f, n1 = 0.f, n2 = 0.f;   // FUSE: sum g_z, sum g_z xh, slope term of the prologue norm
   const int Lin = a.Lin, Lout = a.Lout, L4 = a.Lin >> 2;
   auto pro = [&](float v) {
@@ -718,22 +747,34 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, l
     if (FUSE && gadd) ga = *reinterpret_cast<const float4*>(gadd + (valid ? i0 : 0));
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 g2 = make_float2(0.f, 0.f);
-    if (S == 1)
+    float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 d2 = make_float2(0.f, 0.f);
+    if (S == 1) {
       g4 = *reinterpret_cast<const float4*>(gd + (valid ? i0 : 0));
-    else
+      if (APPLY) d4 = *reinterpret_cast<const float4*>(ax + (valid ? i0 : 0));
+    } else {
       g2 = *reinterpret_cast<const float2*>(gd + (valid ? (i0 >> 1) : 0));   // Lout = Lin/2: both outputs exist
+      if (APPLY) d2 = *reinterpret_cast<const float2*>(ax + (valid ? (i0 >> 1) : 0));
+    }
     // edge lanes: the two positions left of lane 0 / right of lane 63 (i0 % 4 == 0: in range together or not at all)
     const int hi = lane == 0 ? i0 - 2 : i0 + 4;
     const bool hok = edge && valid && hi >= 0 && hi < Lin;
-    float2 hx = make_float2(0.f, 0.f), hg = make_float2(0.f, 0.f);
+    float2 hx = make_float2(0.f, 0.f), hg = make_float2(0.f, 0.f), hd = make_float2(0.f, 0.f);
     if (hok) {
       hx = *reinterpret_cast<const float2*>(xr + hi);
       if (S == 1) {
         hg = *reinterpret_cast<const float2*>(gd + hi);
+        if (APPLY) hd = *reinterpret_cast<const float2*>(ax + hi);
       } else {
         const int hj = lane == 0 ? (i0 >> 1) - 1 : (i0 >> 1) + 2;   // in range exactly when hi is
         hg.x = gd[hj];
+        if (APPLY) hd.x = ax[hj];
       }
+    }
+    if (APPLY) {
+      g4 = make_float4(gd_of(g4.x, d4.x), gd_of(g4.y, d4.y), gd_of(g4.z, d4.z), gd_of(g4.w, d4.w));
+      g2 = make_float2(gd_of(g2.x, d2.x), gd_of(g2.y, d2.y));
+      hg = hok ? make_float2(gd_of(hg.x, hd.x), gd_of(hg.y, hd.y)) : make_float2(0.f, 0.f);
     }
     // ---- prologue'd input window u[0..7] = positions i0-2 .. i0+5
     float u[8];
@@ -891,9 +932,21 @@ extern "C" size_t srf_dwconv5_bwd_scratch_bytes(int groups, int C) {
 // pass of srf_gln_bwd for the prologue norm `in_norm` over that complete gradient written into gln_scratch (layout of
 // srf_gln_bwd's scratch).  *fused reports whether that happened (row kernel preconditions); when it did not, gin
 // holds the plain conv input gradient and the caller runs the unfused sequence.
+// ax != NULL asks for the apply-on-load form on top (only together with the fused form; check
+// srf_dwconv5_bwd_rowwise_ok first): gd is then the gradient w.r.t. the OUTPUT of the norm `anorm` that follows this
+// conv, ax that norm's input (= this conv's output) and a_scratch its reduced sums (srf_gln_bwd_impl mode bit 1).
+bool srf_dwconv5_bwd_rowwise_ok(int Lin, int stride, const void* const* ptrs, int nptrs) {
+  if ((Lin % 4) != 0 || srf_kernel_mode() == 1 || (srf_debug_flags() & ((1 << 29) | (1 << 30)))) return false;
+  if (stride == 2 && ((Lin - 1) / 2 + 1) * 2 != Lin) return false;
+  for (int i = 0; i < nptrs; ++i)
+    if (ptrs[i] && !srf_aligned16(ptrs[i])) return false;
+  return true;
+}
+
 int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups, int C,
                          int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch, const float* gadd,
-                         void* gln_scratch, int* fused, void* stream) {
+                         void* gln_scratch, int* fused, const float* ax, const srf_norm* anorm, const void* a_scratch,
+                         void* stream) {
   if (fused) *fused = 0;
   SRF_CHECK_ARG(gd && xin && w && scratch, "srf_dwconv5_bwd: null pointer");
   SRF_CHECK_ARG(groups > 0 && C > 0 && Lin > 0 && (stride == 1 || stride == 2), "srf_dwconv5_bwd: bad sizes");
@@ -914,6 +967,10 @@ int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_n
   a.gadd = nullptr;
   a.nrm_rowpart = nullptr;
   a.nrm_bsums = nullptr;
+  a.ax = nullptr;
+  a.anrm = SrfNormDev{};
+  a.a_inv_count = 0.0;
+  a.a_bsums = nullptr;
   hipStream_t st = (hipStream_t)stream;
   SRF_CHECK_ARG(groups <= 65535 && C <= 65535, "srf_dwconv5_bwd: groups / channels exceed 65535");
   const bool fast = (Lin % 4) == 0 && srf_aligned16(gd) && srf_aligned16(xin) && (!gin || srf_aligned16(gin)) &&
@@ -921,28 +978,41 @@ int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_n
   const int per_block = fast ? 1024 : 2048;
   const int chunks = (Lin + per_block - 1) / per_block;
   // stride 2 with an odd output count (Lin % 8 == 4) keeps the chunked kernel: its float2 loads assume Lout = Lin / 2
-  const bool rowwise = fast && (stride == 1 || (Lin % 2 == 0 && a.Lout * 2 == Lin)) && !(srf_debug_flags() & (1 << 29));
+  const bool rowwise = fast && (stride == 1 || a.Lout * 2 == Lin) && !(srf_debug_flags() & (1 << 29));
   if (rowwise) {
     const dim3 grid4((unsigned)((rows + 3) / 4));
     const bool fuse = gln_scratch && gin && in_norm && in_norm->sums && in_norm->gamma && in_norm->beta &&
                       (!gadd || srf_aligned16(gadd)) && !(srf_debug_flags() & (1 << 30));
+    SRF_CHECK_ARG(!ax || (fuse && anorm && anorm->sums && anorm->gamma && anorm->beta && a_scratch && srf_aligned16(ax)),
+                  "srf_dwconv5_bwd: apply-on-load needs the fused row kernel");
     if (fuse) {
       a.gadd = gadd;
       a.nrm_bsums = reinterpret_cast<double*>(gln_scratch);
       a.nrm_rowpart = reinterpret_cast<float*>(a.nrm_bsums + (size_t)groups * SRF_STAT_BUCKETS * 2);
       SRF_CHECK_HIP(hipMemsetAsync(a.nrm_bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
-      if (stride == 1)
-        hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<1, true>), grid4, dim3(256), 0, st, a, rows);
-      else
-        hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<2, true>), grid4, dim3(256), 0, st, a, rows);
+      if (ax) {
+        a.ax = ax;
+        a.anrm = srf_norm_dev(anorm);
+        a.a_inv_count = 1.0 / ((double)C * (double)a.Lout);
+        a.a_bsums = reinterpret_cast<const double*>(a_scratch);
+        if (stride == 1)
+          hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<1, true, true>), grid4, dim3(256), 0, st, a, rows);
+        else
+          hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<2, true, true>), grid4, dim3(256), 0, st, a, rows);
+      } else if (stride == 1) {
+        hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<1, true, false>), grid4, dim3(256), 0, st, a, rows);
+      } else {
+        hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<2, true, false>), grid4, dim3(256), 0, st, a, rows);
+      }
       if (fused) *fused = 1;
     } else if (stride == 1) {
-      hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<1, false>), grid4, dim3(256), 0, st, a, rows);
+      hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<1, false, false>), grid4, dim3(256), 0, st, a, rows);
     } else {
-      hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<2, false>), grid4, dim3(256), 0, st, a, rows);
+      hipLaunchKernelGGL((srf_dwconv5_bwd_row_kernel<2, false, false>), grid4, dim3(256), 0, st, a, rows);
     }
     SRF_CHECK_LAUNCH("dwconv5_bwd", st);
   } else {
+    SRF_CHECK_ARG(!ax, "srf_dwconv5_bwd: apply-on-load needs the fused row kernel");
   if (chunks > 1) SRF_CHECK_HIP(hipMemsetAsync(a.rowpart, 0, sizeof(float) * (size_t)rows * 8, st));
   dim3 grid((unsigned)chunks, (unsigned)C, (unsigned)groups);
   if (fast && stride == 1)
@@ -967,7 +1037,7 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
                                int C, int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch,
                                void* stream) {
   return srf_dwconv5_bwd_impl(gd, xin, in_norm, w, groups, C, Lin, stride, gin, dw, dbias, scratch, nullptr, nullptr,
-                              nullptr, stream);
+                              nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // =============================================================================================

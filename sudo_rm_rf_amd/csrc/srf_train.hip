@@ -20,10 +20,12 @@ int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t s
 int srf_accumulate_launch(float* dst, const float* src, long n, hipStream_t st);
 int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
                      int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch,
-                     int pre_reduced, void* stream);
+                     int mode, void* stream);
+bool srf_dwconv5_bwd_rowwise_ok(int Lin, int stride, const void* const* ptrs, int nptrs);
 int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups, int C,
                          int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch, const float* gadd,
-                         void* gln_scratch, int* fused, void* stream);
+                         void* gln_scratch, int* fused, const float* ax, const srf_norm* anorm, const void* a_scratch,
+                         void* stream);
 
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -69,7 +71,7 @@ static TrainLayout train_layout(const srf_plan* p) {
 
 struct ScratchLayout {
   size_t dec, gv, genc, gxa, gxb, gf, go, gd, gn[SRF_MAX_DEPTH], gu[SRF_MAX_DEPTH], frames, wt, zeros, wdpad, wg,
-      gln, dw, gq, gxm, tac, total;
+      gln, gln2, dw, gq, gxm, tac, total;
   int dec_rows;
 };
 
@@ -122,6 +124,7 @@ static ScratchLayout scratch_layout(const srf_plan* p) {
   s.wg = take(wg);
   s.gln = take(max3(srf_gln_bwd_scratch_bytes(p->Bg, p->nC), srf_gln_bwd_scratch_bytes(p->Bt, N),
                     srf_gln_bwd_scratch_bytes(p->Bg, p->nB)));
+  s.gln2 = take(srf_gln_bwd_scratch_bytes(p->Bg, p->nC));   // the pyramid's norms alternate between gln and gln2
   s.dw = take(srf_dwconv5_bwd_scratch_bytes(p->Bg, p->nC));
   const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;
   s.gq = gc ? take(F * Bt * B * L) : 0;
@@ -365,8 +368,12 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     if (rc) return rc;
     // Level k's conv backward also produces the COMPLETE gradient w.r.t. its (normalised) input -- its own input
     // gradient + the merge part gn[k-1] -- and the reduce pass of that input's GlobLN backward (the input tensor
-    // is in its registers), so the norms below level D-1 and the proj norm run their apply pass only.
-    int pre_reduced = 0;
+    // is in its registers); and it evaluates the apply pass of its OWN level's norm on load.  So per level: one
+    // parameter-sum kernel + one conv-backward kernel, g_d never written; only the deepest level needs a reduce
+    // pass.  The two norm scratch areas alternate (level k's sums are read while level k-1's are written).
+    int pre_reduced = 0, pp = 0;
+    char* gsc[2] = {sc + s.gln, sc + s.gln2};
+    const float* g_o = go;   // where level 0's conv leaves the gradient w.r.t. o = PReLU(GlobLN(y1))
     for (int k = D - 1; k >= 0; --k) {
       const float* const* Pk = Pu + 5 + 4 * k;   // conv.weight, conv.bias, norm.gamma, norm.beta
       float* const* Gk = Gu + 5 + 4 * k;
@@ -375,11 +382,8 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
       srf_norm nk{slot(s0 + 1 + k), Pk[2], Pk[3], nullptr};
       // gradient w.r.t. the normalised level k: merge part (gn[k]) + what level k+1's conv sent down
       const float* gu_in = (k < D - 1) ? (k == 0 ? go : fp(s.gu[k])) : nullptr;
-      if (pre_reduced)   // gu_in already holds the sum of both, its reduction is in the scratch
-        rc = srf_gln_bwd_impl(gu_in, nullptr, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, sc + s.gln, 1, stream);
-      else
-        rc = srf_gln_bwd(gn[k], gu_in, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, sc + s.gln, stream);
-      if (rc) return rc;
+      const float* gout1 = pre_reduced ? gu_in : gn[k];    // pre-reduced: gu_in already holds the sum of both
+      const float* gout2 = pre_reduced ? nullptr : gu_in;
       srf_norm in;
       const float* src;
       int Lin, stride;
@@ -389,7 +393,7 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
         src = y1;
         Lin = L;
         stride = 1;
-        gin = go;       // gradient w.r.t. o = PReLU(GlobLN(y1)) (go was consumed as gu_in just above)
+        gin = go;       // gradient w.r.t. o = PReLU(GlobLN(y1)) (go is consumed as gu_in by this level first)
       } else {
         const float* const* Pprev = Pu + 5 + 4 * (k - 1);
         in = srf_norm{slot(s0 + k), Pprev[2], Pprev[3], nullptr};
@@ -398,13 +402,26 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
         stride = 2;
         gin = (k - 1 == 0) ? go : fp(s.gu[k - 1]);   // gradient w.r.t. normalised level k-1
       }
-      rc = srf_dwconv5_bwd_impl(gd, src, &in, Pk[0], Bg, nC, Lin, stride, gin, Gk[0], Gk[1], sc + s.dw,
-                                k > 0 ? gn[k - 1] : nullptr, sc + s.gln, &pre_reduced, stream);
+      const float* gadd = k > 0 ? gn[k - 1] : nullptr;
+      // apply-on-load reads gout1 (with halos) while the same kernel writes gin: at level 0 both would be `go`, so
+      // the input gradient goes to the g_d buffer instead, which the on-load form leaves unused
+      if (k == 0 && !gout2 && gout1 == go) gin = gd;
+      const void* ptrs[5] = {gout1, dk, src, gin, gadd};
+      const bool on_load = !gout2 && gout1 != gin && srf_dwconv5_bwd_rowwise_ok(Lin, stride, ptrs, 5);
+      if (!on_load && k == 0) gin = go;
+      if (k == 0) g_o = gin;
+      rc = srf_gln_bwd_impl(gout1, gout2, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, gsc[pp],
+                            (pre_reduced ? 1 : 0) | (on_load ? 2 : 0), stream);
       if (rc) return rc;
+      rc = srf_dwconv5_bwd_impl(on_load ? gout1 : gd, src, &in, Pk[0], Bg, nC, Lin, stride, gin, Gk[0], Gk[1], sc + s.dw,
+                                gadd, gsc[pp ^ 1], &pre_reduced, on_load ? dk : nullptr, on_load ? &nk : nullptr,
+                                on_load ? gsc[pp] : nullptr, stream);
+      if (rc) return rc;
+      pp ^= 1;
     }
     // proj_1x1: y1 = W_p xin + b_p, o = PReLU(GlobLN(y1))
     srf_norm pn{slot(s0), Pu[2], Pu[3], Pu[4]};
-    rc = srf_gln_bwd_impl(go, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], sc + s.gln, pre_reduced,
+    rc = srf_gln_bwd_impl(g_o, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], gsc[pp], pre_reduced,
                           stream);   // go = g_y1
     if (rc) return rc;
     rc = srf_pw_wgrad(go, xin, nullptr, Bg, nB, nC, L, Gu[0], Gu[1], 1, wg, stream);
