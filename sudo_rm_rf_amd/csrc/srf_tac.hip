@@ -358,17 +358,24 @@ struct TacBwdArgs {
   int G, L;
 };
 
+// Register budget: the first version kept pz[H], gz[H] and every weight of the fully unrolled loops alive (256 VGPRs,
+// 630 spilled SGPRs, ONE wavefront per SIMD at n = 16: 1.47 ms per launch on cfg 3).  Now two rolled loops over the
+// hidden units with O(n) live values each: loop A computes pz_j -> z_j, zbar_j and accumulates the output layer and
+// this lane's slice of the q path on the fly; loop B RECOMPUTES pz_j from x (n FMAs -- cheaper than keeping or
+// re-reading it) and folds g_z_j straight into g_pz_j and g_x.  Wo is staged in LDS transposed ([j][i], both halves) so
+// a hidden unit's n weights are one broadcast 16-byte-vector read; Wi rows are scalar loads.
 template <int NN, int G>
 __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, const float* __restrict__ wi,
                                                                 const float* __restrict__ bi,
                                                                 const float* __restrict__ wo,
                                                                 const float* __restrict__ bo,
                                                                 const float* __restrict__ wi2,
-                                                                const float* __restrict__ wo2) {
+                                                                const float* __restrict__ bi2) {
   constexpr int HH = 3 * NN, CW = 64 / G, JPL = (HH + G - 1) / G;
   constexpr int PM = HH + 4, PO = NN + 4;
   __shared__ __attribute__((aligned(16))) float s_wm[HH * PM];   // Wm[j][i]
   __shared__ __attribute__((aligned(16))) float s_wq[HH * PO];   // Wo[i][H + j] stored as [j][i]
+  __shared__ __attribute__((aligned(16))) float s_wd[HH * PO];   // Wo[i][j]     stored as [j][i]
   __shared__ float s_bm[HH];
   __shared__ float s_red[4][3];
 
@@ -380,6 +387,7 @@ __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, co
   for (int e = tid; e < HH * NN; e += 256) {
     const int j = e / NN, i = e % NN;
     s_wq[j * PO + i] = wo[i * 2 * HH + HH + j];
+    s_wd[j * PO + i] = wo[i * 2 * HH + j];
   }
   for (int e = tid; e < HH; e += 256) s_bm[e] = a.bm[e];
   __syncthreads();
@@ -398,17 +406,18 @@ __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, co
 #pragma unroll
     for (int i = 0; i < NN; ++i) x[i] = a.x[(rowg * NN + i) * L + lc];
 
-    // ---- forward recompute: pz, zbar (written by the lane that owns the hidden unit), this lane's slice of pq
-    float pz[HH], qacc[JPL];
+    // ---- loop A: pz_j, z_j, zbar_j; output-layer pre-activation and this lane's slice of pq accumulate on the fly
+    float po[NN], qacc[JPL];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) po[i] = 0.f;
 #pragma unroll
     for (int t = 0; t < JPL; ++t) qacc[t] = 0.f;
-#pragma unroll
+#pragma unroll 2
     for (int j = 0; j < HH; ++j) {
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < NN; ++i) t = fmaf(wi[j * NN + i], x[i], t);
-      pz[j] = t + bi[j];
-      const float zj = srf_prelu(pz[j], ai);
+      const float zj = srf_prelu(t + bi[j], ai);
       const float zb = srf_group_allsum<G>(zj) * (1.f / (float)G);
       if (valid) {
         a.Z[(rowg * HH + j) * L + l] = zj;
@@ -419,6 +428,9 @@ __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, co
         const int jr = jrow + t2 < HH ? jrow + t2 : HH - 1;
         qacc[t2] = fmaf(s_wm[jr * PM + j], zb, qacc[t2]);
       }
+      const float* wd = s_wd + j * PO;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) po[i] = fmaf(wd[i], zj, po[i]);
     }
     float pq[JPL], r[NN];
 #pragma unroll
@@ -435,36 +447,18 @@ __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, co
 #pragma unroll
       for (int i = 0; i < NN; ++i) r[i] = fmaf(wq[i], qv, r[i]);
     }
-#pragma unroll
-    for (int i = 0; i < NN; ++i) r[i] = srf_group_allsum<G>(r[i]);
 
     // ---- output layer backward
     float gpo[NN], gs[NN];
 #pragma unroll
     for (int i = 0; i < NN; ++i) {
-      float po = 0.f;
-#pragma unroll
-      for (int j = 0; j < HH; ++j) po = fmaf(wo[i * 2 * HH + j], srf_prelu(pz[j], ai), po);
-      po = (po + r[i]) + bo[i];
+      const float pv = (po[i] + srf_group_allsum<G>(r[i])) + bo[i];
       const float gv = valid ? a.go[(rowg * NN + i) * L + lc] : 0.f;
-      gpo[i] = po >= 0.f ? gv : gv * ao;
-      if (po < 0.f) d_ao = fmaf(gv, po, d_ao);
+      gpo[i] = pv >= 0.f ? gv : gv * ao;
+      if (pv < 0.f) d_ao = fmaf(gv, pv, d_ao);
       if (valid) a.GPO[(rowg * NN + i) * L + l] = gpo[i];
       gs[i] = srf_group_allsum<G>(gpo[i]);
       if (valid && g == 0) a.GS[((size_t)b * NN + i) * L + l] = gs[i];
-    }
-    // Second use of Wo / Wi: through opaque copies of the pointers, so that the compiler RE-LOADS the weights
-    // (scalar loads, cheap) instead of keeping all 2300 of them alive from their first use -- which it did by
-    // spilling ~1450 SGPRs into VGPR lanes (256 VGPRs, occupancy 1).
-    // (wo2 / wi2 are the same arrays passed a second time as separate noalias kernel arguments.)
-    // g_z (direct part) = Wo[:, :H]^T g_po
-    float gz[HH];
-#pragma unroll
-    for (int j = 0; j < HH; ++j) {
-      float t = 0.f;
-#pragma unroll
-      for (int i = 0; i < NN; ++i) t = fmaf(wo2[i * 2 * HH + j], gpo[i], t);
-      gz[j] = t;
     }
     // this lane's slice of g_pq = PReLU'(pq) * (Wo[:, H:]^T sum_g g_po)
     float gpq[JPL];
@@ -483,26 +477,30 @@ __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, co
         a.GPQ[((size_t)b * HH + jc) * L + l] = gpq[t];
       }
     }
-    // g_zbar = Wm^T g_pq (hidden units split over the G lanes, then all-reduced); g_z += g_zbar / G
+    // ---- loop B: g_z_j = Wo[:, j]^T g_po + (Wm[:, j]^T g_pq summed over the group) / G -> g_pz_j -> g_x
+    float gx[NN];
 #pragma unroll
-    for (int i = 0; i < HH; ++i) {
+    for (int i = 0; i < NN; ++i) gx[i] = 0.f;
+#pragma unroll 2
+    for (int j = 0; j < HH; ++j) {
+      float pz = 0.f;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) pz = fmaf(wi2[j * NN + i], x[i], pz);
+      pz += bi2[j];
+      const float* wd = s_wd + j * PO;
+      float gz = 0.f;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) gz = fmaf(wd[i], gpo[i], gz);
       float t = 0.f;
 #pragma unroll
       for (int t2 = 0; t2 < JPL; ++t2) {
         const int jr = jrow + t2 < HH ? jrow + t2 : HH - 1;
-        t = fmaf(s_wm[jr * PM + i], gpq[t2], t);
+        t = fmaf(s_wm[jr * PM + j], gpq[t2], t);
       }
-      gz[i] = fmaf(srf_group_allsum<G>(t), 1.f / (float)G, gz[i]);
-    }
-    // input layer backward
-    float gx[NN];
-#pragma unroll
-    for (int i = 0; i < NN; ++i) gx[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < HH; ++j) {
-      const float gp = pz[j] >= 0.f ? gz[j] : gz[j] * ai;
+      gz = fmaf(srf_group_allsum<G>(t), 1.f / (float)G, gz);
+      const float gp = pz >= 0.f ? gz : gz * ai;
       if (valid) {
-        if (pz[j] < 0.f) d_ai = fmaf(gz[j], pz[j], d_ai);
+        if (pz < 0.f) d_ai = fmaf(gz, pz, d_ai);
         a.GPZ[(rowg * HH + j) * L + l] = gp;
       }
 #pragma unroll
@@ -540,7 +538,7 @@ static bool srf_tac_bwd_g(const TacBwdArgs& a, const float* const* P, int Bt, hi
   {                                                                                                          \
     constexpr int CW = 64 / GG;                                                                              \
     dim3 grid((a.L + 4 * CW - 1) / (4 * CW), Bt);                                                            \
-    hipLaunchKernelGGL((srf_tac_bwd_lanes_kernel<NN, GG>), grid, dim3(256), 0, st, a, P[0], P[1], P[6], P[7], P[0], P[6]); \
+    hipLaunchKernelGGL((srf_tac_bwd_lanes_kernel<NN, GG>), grid, dim3(256), 0, st, a, P[0], P[1], P[6], P[7], P[0], P[1]); \
     return true;                                                                                             \
   }
   switch (a.G) {
