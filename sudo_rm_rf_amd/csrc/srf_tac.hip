@@ -128,7 +128,28 @@ __device__ __forceinline__ float srf_group_allsum(float v) {
   return v;
 }
 
-template <int NN, int G>
+// TW time steps per lane (1 | 2): with TW = 2 every matrix-vector FMA is a v_pk_fma_f32 (two fp32 FMAs per lane and
+// issue slot, the weight a broadcast SGPR) and the loads / stores are 8-byte; the kernel is VALU-bound (n = 16, G = 16:
+// ~2300 VALU instructions per wavefront and time-step group, 150 us per launch at TW = 1), the group all-sums stay per
+// component.  TW = 2 needs an even L.
+template <int TW>
+struct SrfTacVec {
+  typedef float type __attribute__((ext_vector_type(TW)));
+};
+template <int TW, int G>
+__device__ __forceinline__ typename SrfTacVec<TW>::type srf_group_allsum_v(typename SrfTacVec<TW>::type v) {
+#pragma unroll
+  for (int u = 0; u < TW; ++u) v[u] = srf_group_allsum<G>(v[u]);
+  return v;
+}
+template <int TW>
+__device__ __forceinline__ typename SrfTacVec<TW>::type srf_prelu_v(typename SrfTacVec<TW>::type v, float a) {
+#pragma unroll
+  for (int u = 0; u < TW; ++u) v[u] = srf_prelu(v[u], a);
+  return v;
+}
+
+template <int NN, int G, int TW>
 __global__ __launch_bounds__(256) void srf_tac_lanes_kernel(
     TacArgs a, int tiles_per_block,
     // the weights again as noalias kernel arguments: only then does the compiler know the stores to q
@@ -136,10 +157,12 @@ __global__ __launch_bounds__(256) void srf_tac_lanes_kernel(
     // VMEM loads (measured in the ISA: 431 global_load + 654 v_mov per tile without this)
     const float* __restrict__ wi, const float* __restrict__ bi, const float* __restrict__ wo,
     const float* __restrict__ bo) {
+  typedef typename SrfTacVec<TW>::type vT;
   constexpr int HH = 3 * NN, CW = 64 / G, JPL = (HH + G - 1) / G;
   constexpr int PM = HH + 4, PO = NN + 4;   // LDS row pitches (floats), 16-B aligned rows
   __shared__ __attribute__((aligned(16))) float s_wm[HH * PM];   // Wm[j][i]
   __shared__ __attribute__((aligned(16))) float s_wq[HH * PO];   // Wo[i][H + j] stored as [j][i]
+  __shared__ __attribute__((aligned(16))) float s_wd[HH * PO];   // Wo[i][j]     stored as [j][i]
   __shared__ float s_bm[HH];
   __shared__ float s_red[4][G][2];
 
@@ -151,6 +174,7 @@ __global__ __launch_bounds__(256) void srf_tac_lanes_kernel(
   for (int e = tid; e < HH * NN; e += 256) {
     const int j = e / NN, i = e % NN;
     s_wq[j * PO + i] = a.wo[i * 2 * HH + HH + j];
+    s_wd[j * PO + i] = a.wo[i * 2 * HH + j];
   }
   for (int e = tid; e < HH; e += 256) s_bm[e] = a.bm[e];
   __syncthreads();
@@ -161,63 +185,70 @@ __global__ __launch_bounds__(256) void srf_tac_lanes_kernel(
   float ss = 0.f, sq = 0.f;
 
   for (int it = 0; it < tiles_per_block; ++it) {
-    const int l0 = ((blockIdx.x * tiles_per_block + it) * 4 + wave) * CW;   // wave-uniform
+    const int l0 = ((blockIdx.x * tiles_per_block + it) * 4 + wave) * (CW * TW);   // wave-uniform
     if (l0 >= L) break;
-    const int l = l0 + c;
-    const bool valid = l < L;
-    const int lc = valid ? l : L - 1;
+    const int l = l0 + c * TW;
+    const bool valid = l < L;              // TW = 2: L is even, both time steps are in range together
+    const int lc = valid ? l : L - TW;
 
-    float x[NN];
+    vT x[NN];
 #pragma unroll
-    for (int i = 0; i < NN; ++i) x[i] = xb[(size_t)i * L + lc];
+    for (int i = 0; i < NN; ++i) x[i] = *reinterpret_cast<const vT*>(xb + (size_t)i * L + lc);
 
     // z_g = PReLU(Wi x_g + bi); zbar = mean_g z_g is consumed on the fly by this lane's JPL rows of Wm
-    float z[HH], qacc[JPL];
+    // (rolled: the fully unrolled form kept z[H] and all H*n output weights alive -- 107 VGPRs + spilled SGPRs at
+    // n = 16; the output layer's direct part Wo[:, :H] z accumulates on the fly from the transposed LDS copy)
+    vT o[NN], qacc[JPL];
 #pragma unroll
-    for (int t = 0; t < JPL; ++t) qacc[t] = 0.f;
+    for (int i = 0; i < NN; ++i) o[i] = (vT)(0.f);
+#pragma unroll
+    for (int t = 0; t < JPL; ++t) qacc[t] = (vT)(0.f);
     const int jrow = g * JPL;
-#pragma unroll
+#pragma unroll 2
     for (int j = 0; j < HH; ++j) {
-      float t = 0.f;
+      vT t = (vT)(0.f);
 #pragma unroll
-      for (int i = 0; i < NN; ++i) t = fmaf(wi[j * NN + i], x[i], t);
-      z[j] = srf_prelu(t + bi[j], ai);
-      const float zb = srf_group_allsum<G>(z[j]) * (1.f / (float)G);
+      for (int i = 0; i < NN; ++i) t = __builtin_elementwise_fma((vT)(wi[j * NN + i]), x[i], t);
+      const vT zj = srf_prelu_v<TW>(t + (vT)(bi[j]), ai);
+      const vT zb = srf_group_allsum_v<TW, G>(zj) * (vT)(1.f / (float)G);
 #pragma unroll
       for (int t2 = 0; t2 < JPL; ++t2) {
         const int jr = jrow + t2 < HH ? jrow + t2 : HH - 1;
-        qacc[t2] = fmaf(s_wm[jr * PM + j], zb, qacc[t2]);
+        qacc[t2] = __builtin_elementwise_fma((vT)(s_wm[jr * PM + j]), zb, qacc[t2]);
       }
+      const float* wd = s_wd + j * PO;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) o[i] = __builtin_elementwise_fma((vT)(wd[i]), zj, o[i]);
     }
 
     // this lane's slice of q = PReLU(Wm zbar + bm) and of r = Wo[:, H:2H] q
-    float r[NN];
+    vT r[NN];
 #pragma unroll
-    for (int i = 0; i < NN; ++i) r[i] = 0.f;
+    for (int i = 0; i < NN; ++i) r[i] = (vT)(0.f);
 #pragma unroll
     for (int t = 0; t < JPL; ++t) {
       const bool jm = jrow + t < HH;
       const int jc = jm ? jrow + t : HH - 1;
-      float qv = srf_prelu(qacc[t] + s_bm[jc], am);
-      qv = jm ? qv : 0.f;
+      vT qv = srf_prelu_v<TW>(qacc[t] + (vT)(s_bm[jc]), am);
+      qv = jm ? qv : (vT)(0.f);
       const float* wq = s_wq + jc * PO;
 #pragma unroll
-      for (int i = 0; i < NN; ++i) r[i] = fmaf(wq[i], qv, r[i]);
+      for (int i = 0; i < NN; ++i) r[i] = __builtin_elementwise_fma((vT)(wq[i]), qv, r[i]);
     }
 #pragma unroll
-    for (int i = 0; i < NN; ++i) r[i] = srf_group_allsum<G>(r[i]);
+    for (int i = 0; i < NN; ++i) r[i] = srf_group_allsum_v<TW, G>(r[i]);
 
     // o_g = PReLU(Wo[:, :H] z_g + r + bo)
 #pragma unroll
     for (int i = 0; i < NN; ++i) {
-      float o = 0.f;
-#pragma unroll
-      for (int j = 0; j < HH; ++j) o = fmaf(wo[i * 2 * HH + j], z[j], o);
-      const float v = srf_prelu((o + r[i]) + bo[i], ao);
+      const vT v = srf_prelu_v<TW>((o[i] + r[i]) + (vT)(bo[i]), ao);
       if (valid) {
-        qb[(size_t)i * L + l] = v;
-        ss += v;
-        sq = fmaf(v, v, sq);
+        *reinterpret_cast<vT*>(qb + (size_t)i * L + l) = v;
+#pragma unroll
+        for (int u = 0; u < TW; ++u) {
+          ss += v[u];
+          sq = fmaf(v[u], v[u], sq);
+        }
       }
     }
   }
@@ -251,7 +282,8 @@ __global__ __launch_bounds__(256) void srf_tac_lanes_kernel(
 template <int NN, int G>
 static void srf_tac_lanes_go(const TacArgs& a, int Bt, hipStream_t st) {
   constexpr int CW = 64 / G;
-  const int tiles = (a.L + 4 * CW - 1) / (4 * CW);   // block-tiles (4 wavefronts x CW columns) per row
+  const int TW = (a.L % 2 == 0 && !(srf_debug_flags() & 1024)) ? 2 : 1;   // debug flag 1024: one time step per lane
+  const int tiles = (a.L + 4 * CW * TW - 1) / (4 * CW * TW);   // block-tiles (4 wavefronts x CW*TW columns) per row
   // enough blocks to keep >= ~8 per CU in flight, otherwise fold tiles into one block (fewer atomics,
   // weight staging amortised)
   int tpb = 1;
@@ -259,7 +291,10 @@ static void srf_tac_lanes_go(const TacArgs& a, int Bt, hipStream_t st) {
   if (srf_debug_flags() & (1 << 25)) tpb = 1;
   if (srf_debug_flags() & (1 << 26)) tpb = 4;
   dim3 grid((tiles + tpb - 1) / tpb, Bt), block(256);
-  hipLaunchKernelGGL((srf_tac_lanes_kernel<NN, G>), grid, block, 0, st, a, tpb, a.wi, a.bi, a.wo, a.bo);
+  if (TW == 2)
+    hipLaunchKernelGGL((srf_tac_lanes_kernel<NN, G, 2>), grid, block, 0, st, a, tpb, a.wi, a.bi, a.wo, a.bo);
+  else
+    hipLaunchKernelGGL((srf_tac_lanes_kernel<NN, G, 1>), grid, block, 0, st, a, tpb, a.wi, a.bi, a.wo, a.bo);
 }
 
 template <int NN>
