@@ -232,8 +232,14 @@ class ModelEngine:
         skew = (batch - (3 * batch) // 8, (3 * batch) // 8)
         if _SPLIT_MODE == "half":
             return [half]
-        if _SPLIT_MODE == "5:3":
-            return [skew]
+        if ":" in _SPLIT_MODE:          # explicit weights, e.g. "5:3" or "1:1:1" (experiments)
+            wts = [int(v) for v in _SPLIT_MODE.split(":")]
+            parts, left = [], batch
+            for i, wv in enumerate(wts):
+                n = left if i == len(wts) - 1 else max(1, round(batch * wv / sum(wts)))
+                parts.append(min(n, left - (len(wts) - 1 - i)))
+                left -= parts[-1]
+            return [tuple(parts)]
         return [(batch,), half, skew] if skew != half else [(batch,), half]
 
     def _forward_split(self, parts, x, out, table):
@@ -242,7 +248,9 @@ class ModelEngine:
             self.plan_for(parts[0], x.shape[-1], dev).forward(table, x, out)
             return
         cur = torch.cuda.current_stream(dev)
-        streams = self._side_streams.setdefault(dev.index, [torch.cuda.Stream(dev) for _ in range(2)])
+        streams = self._side_streams.setdefault(dev.index, [])
+        while len(streams) < len(parts):
+            streams.append(torch.cuda.Stream(dev))
         lo = 0
         for lane, n in enumerate(parts):
             st = streams[lane]
