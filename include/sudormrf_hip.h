@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 6
+#define SRF_ABI_VERSION 7
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -199,6 +199,11 @@ int srf_tac(const float* x, float* q, const float* const* params, int Bt, int G,
 /* pr + w * (mix - sum_s pr), uniform weights (w = 1/S).  pr,out: [Bt,S,T], mix: [Bt,1,T]. */
 int srf_mixture_consistency(const float* pr, const float* mix, float* out, int Bt, int S, int T,
                             void* stream);
+
+/* The 'magsq' variant (mixture_consistency.py:26-28): w[b,s] = mean_t pr[b,s]^2 / (sum_s mean_t pr[b,s]^2 + 1e-9).
+ * work: Bt*S floats of device scratch (receives the per-source energies). */
+int srf_mixture_consistency_magsq(const float* pr, const float* mix, float* out, int Bt, int S, int T, float* work,
+                                  void* stream);
 
 /* Caller-side pre/post-processing that every user of the reference wraps around model() (README.md:100-114,
  * experiments/simple_whamr_evaluation.py:142-148):

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 STAT_BUCKETS = 64
 
 SRF_OK = 0
@@ -98,6 +98,7 @@ _PROTOS = {
     "srf_decoder": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "srf_tac": (_i, [_vp, _vp, C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp]),
     "srf_mixture_consistency": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "srf_mixture_consistency_magsq": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

@@ -128,6 +128,52 @@ extern "C" int srf_mixture_consistency(const float* pr, const float* mix, float*
   return SRF_OK;
 }
 
+// ---- mixture consistency, 'magsq' weights (mixture_consistency.py:26-28) --------------------------
+// w[b,s] = E[b,s] / (sum_s E[b,s] + 1e-9), E = mean_t pr^2.  Pass 1: one block per (b,s) row, fp64 sum of squares
+// -> E as fp32 (the reference's torch.mean is fp32 as well); pass 2: the correction with the per-row weights.
+__global__ __launch_bounds__(256) void srf_row_meansq_kernel(const float* __restrict__ x, float* __restrict__ e, int T) {
+  __shared__ double red[4];
+  const float* xr = x + (size_t)blockIdx.x * T;
+  double q = 0.0;
+  for (int t = threadIdx.x; t < T; t += 256) q += (double)xr[t] * (double)xr[t];
+  q = srf_wave_sum(q);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) e[blockIdx.x] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)T);
+}
+
+__global__ __launch_bounds__(256) void srf_mixcons_magsq_kernel(const float* __restrict__ pr, const float* __restrict__ mix,
+                                                                const float* __restrict__ e, float* __restrict__ out,
+                                                                int S, int T, long total /* Bt*T */) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / T;
+  const int t = (int)(i - b * T);
+  const float* p = pr + (size_t)b * S * T + t;
+  const float* eb = e + b * S;
+  float sum = 0.f, esum = 0.f;
+  for (int s = 0; s < S; ++s) {
+    sum += p[(size_t)s * T];
+    esum += eb[s];
+  }
+  const float resid = mix[i] - sum;
+  float* o = out + (size_t)b * S * T + t;
+  for (int s = 0; s < S; ++s) o[(size_t)s * T] = p[(size_t)s * T] + (eb[s] / (esum + 1e-9f)) * resid;
+}
+
+extern "C" int srf_mixture_consistency_magsq(const float* pr, const float* mix, float* out, int Bt, int S, int T,
+                                             float* work, void* stream) {
+  SRF_CHECK_ARG(pr && mix && out && work && Bt > 0 && S > 0 && T > 0, "srf_mixture_consistency_magsq: bad arguments");
+  SRF_CHECK_ARG((long)Bt * S < (1L << 31), "srf_mixture_consistency_magsq: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(srf_row_meansq_kernel, dim3((unsigned)(Bt * S)), dim3(256), 0, st, pr, work, T);
+  const long total = (long)Bt * T;
+  hipLaunchKernelGGL(srf_mixcons_magsq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pr, mix, work,
+                     out, S, T, total);
+  SRF_CHECK_LAUNCH("mixture_consistency_magsq", stream);
+  return SRF_OK;
+}
+
 // ---- decoder helpers ---------------------------------------------------------------------------
 // wt[m][ci] = w[ci][m]   (w: [Ci][M] = ConvTranspose1d weight with (o,k) flattened to m)
 __global__ __launch_bounds__(256) void srf_transpose_kernel(const float* __restrict__ w,

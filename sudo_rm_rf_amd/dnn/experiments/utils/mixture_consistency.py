@@ -2,7 +2,8 @@
 
 ``apply(pr_batch, input_mixture, mix_weights_type='uniform')`` -- same signature and errors.  The
 uniform case (the only one the reference's runners use, run_sudormrf_gc_v2.py:154-155) is one HIP
-kernel; 'magsq' is not on the hot path and raises NotImplementedError.  The GroupComm runner applies it INSIDE the
+kernel; 'magsq' (per-source energy weights) is two (row energies, correction) and inference-only: it raises under
+autograd, no runner trains through it.  The GroupComm runner applies the uniform form INSIDE the
 training graph (between the model and the loss), so it carries autograd: the map is linear in the estimates,
 out = pr + (mix - sum_s pr)/S, hence grad_pr = g - mean_s g = the same kernel applied to g with a zero mixture, and
 grad_mix = mean_s g.
@@ -31,9 +32,7 @@ class _MixtureConsistency(torch.autograd.Function):
 
 def apply(pr_batch, input_mixture, mix_weights_type='uniform'):
     """pr_batch: [batch, n_sources, time]; input_mixture: [batch, 1, time]."""
-    if mix_weights_type == 'magsq':
-        raise NotImplementedError("mix_weights_type='magsq' is not implemented on the HIP path")
-    elif mix_weights_type != 'uniform':
+    if mix_weights_type not in ('magsq', 'uniform'):
         raise ValueError('Invalid mixture consistency weight type: {}'
                          ''.format(mix_weights_type))
     if pr_batch.device.type != "cuda":
@@ -42,4 +41,10 @@ def apply(pr_batch, input_mixture, mix_weights_type='uniform'):
             input_mixture.shape[0] != pr_batch.shape[0] or input_mixture.shape[2] != pr_batch.shape[2]:
         raise RuntimeError("expected pr_batch [B,S,T] and input_mixture [B,1,T], got %s and %s" %
                            (tuple(pr_batch.shape), tuple(input_mixture.shape)))
+    if mix_weights_type == 'magsq':
+        if torch.is_grad_enabled() and (pr_batch.requires_grad or input_mixture.requires_grad):
+            raise NotImplementedError("mix_weights_type='magsq' has no backward on the HIP path (the reference's "
+                                      "runners train through the uniform form only)")
+        return ops.mixture_consistency(pr_batch.detach().to(torch.float32).contiguous(),
+                                       input_mixture.detach().to(torch.float32).contiguous(), 'magsq')
     return _MixtureConsistency.apply(pr_batch, input_mixture)

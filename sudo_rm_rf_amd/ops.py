@@ -189,10 +189,16 @@ def tac(x4, params, out_sums=None):
     return q
 
 
-def mixture_consistency(pr_batch, input_mixture):
+def mixture_consistency(pr_batch, input_mixture, mix_weights_type="uniform"):
     dev = _chk(pr_batch, input_mixture)
     Bt, S, T = pr_batch.shape
     out = torch.empty_like(pr_batch)
+    if mix_weights_type == "magsq":
+        work = torch.empty(Bt * S, dtype=torch.float32, device=pr_batch.device)
+        rc = _lib.load().srf_mixture_consistency_magsq(_lib.ptr(pr_batch), _lib.ptr(input_mixture), _lib.ptr(out),
+                                                       Bt, S, T, _lib.ptr(work), _lib.current_stream(dev))
+        _lib.check(rc, "srf_mixture_consistency_magsq")
+        return out
     rc = _lib.load().srf_mixture_consistency(_lib.ptr(pr_batch), _lib.ptr(input_mixture), _lib.ptr(out),
                                              Bt, S, T, _lib.current_stream(dev))
     _lib.check(rc, "srf_mixture_consistency")

@@ -335,6 +335,22 @@ def test_mixture_consistency():
     check(ops.mixture_consistency(dev32(pr), dev32(mix)), want, 1e-6, "mixture consistency")
 
 
+def test_mixture_consistency_magsq():
+    """the 'magsq' weights (mixture_consistency.py:26-28) against the numpy oracle, through the module mirror."""
+    import sudo_rm_rf.dnn.experiments.utils.mixture_consistency as mixture_consistency
+    from oracle import np_oracle
+    for (Bt, S, T, seed) in [(3, 4, 1001, 92), (2, 2, 32000, 93), (1, 1, 7, 94)]:
+        pr = rnd(Bt, S, T, seed=seed) * torch.arange(1, S + 1, dtype=torch.float64).view(1, S, 1)   # unequal energies
+        mix = rnd(Bt, 1, T, seed=seed + 10)
+        want = torch.from_numpy(np_oracle.mixture_consistency(pr.numpy(), mix.numpy(), "magsq"))
+        got = mixture_consistency.apply(dev32(pr), dev32(mix), mix_weights_type='magsq')
+        check(got, want, 2e-6 * float(want.abs().max()), "mixture consistency magsq")
+    with pytest.raises(ValueError):
+        mixture_consistency.apply(dev32(pr), dev32(mix), mix_weights_type='nope')
+    with pytest.raises(NotImplementedError):
+        mixture_consistency.apply(dev32(pr).requires_grad_(), dev32(mix), mix_weights_type='magsq')
+
+
 @pytest.mark.parametrize("Bt,S,T,mc", [(3, 2, 1001, False), (2, 2, 32000, True), (1, 3, 77, True), (4, 1, 5, False)])
 def test_wav_normalize_denormalize(Bt, S, T, mc):
     """README.md:100-114: (x-mean)/(std+1e-9) with torch's unbiased std, est*std+mean, mixture consistency."""
