@@ -19,6 +19,8 @@
  *   srf_gln_apply_add      <- TAC_norm + residual add     models/groupcomm_sudormrf_v2.py:378-382
  *   srf_mixture_consistency<- mixture_consistency.apply   experiments/utils/mixture_consistency.py:14-36
  *   srf_wav_normalize / srf_wav_denormalize <- the callers' normalise / rescale lines   README.md:100-114
+ *   srf_pit_sisdr_*        <- PITLossWrapper(PairwiseNegSDR("sisdr")) fwd/bwd        losses/sisdr.py:254-311,426-458
+ *   srf_perm_inv_sisdr     <- PermInvariantSISDR.forward (validation metric)        losses/sisdr.py:66-196
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 (or fp64 for GlobLN sums) owned by the
@@ -42,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 7
+#define SRF_ABI_VERSION 8
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -231,6 +233,19 @@ int srf_pit_sisdr_forward(const float* est, const float* tgt, int Bt, int S, int
 int srf_pit_sisdr_match(const void* work, int Bt, int S, int* match_out, void* stream);
 int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt, int S, int T, float clamp, const void* work,
                            const float* loss, const float* upstream, float* grad_est, void* stream);
+
+/* ---- validation metric of the runners: PermInvariantSISDR.forward (losses/sisdr.py:66-196; constructed at
+ * experiments/run_improved_sudormrf.py:82-85, called :201-205).  pr, tgt: [Bt,S,T], mix: [Bt,1,T] or NULL; S <= 4.
+ *   best      [Bt]    max over permutations (itertools order) of the source-mean SI-SNR in dB, eps as the class
+ *                     places it: s = <p,t>/(<t,t>+eps) t, 10 log10(<s,s>/(<p-s,p-s>+eps));
+ *   best_perm [Bt]    index of that permutation in itertools.permutations(range(S)) (first maximum);
+ *   base      [Bt*S]  optional (needs mix): SI-SNR of the mixture against every target -- the class subtracts
+ *                     mean(base) over batch AND sources from `best` when improvement=True;
+ *   zero_mean         subtract the time mean of every signal first (perform_zero_mean);
+ *   work              srf_perm_inv_sisdr_work_bytes(Bt,S) bytes, 8-byte aligned. */
+size_t srf_perm_inv_sisdr_work_bytes(int Bt, int S);
+int srf_perm_inv_sisdr(const float* pr, const float* tgt, const float* mix, int Bt, int S, int T, int zero_mean,
+                       double eps, void* work, float* best, int* best_perm, float* base, void* stream);
 
 /* ---- training step, backward kernels (one entry point per kernel for unit parity) ---- */
 

@@ -88,3 +88,54 @@ def loss_and_grad(est_np, tgt_np, clamp=30.0, dtype=torch.float64):
     l, raw, pw, match = pit_sisdr_loss(est, tgt, clamp)
     l.backward()
     return (float(l.detach()), float(raw.detach()), pw.detach().numpy(), match.numpy().astype(np.int32), est.grad.numpy())
+
+
+def perm_invariant_sisdr(pr, tgt, mix=None, zero_mean=False, improvement=False, backward_loss=True,
+                         return_individual_results=False, eps=1e-9):
+    """PermInvariantSISDR(n_sources=S, zero_mean, backward_loss, improvement, return_individual_results)
+    .forward(pr, tgt, eps, initial_mixtures=mix, return_best_permutation=True)   (losses/sisdr.py:66-196).
+    numpy arrays [batch, n_src, T] (mix [batch, 1, T]) -> (value, best permutation index per example); fp64."""
+    pr, tgt = np.asarray(pr, np.float64), np.asarray(tgt, np.float64)
+    min_len = min(pr.shape[-1], tgt.shape[-1])                                   # normalize_input :97-113
+    if mix is not None:
+        mix = np.asarray(mix, np.float64)
+        min_len = min(min_len, mix.shape[-1])
+        mix = mix[:, :, :min_len]
+    pr, tgt = pr[:, :, :min_len], tgt[:, :, :min_len]
+    if zero_mean:
+        pr = pr - pr.mean(-1, keepdims=True)
+        tgt = tgt - tgt.mean(-1, keepdims=True)
+        if mix is not None:
+            mix = mix - mix.mean(-1, keepdims=True)
+    S = pr.shape[1]
+
+    def dot(x, y):
+        return (x * y).sum(-1, keepdims=True)
+
+    tt = dot(tgt, tgt)                                                           # :136
+
+    def sisnrs(p):                                                               # compute_permuted_sisnrs :119-128
+        s_t = dot(p, tgt) / (tt + eps) * tgt
+        e_t = p - s_t
+        return 10 * np.log10(dot(s_t, s_t) / (dot(e_t, e_t) + eps))
+
+    allp = np.concatenate([sisnrs(pr[:, list(perm), :]) for perm in itertools.permutations(range(S))], -1)   # :138-145
+    mean_over_src = allp.mean(-2)                                                # [B, P]
+    best_idx = mean_over_src.argmax(-1)                                          # torch.max: first maximum
+    best = mean_over_src.max(-1)
+    if improvement:                                                              # :149-154
+        base = sisnrs(np.repeat(mix, S, axis=1))
+        best = best - base.mean()
+    if not return_individual_results:
+        best = best.mean()
+    return (-best if backward_loss else best), best_idx
+
+
+def make_metric_case(name, c):
+    """Inputs of a tests/golden/metric_*.npz case (tools/make_golden_metric.py): estimates, targets, mixture = sum
+    of the targets; the 'ragged' case hands in signals of three different lengths."""
+    est, tgt = make_loss_case(c["batch"], c["n_src"], c["T"], c["seed"], c["snr_db"], c["mode"])
+    mix = tgt.sum(1, keepdims=True).astype(np.float32)
+    if name == "metric_ragged_lengths":
+        est, mix = est[..., :c["T"] - 37], mix[..., :c["T"] - 5]
+    return est, tgt, mix

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 STAT_BUCKETS = 64
 
 SRF_OK = 0
@@ -60,6 +60,8 @@ _PROTOS = {
     "srf_pack_pw_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
     "srf_pw_conv_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _i, _vp, _i, _vp]),
     "srf_pit_sisdr_work_bytes": (_sz, [_i, _i]),
+    "srf_perm_inv_sisdr_work_bytes": (_sz, [_i, _i]),
+    "srf_perm_inv_sisdr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "srf_pit_sisdr_forward": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
     "srf_pit_sisdr_match": (_i, [_vp, _i, _i, _vp, _vp]),
     "srf_pit_sisdr_backward": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),

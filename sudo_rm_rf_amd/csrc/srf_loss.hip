@@ -236,3 +236,134 @@ extern "C" int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt
   SRF_CHECK_LAUNCH("pit_sisdr_grad", stream);
   return SRF_OK;
 }
+
+// =============================================================================================
+// Validation metric of the runners: PermInvariantSISDR (losses/sisdr.py:66-196; used as
+// PermInvariantSISDR(zero_mean=True, backward_loss=False, improvement=True, return_individual_results=True),
+// experiments/run_improved_sudormrf.py:82-85,201-205).  Same inner products as the training loss plus the
+// mixture's {sum m, sum m^2, sum m t_j}; per example: SI-SNR of every (estimate, target) pair with the class's own
+// eps placement  s = <p,t>/(<t,t>+eps) t,  10 log10(<s,s> / (<p-s,p-s> + eps)),  the mean over sources for every
+// permutation in itertools order, the maximum (first maximum wins, like torch.max), and the SI-SNR of the mixture
+// against every target (the "improvement" baseline, which the class subtracts as ONE batch-and-source mean).
+// =============================================================================================
+__global__ __launch_bounds__(256) void srf_mix_stats_kernel(const float* __restrict__ mix, const float* __restrict__ tgt,
+                                                            double* __restrict__ work, int S, int T, int per_block) {
+  __shared__ double red[4][2 + SRF_LOSS_MAX_SRC];
+  const long b = blockIdx.y;
+  const int beg = blockIdx.x * per_block, end = min(beg + per_block, T);
+  double acc[2 + SRF_LOSS_MAX_SRC];
+#pragma unroll
+  for (int k = 0; k < 2 + SRF_LOSS_MAX_SRC; ++k) acc[k] = 0.0;
+  const float* mb = mix + b * (long)T;
+  const float* tb = tgt + b * (long)S * T;
+  for (int t = beg + threadIdx.x; t < end; t += 256) {
+    const double m = (double)mb[t];
+    acc[0] += m;
+    acc[1] += m * m;
+#pragma unroll
+    for (int j = 0; j < SRF_LOSS_MAX_SRC; ++j)
+      if (j < S) acc[2 + j] += m * (double)tb[(long)j * T + t];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 2 + SRF_LOSS_MAX_SRC; ++k) {
+    if (k < 2 + S) {
+      const double v = srf_wave_sum(acc[k]);
+      if (lane == 0) red[wave][k] = v;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 + S) {
+    const int k = threadIdx.x;
+    atomicAdd(work + b * (2 + S) + k, (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]));
+  }
+}
+
+__global__ __launch_bounds__(256) void srf_perm_inv_finalize_kernel(const double* __restrict__ work,
+                                                                    const double* __restrict__ mwork, int Bt, int S, int T,
+                                                                    int zero_mean, double eps, float* __restrict__ best_out,
+                                                                    int* __restrict__ perm_out, float* __restrict__ base_out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= Bt) return;
+  const int nstat = 4 * S + S * S;
+  const double* w = work + (long)b * nstat;
+  const double dT = (double)T, zm = zero_mean ? 1.0 : 0.0;
+  auto sisnr = [&](double pp, double tt, double pt) {   // inner products of the (centred) signals
+    const double al = pt / (tt + eps);
+    const double ss = al * al * tt;
+    double ee = pp - 2.0 * al * pt + al * al * tt;
+    ee = ee < 0.0 ? 0.0 : ee;
+    return 10.0 * log10(ss / (ee + eps));
+  };
+  double sn[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC];
+  for (int i = 0; i < S; ++i) {
+    const double me = zm * w[i] / dT, pp = w[S + i] - dT * me * me;
+    for (int j = 0; j < S; ++j) {
+      const double mt = zm * w[2 * S + j] / dT;
+      sn[i][j] = sisnr(pp, w[3 * S + j] - dT * mt * mt, w[4 * S + i * S + j] - dT * me * mt);
+    }
+  }
+  // permutations in itertools order; permuted_pr[:, j] = pr[:, perm[j]] is scored against target j
+  int perm[SRF_LOSS_MAX_SRC];
+  for (int j = 0; j < S; ++j) perm[j] = j;
+  double best = 0.0;
+  int best_idx = 0, idx = 0;
+  for (;;) {
+    double l = 0.0;
+    for (int j = 0; j < S; ++j) l += sn[perm[j]][j];
+    l /= (double)S;
+    if (idx == 0 || l > best) {
+      best = l;
+      best_idx = idx;
+    }
+    ++idx;
+    int p = S - 2;
+    while (p >= 0 && perm[p] > perm[p + 1]) --p;
+    if (p < 0) break;
+    int q = S - 1;
+    while (perm[q] < perm[p]) --q;
+    int tmp = perm[p];
+    perm[p] = perm[q];
+    perm[q] = tmp;
+    for (int lo = p + 1, hi = S - 1; lo < hi; ++lo, --hi) {
+      tmp = perm[lo];
+      perm[lo] = perm[hi];
+      perm[hi] = tmp;
+    }
+  }
+  best_out[b] = (float)best;
+  perm_out[b] = best_idx;
+  if (base_out && mwork) {
+    const double* mw = mwork + (long)b * (2 + S);
+    const double mm_ = zm * mw[0] / dT, pp = mw[1] - dT * mm_ * mm_;
+    for (int j = 0; j < S; ++j) {
+      const double mt = zm * w[2 * S + j] / dT;
+      base_out[(long)b * S + j] = (float)sisnr(pp, w[3 * S + j] - dT * mt * mt, mw[2 + j] - dT * mm_ * mt);
+    }
+  }
+}
+
+extern "C" size_t srf_perm_inv_sisdr_work_bytes(int Bt, int S) {
+  if (Bt <= 0 || S <= 0 || S > SRF_LOSS_MAX_SRC) return 0;
+  return (size_t)Bt * ((4 * S + S * S) + (2 + S)) * sizeof(double);
+}
+
+extern "C" int srf_perm_inv_sisdr(const float* pr, const float* tgt, const float* mix, int Bt, int S, int T, int zero_mean,
+                                  double eps, void* work, float* best, int* best_perm, float* base, void* stream) {
+  SRF_CHECK_ARG(pr && tgt && work && best && best_perm, "srf_perm_inv_sisdr: null pointer");
+  SRF_CHECK_ARG(Bt > 0 && Bt <= 65535 && T > 0, "srf_perm_inv_sisdr: bad sizes");
+  SRF_CHECK_ARG(S >= 1 && S <= SRF_LOSS_MAX_SRC, "srf_perm_inv_sisdr: %d sources unsupported (1..%d)", S, SRF_LOSS_MAX_SRC);
+  SRF_CHECK_ARG(!base || mix, "srf_perm_inv_sisdr: the improvement baseline needs the mixtures");
+  hipStream_t st = (hipStream_t)stream;
+  double* stats = reinterpret_cast<double*>(work);
+  double* mstats = stats + (size_t)Bt * (4 * S + S * S);
+  SRF_CHECK_HIP(hipMemsetAsync(work, 0, srf_perm_inv_sisdr_work_bytes(Bt, S), st));
+  const int per_block = 256 * 16;
+  dim3 grid((unsigned)((T + per_block - 1) / per_block), (unsigned)Bt);
+  hipLaunchKernelGGL(srf_pit_stats_kernel, grid, dim3(256), 0, st, pr, tgt, stats, S, T, per_block);
+  if (mix && base) hipLaunchKernelGGL(srf_mix_stats_kernel, grid, dim3(256), 0, st, mix, tgt, mstats, S, T, per_block);
+  hipLaunchKernelGGL(srf_perm_inv_finalize_kernel, dim3((unsigned)((Bt + 255) / 256)), dim3(256), 0, st, stats,
+                     (mix && base) ? mstats : nullptr, Bt, S, T, zero_mean, eps, best, best_perm, base);
+  SRF_CHECK_LAUNCH("perm_inv_sisdr", st);
+  return SRF_OK;
+}

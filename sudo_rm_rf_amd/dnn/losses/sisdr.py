@@ -4,6 +4,7 @@
     PITLossWrapper(PairwiseNegSDR("sisdr"), pit_from='pw_mtx')      experiments/run_improved_sudormrf.py:63-66
     PairwiseNegSDR                                                  losses/sisdr.py:390-458
     PITLossWrapper                                                  losses/sisdr.py:199-387
+    PermInvariantSISDR (the runners' validation metric, SI-SDRi)    losses/sisdr.py:66-196; run_improved_sudormrf.py:82-85
 
 Same class names, constructor arguments and call signatures; the arithmetic runs in csrc/srf_loss.hip (one
 streaming pass for the forward, one for the gradient).  Configurations the runners never use (plain SNR / SD-SDR,
@@ -11,6 +12,7 @@ streaming pass for the forward, one for the gradient).  Configurations the runne
 to a CPU/ATen path.
 """
 import ctypes as C
+import itertools
 
 import torch
 from torch import nn
@@ -137,3 +139,71 @@ class PITLossWrapper(nn.Module):
             _lib.check(rc, "srf_pit_sisdr_match")
         idx = match.long().unsqueeze(-1).expand(Bt, S, T)
         return torch.gather(est_targets, 1, idx)
+
+
+class PermInvariantSISDR(nn.Module):
+    """The runners' validation metric (reference: losses/sisdr.py:66-196): permutation-invariant SI-SNR of
+    reconstructed vs target wavs, optionally as an improvement over the input mixture.  Same constructor and
+    ``forward`` arguments; one streaming pass over the signals + a per-example finalize (csrc/srf_loss.hip:
+    srf_perm_inv_sisdr) instead of the S! materialised permuted copies.  Evaluation only: it raises under autograd
+    (the runners train with PITLossWrapper; their PermInvariantSISDR training line is commented out,
+    run_improved_sudormrf.py:68-71)."""
+
+    def __init__(self, batch_size=None, zero_mean=False, n_sources=None, backward_loss=True, improvement=False,
+                 return_individual_results=False):
+        super().__init__()
+        self.bs = batch_size
+        self.perform_zero_mean = zero_mean
+        self.backward_loss = backward_loss
+        self.permutations = list(itertools.permutations(torch.arange(n_sources)))
+        self.permutations_tensor = torch.LongTensor(self.permutations)
+        self.improvement = improvement
+        self.n_sources = n_sources
+        self.return_individual_results = return_individual_results
+
+    def forward(self, pr_batch, t_batch, eps=1e-9, initial_mixtures=None, return_best_permutation=False):
+        if torch.is_grad_enabled() and (pr_batch.requires_grad or t_batch.requires_grad):
+            raise NotImplementedError("PermInvariantSISDR is an evaluation metric on the HIP path (no backward): "
+                                      "call it under torch.no_grad(), train with PITLossWrapper")
+        if pr_batch.dim() != 3 or t_batch.dim() != 3 or pr_batch.shape[:2] != t_batch.shape[:2]:
+            raise RuntimeError("expected [batch, n_src, time] estimates and targets, got %s and %s" %
+                               (tuple(pr_batch.shape), tuple(t_batch.shape)))
+        if pr_batch.shape[1] != self.n_sources:
+            raise RuntimeError("constructed for %s sources, got %d" % (self.n_sources, pr_batch.shape[1]))
+        if pr_batch.device.type != "cuda" or t_batch.device != pr_batch.device:
+            raise _lib.SrfError("sudo_rm_rf_amd losses run on an MI355X only (estimates on %s, targets on %s); "
+                                "there is deliberately no CPU fallback" % (pr_batch.device, t_batch.device))
+        if self.n_sources > 4:
+            raise NotImplementedError("the HIP metric supports up to 4 sources, got %d" % self.n_sources)
+        if self.improvement and initial_mixtures is None:
+            raise AttributeError("improvement=True needs initial_mixtures")      # the reference fails on None.repeat
+        # normalize_input (sisdr.py:97-113): crop everything to the shortest signal
+        min_len = min(pr_batch.shape[-1], t_batch.shape[-1])
+        if initial_mixtures is not None:
+            min_len = min(min_len, initial_mixtures.shape[-1])
+        dev = pr_batch.device
+        pr = pr_batch.detach()[:, :, :min_len].to(torch.float32).contiguous()
+        tg = t_batch.detach()[:, :, :min_len].to(torch.float32).contiguous()
+        mix = None
+        if initial_mixtures is not None and self.improvement:
+            mix = initial_mixtures.detach()[:, :1, :min_len].to(device=dev, dtype=torch.float32).contiguous()
+        Bt, S, T = pr.shape
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            work = torch.empty(lib.srf_perm_inv_sisdr_work_bytes(Bt, S), dtype=torch.uint8, device=dev)
+            best = torch.empty(Bt, dtype=torch.float32, device=dev)
+            perm = torch.empty(Bt, dtype=torch.int32, device=dev)
+            base = torch.empty(Bt * S, dtype=torch.float32, device=dev) if mix is not None else None
+            rc = lib.srf_perm_inv_sisdr(_lib.ptr(pr), _lib.ptr(tg), _lib.ptr(mix), Bt, S, T,
+                                        1 if self.perform_zero_mean else 0, C.c_double(float(eps)), _lib.ptr(work),
+                                        _lib.ptr(best), _lib.ptr(perm), _lib.ptr(base), _lib.current_stream(dev))
+        _lib.check(rc, "srf_perm_inv_sisdr")
+        best_sisdr = best
+        if self.improvement:
+            best_sisdr = best_sisdr - base.mean()             # one batch-and-source mean, as sisdr.py:154
+        if not self.return_individual_results:
+            best_sisdr = best_sisdr.mean()
+        out = -best_sisdr if self.backward_loss else best_sisdr
+        if return_best_permutation:
+            return out, self.permutations_tensor[perm.long().cpu()]
+        return out

@@ -75,3 +75,43 @@ def test_pit_sisdr_interface_errors():
         sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("snr"), pit_from='pw_mtx')(e.to(DEV), t.to(DEV))
     with pytest.raises(ValueError):
         sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='nope')
+
+
+METRIC = json.load(open(os.path.join(GOLD, "METRIC_MANIFEST.json")))
+
+
+@pytest.mark.parametrize("name", sorted(METRIC))
+def test_perm_invariant_sisdr_matches_reference_golden(name):
+    """The runners' validation metric (PermInvariantSISDR, losses/sisdr.py:66-196) through the module mirror against
+    the values of the reference class itself (tools/make_golden_metric.py)."""
+    import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib
+    c = METRIC[name]
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    est, tgt, mix = loss_oracle.make_metric_case(name, c)
+    fn = sisdr_lib.PermInvariantSISDR(batch_size=c["batch"], n_sources=c["n_src"], zero_mean=c["zero_mean"],
+                                      backward_loss=c["backward_loss"], improvement=c["improvement"],
+                                      return_individual_results=c["individual"])
+    with torch.no_grad():
+        val, perms = fn(torch.tensor(est, device=DEV), torch.tensor(tgt, device=DEV),
+                        initial_mixtures=torch.tensor(mix, device=DEV), return_best_permutation=True)
+        only = fn(torch.tensor(est, device=DEV), torch.tensor(tgt, device=DEV), initial_mixtures=torch.tensor(mix, device=DEV))
+    got = val.cpu().numpy()
+    assert got.shape == z["value"].shape
+    assert (np.abs(got - z["value"]) <= 2e-4 + 2e-5 * np.abs(z["value"])).all()
+    assert (perms.numpy() == z["perms"]).all()
+    assert torch.equal(only, val)
+
+
+def test_perm_invariant_sisdr_interface_errors():
+    import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib
+    fn = sisdr_lib.PermInvariantSISDR(batch_size=2, n_sources=2, zero_mean=True, backward_loss=False, improvement=True)
+    e, t = torch.randn(2, 2, 100), torch.randn(2, 2, 100)
+    with pytest.raises(Exception, match="MI355X"):
+        fn(e, t, initial_mixtures=t.sum(1, keepdim=True))                   # CPU tensors: no fallback
+    with pytest.raises(AttributeError):
+        fn(e.to(DEV), t.to(DEV))                                            # improvement without mixtures
+    with pytest.raises(NotImplementedError):
+        fn(e.to(DEV).requires_grad_(), t.to(DEV), initial_mixtures=t.sum(1, keepdim=True).to(DEV))
+    with pytest.raises(RuntimeError):
+        fn(torch.randn(2, 3, 100, device=DEV), torch.randn(2, 3, 100, device=DEV),
+           initial_mixtures=torch.randn(2, 1, 100, device=DEV))             # constructed for 2 sources

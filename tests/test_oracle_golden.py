@@ -106,6 +106,31 @@ def test_loss_oracle_matches_reference_golden(name):
     assert np.abs((grad ** 2).sum(-1) - z["grad_sqsum"]).max() <= 1e-4 * max(z["grad_sqsum"].max(), 1e-12)
 
 
+def _metric_manifest():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "METRIC_MANIFEST.json")))
+
+
+@pytest.mark.parametrize("name", sorted(_metric_manifest()))
+def test_metric_oracle_matches_reference_golden(name):
+    """PermInvariantSISDR (the runners' validation metric, losses/sisdr.py:66-196): restatement vs the values the
+    reference class itself produced (tools/make_golden_metric.py)."""
+    import itertools
+    import os
+    from oracle import loss_oracle
+    c = _metric_manifest()[name]
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    est, tgt, mix = loss_oracle.make_metric_case(name, c)
+    val, idx = loss_oracle.perm_invariant_sisdr(est, tgt, mix, zero_mean=c["zero_mean"], improvement=c["improvement"],
+                                                backward_loss=c["backward_loss"],
+                                                return_individual_results=c["individual"])
+    assert np.shape(val) == z["value"].shape
+    assert (np.abs(val - z["value"]) <= 2e-4 + 2e-5 * np.abs(z["value"])).all()      # fp32 reference, dB
+    perms = list(itertools.permutations(range(c["n_src"])))
+    assert (np.array([perms[i] for i in idx]) == z["perms"]).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # one training step's gradients: oracle forward + oracle loss under torch autograd (fp64) vs the reference's own
 # fp32 backward (tools/make_golden_train.py)
