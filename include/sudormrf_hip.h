@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 8
+#define SRF_ABI_VERSION 9
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -230,6 +230,11 @@ int srf_wav_denormalize(const float* est, const float* stats, const float* mix_n
 size_t srf_pit_sisdr_work_bytes(int Bt, int S);
 int srf_pit_sisdr_forward(const float* est, const float* tgt, int Bt, int S, int T, float clamp, void* work,
                           float* pw, float* loss, void* stream);
+/* The other PairwiseNegSDR configurations (losses/sisdr.py:418-424,440-458): sdr_type 0 = "sisdr", 1 = "sdsdr",
+ * 2 = "snr"; zero_mean / take_log as the constructor flags.  srf_pit_sisdr_forward == (0, 1, 1).  Same work buffer,
+ * srf_pit_sisdr_match / _backward apply unchanged. */
+int srf_pit_sdr_forward(const float* est, const float* tgt, int Bt, int S, int T, float clamp, int sdr_type,
+                        int zero_mean, int take_log, void* work, float* pw, float* loss, void* stream);
 int srf_pit_sisdr_match(const void* work, int Bt, int S, int* match_out, void* stream);
 int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt, int S, int T, float clamp, const void* work,
                            const float* loss, const float* upstream, float* grad_est, void* stream);

@@ -45,19 +45,31 @@ def make_loss_case(batch, n_src, T, seed, snr_db=5.0, mode="noisy"):
     return est.astype(np.float32), tgt.astype(np.float32)
 
 
-def pairwise_neg_sisdr(est, tgt):
-    """PairwiseNegSDR('sisdr', zero_mean=True, take_log=True).forward  (losses/sisdr.py:426-458).
+def pairwise_neg_sdr(est, tgt, sdr_type="sisdr", zero_mean=True, take_log=True):
+    """PairwiseNegSDR(sdr_type, zero_mean, take_log).forward  (losses/sisdr.py:426-458).
     torch tensors [batch, n_src, T] -> [batch, n_src(est), n_src(tgt)]; differentiable."""
-    tgt = tgt - tgt.mean(dim=2, keepdim=True)                                   # :431-435
-    est = est - est.mean(dim=2, keepdim=True)
+    assert sdr_type in ("snr", "sisdr", "sdsdr")                                # :421
+    if zero_mean:                                                               # :431-435
+        tgt = tgt - tgt.mean(dim=2, keepdim=True)
+        est = est - est.mean(dim=2, keepdim=True)
     s_target = tgt.unsqueeze(1)                                                 # :437  [B,1,S,T]
     s_estimate = est.unsqueeze(2)                                               # :438  [B,S,1,T]
-    dot = (s_estimate * s_target).sum(dim=3, keepdim=True)                      # :442
-    energy = (s_target ** 2).sum(dim=3, keepdim=True) + EPS                     # :445
-    proj = dot * s_target / energy                                              # :447
-    noise = s_estimate - proj                                                   # :454
+    if sdr_type in ("sisdr", "sdsdr"):                                          # :440-447
+        dot = (s_estimate * s_target).sum(dim=3, keepdim=True)
+        energy = (s_target ** 2).sum(dim=3, keepdim=True) + EPS
+        proj = dot * s_target / energy
+    else:                                                                       # :448-450
+        proj = s_target.repeat(1, s_target.shape[2], 1, 1)
+    noise = s_estimate - s_target if sdr_type in ("sdsdr", "snr") else s_estimate - proj    # :451-454
     sdr = (proj ** 2).sum(dim=3) / ((noise ** 2).sum(dim=3) + EPS)              # :456-457
-    return -10.0 * torch.log10(sdr + EPS)                                       # :458-460
+    if take_log:
+        sdr = 10.0 * torch.log10(sdr + EPS)                                     # :458-459
+    return -sdr
+
+
+def pairwise_neg_sisdr(est, tgt):
+    """PairwiseNegSDR('sisdr', zero_mean=True, take_log=True).forward -- the runners' configuration."""
+    return pairwise_neg_sdr(est, tgt)
 
 
 def best_perm(pw):
@@ -72,20 +84,20 @@ def best_perm(pw):
     return loss_set.gather(1, idx[:, None])[:, 0], idx, perms
 
 
-def pit_sisdr_loss(est, tgt, clamp=30.0):
+def pit_sisdr_loss(est, tgt, clamp=30.0, sdr_type="sisdr", zero_mean=True, take_log=True):
     """The scalar the runner back-propagates: clamp(mean_b min_perm mean_j pw[b, perm_j, j], -30, 30)."""
-    pw = pairwise_neg_sisdr(est, tgt)
+    pw = pairwise_neg_sdr(est, tgt, sdr_type, zero_mean, take_log)
     min_loss, idx, perms = best_perm(pw)
     raw = min_loss.mean()                                                       # sisdr.py:307
     return (torch.clamp(raw, min=-clamp, max=clamp) if clamp else raw), raw, pw, perms[idx]
 
 
-def loss_and_grad(est_np, tgt_np, clamp=30.0, dtype=torch.float64):
+def loss_and_grad(est_np, tgt_np, clamp=30.0, dtype=torch.float64, sdr_type="sisdr", zero_mean=True, take_log=True):
     """numpy in / numpy out: (clamped loss, raw loss, pw [B,S,S], matched estimate per target [B,S],
     d clamped_loss / d est [B,S,T])."""
     est = torch.tensor(est_np, dtype=dtype, requires_grad=True)
     tgt = torch.tensor(tgt_np, dtype=dtype)
-    l, raw, pw, match = pit_sisdr_loss(est, tgt, clamp)
+    l, raw, pw, match = pit_sisdr_loss(est, tgt, clamp, sdr_type, zero_mean, take_log)
     l.backward()
     return (float(l.detach()), float(raw.detach()), pw.detach().numpy(), match.numpy().astype(np.int32), est.grad.numpy())
 

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 STAT_BUCKETS = 64
 
 SRF_OK = 0
@@ -63,6 +63,7 @@ _PROTOS = {
     "srf_perm_inv_sisdr_work_bytes": (_sz, [_i, _i]),
     "srf_perm_inv_sisdr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "srf_pit_sisdr_forward": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
+    "srf_pit_sdr_forward": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "srf_pit_sisdr_match": (_i, [_vp, _i, _i, _vp, _vp]),
     "srf_pit_sisdr_backward": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "srf_pw_wgrad_scratch_bytes": (_sz, [_i, _i, _i, _i]),

@@ -70,8 +70,13 @@ struct PitOut {
   float* loss;    // {clamped batch mean, raw batch mean}
 };
 
+// sdr_type: 0 = "sisdr", 1 = "sdsdr", 2 = "snr" (losses/sisdr.py:440-455); zero_mean / take_log: the constructor flags.
+// With P = |projection|^2 and N = |noise|^2 + 1e-8 as functions of (ee = <e,e>, d = <e,t>) for a fixed target:
+//   sisdr: P = d^2 tt/tau^2, N0 = ee - 2 d^2/tau + d^2 tt/tau^2;  sdsdr: same P, N0 = ee - 2 d + tt;  snr: P = tt, N0 as sdsdr
+//   d l / d e = 2 l_N (e - mean e) + (l_P P_d + l_N N_d) (t - mean t)       (means 0 without zero_mean)
 __global__ __launch_bounds__(256) void srf_pit_finalize_kernel(const double* __restrict__ work, PitOut o, int Bt,
-                                                               int S, int T, float clamp) {
+                                                               int S, int T, float clamp, int sdr_type, int zero_mean,
+                                                               int take_log) {
   __shared__ double red[4];
   const int nstat = 4 * S + S * S;
   double mysum = 0.0;
@@ -80,21 +85,35 @@ __global__ __launch_bounds__(256) void srf_pit_finalize_kernel(const double* __r
     double pw[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC], cA[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC],
         cB[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC];
     const double dT = (double)T;
+    const double zm = zero_mean ? 1.0 : 0.0;
     for (int i = 0; i < S; ++i) {
-      const double me = w[i] / dT, ee = w[S + i] - dT * me * me;
+      const double me = zm * w[i] / dT, ee = w[S + i] - dT * me * me;
       for (int j = 0; j < S; ++j) {
-        const double mt = w[2 * S + j] / dT;
+        const double mt = zm * w[2 * S + j] / dT;
         const double tau0 = w[3 * S + j] - dT * mt * mt, tau = tau0 + 1e-8;
         const double d = w[4 * S + i * S + j] - dT * me * mt;
         const double al = d / tau;
-        const double P = al * al * tau0;
-        const double N = ee - 2.0 * al * d + al * al * tau0 + 1e-8;
+        double P, N, P_d, N_d;
+        if (sdr_type == 2) {
+          P = tau0;
+          P_d = 0.0;
+        } else {
+          P = al * al * tau0;
+          P_d = 2.0 * al * tau0 / tau;
+        }
+        if (sdr_type == 0) {
+          N = ee - 2.0 * al * d + al * al * tau0 + 1e-8;
+          N_d = -2.0 * al * (2.0 - tau0 / tau);
+        } else {
+          N = ee - 2.0 * d + tau0 + 1e-8;
+          N_d = -2.0;
+        }
         const double sdr = P / N;
-        pw[i][j] = -10.0 * log10(sdr + 1e-8);
+        pw[i][j] = take_log ? -10.0 * log10(sdr + 1e-8) : -sdr;
         // d pw / d e_i = cA * (e_i - me) + cB * (t_j - mt)
-        const double k = -(10.0 / log(10.0)) / (sdr + 1e-8);
+        const double k = take_log ? -(10.0 / log(10.0)) / (sdr + 1e-8) : -1.0;
         cA[i][j] = k * (-2.0 * P / (N * N));
-        cB[i][j] = k * (2.0 * al / (N * N)) * ((tau0 / tau) * N + P * (2.0 - tau0 / tau));
+        cB[i][j] = k * (P_d / N - P * N_d / (N * N));
         if (o.pw) o.pw[((long)b * S + i) * S + j] = (float)pw[i][j];
       }
     }
@@ -136,8 +155,8 @@ __global__ __launch_bounds__(256) void srf_pit_finalize_kernel(const double* __r
       float* c = o.coef + ((long)b * S + i) * 4;
       c[0] = (float)(cA[i][j] * scale);
       c[1] = (float)(cB[i][j] * scale);
-      c[2] = (float)(w[i] / dT);
-      c[3] = (float)(w[2 * S + j] / dT);
+      c[2] = (float)(zm * w[i] / dT);
+      c[3] = (float)(zm * w[2 * S + j] / dT);
     }
   }
   mysum = srf_wave_sum(mysum);
@@ -188,8 +207,17 @@ static void pit_carve(void* work, int Bt, int S, double** stats, float** coef, i
   *tmatch = *match + (size_t)Bt * S;
 }
 
+extern "C" int srf_pit_sdr_forward(const float* est, const float* tgt, int Bt, int S, int T, float clamp, int sdr_type,
+                                   int zero_mean, int take_log, void* work, float* pw, float* loss, void* stream);
+
 extern "C" int srf_pit_sisdr_forward(const float* est, const float* tgt, int Bt, int S, int T, float clamp,
                                      void* work, float* pw, float* loss, void* stream) {
+  return srf_pit_sdr_forward(est, tgt, Bt, S, T, clamp, 0, 1, 1, work, pw, loss, stream);
+}
+
+extern "C" int srf_pit_sdr_forward(const float* est, const float* tgt, int Bt, int S, int T, float clamp, int sdr_type,
+                                   int zero_mean, int take_log, void* work, float* pw, float* loss, void* stream) {
+  SRF_CHECK_ARG(sdr_type >= 0 && sdr_type <= 2, "srf_pit_sdr_forward: sdr_type %d (0 sisdr, 1 sdsdr, 2 snr)", sdr_type);
   SRF_CHECK_ARG(est && tgt && work && loss, "srf_pit_sisdr_forward: null pointer");
   SRF_CHECK_ARG(Bt > 0 && Bt <= 65535 && T > 0, "srf_pit_sisdr_forward: bad sizes");
   SRF_CHECK_ARG(S >= 1 && S <= SRF_LOSS_MAX_SRC, "srf_pit_sisdr_forward: %d sources unsupported (1..%d)", S,
@@ -205,7 +233,8 @@ extern "C" int srf_pit_sisdr_forward(const float* est, const float* tgt, int Bt,
   dim3 grid((unsigned)((T + per_block - 1) / per_block), (unsigned)Bt);
   hipLaunchKernelGGL(srf_pit_stats_kernel, grid, dim3(256), 0, st, est, tgt, stats, S, T, per_block);
   SRF_CHECK_LAUNCH("pit_sisdr_stats", st);
-  hipLaunchKernelGGL(srf_pit_finalize_kernel, dim3(1), dim3(256), 0, st, stats, o, Bt, S, T, clamp);
+  hipLaunchKernelGGL(srf_pit_finalize_kernel, dim3(1), dim3(256), 0, st, stats, o, Bt, S, T, clamp, sdr_type,
+                     zero_mean ? 1 : 0, take_log ? 1 : 0);
   SRF_CHECK_LAUNCH("pit_sisdr_finalize", st);
   return SRF_OK;
 }

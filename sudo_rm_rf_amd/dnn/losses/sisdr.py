@@ -7,9 +7,10 @@
     PermInvariantSISDR (the runners' validation metric, SI-SDRi)    losses/sisdr.py:66-196; run_improved_sudormrf.py:82-85
 
 Same class names, constructor arguments and call signatures; the arithmetic runs in csrc/srf_loss.hip (one
-streaming pass for the forward, one for the gradient).  Configurations the runners never use (plain SNR / SD-SDR,
-``pit_from`` other than 'pw_mtx', a custom ``perm_reduce``) raise NotImplementedError instead of falling back
-to a CPU/ATen path.
+streaming pass for the forward, one for the gradient).  PairwiseNegSDR takes all of its configurations
+("sisdr" | "sdsdr" | "snr", zero_mean, take_log); ``pit_from`` other than 'pw_mtx' or a custom ``perm_reduce`` (which
+need loss functions this file of the reference does not contain) raise NotImplementedError instead of falling back to
+a CPU/ATen path.
 """
 import ctypes as C
 import itertools
@@ -34,26 +35,30 @@ def _check(est, tgt):
         raise NotImplementedError("the HIP PIT loss supports up to 4 sources, got %d" % est.shape[1])
 
 
-def _forward(est, tgt, want_pw):
+_SDR_TYPES = {"sisdr": 0, "sdsdr": 1, "snr": 2}
+_DEFAULT_VARIANT = (0, 1, 1)      # PairwiseNegSDR("sisdr", zero_mean=True, take_log=True)
+
+
+def _forward(est, tgt, want_pw, variant=_DEFAULT_VARIANT):
     lib = _lib.load()
     Bt, S, T = est.shape
     dev = est.device
     work = torch.empty(lib.srf_pit_sisdr_work_bytes(Bt, S), dtype=torch.uint8, device=dev)
     loss = torch.empty(2, dtype=torch.float32, device=dev)
     pw = torch.empty((Bt, S, S), dtype=torch.float32, device=dev) if want_pw else None
-    rc = lib.srf_pit_sisdr_forward(_lib.ptr(est), _lib.ptr(tgt), Bt, S, T, C.c_float(0.0), _lib.ptr(work),
-                                   _lib.ptr(pw), _lib.ptr(loss), _lib.current_stream(dev))
-    _lib.check(rc, "srf_pit_sisdr_forward")
+    rc = lib.srf_pit_sdr_forward(_lib.ptr(est), _lib.ptr(tgt), Bt, S, T, C.c_float(0.0), variant[0], variant[1],
+                                 variant[2], _lib.ptr(work), _lib.ptr(pw), _lib.ptr(loss), _lib.current_stream(dev))
+    _lib.check(rc, "srf_pit_sdr_forward")
     return work, loss, pw
 
 
 class _PitSisdr(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, est, tgt):
+    def forward(ctx, est, tgt, variant=_DEFAULT_VARIANT):
         est_c = est.detach().to(torch.float32).contiguous()
         tgt_c = tgt.detach().to(torch.float32).contiguous()
         with torch.cuda.device(est.device):
-            work, loss, _ = _forward(est_c, tgt_c, False)
+            work, loss, _ = _forward(est_c, tgt_c, False, variant)
         ctx.save_for_backward(est_c, tgt_c, work, loss)
         ctx.in_dtype = est.dtype
         return loss[1].clone()
@@ -69,7 +74,7 @@ class _PitSisdr(torch.autograd.Function):
                                                     _lib.ptr(work), _lib.ptr(loss), _lib.ptr(up), _lib.ptr(grad),
                                                     _lib.current_stream(est.device))
         _lib.check(rc, "srf_pit_sisdr_backward")
-        return grad.to(ctx.in_dtype), None
+        return grad.to(ctx.in_dtype), None, None
 
 
 class PairwiseNegSDR(_Loss):
@@ -83,13 +88,10 @@ class PairwiseNegSDR(_Loss):
         self.zero_mean = zero_mean
         self.take_log = take_log
 
-    def _supported(self):
-        if self.sdr_type != "sisdr" or not self.zero_mean or not self.take_log:
-            raise NotImplementedError("the HIP path implements PairwiseNegSDR('sisdr', zero_mean=True, "
-                                      "take_log=True), the configuration the reference's runners train with")
+    def _variant(self):
+        return (_SDR_TYPES[self.sdr_type], 1 if self.zero_mean else 0, 1 if self.take_log else 0)
 
     def forward(self, est_targets, targets):
-        self._supported()
         _check(est_targets, targets)
         if torch.is_grad_enabled() and est_targets.requires_grad:
             raise NotImplementedError("gradients flow through PITLossWrapper(PairwiseNegSDR('sisdr'), "
@@ -97,7 +99,7 @@ class PairwiseNegSDR(_Loss):
         est = est_targets.detach().to(torch.float32).contiguous()
         tgt = targets.detach().to(torch.float32).contiguous()
         with torch.cuda.device(est.device):
-            return _forward(est, tgt, True)[2]
+            return _forward(est, tgt, True, self._variant())[2]
 
 
 class PITLossWrapper(nn.Module):
@@ -116,24 +118,24 @@ class PITLossWrapper(nn.Module):
         n_src = targets.shape[1]
         assert n_src < 10, f"Expected source axis along dim 1, found {n_src}"      # sisdr.py:274
         if self.pit_from != 'pw_mtx' or self.perm_reduce is not None or not isinstance(self.loss_func, PairwiseNegSDR):
-            raise NotImplementedError("the HIP path implements PITLossWrapper(PairwiseNegSDR('sisdr'), "
+            raise NotImplementedError("the HIP path implements PITLossWrapper(PairwiseNegSDR(...), "
                                       "pit_from='pw_mtx') (run_improved_sudormrf.py:63-66)")
-        self.loss_func._supported()
         _check(est_targets, targets)
-        mean_loss = _PitSisdr.apply(est_targets, targets)
+        variant = self.loss_func._variant()
+        mean_loss = _PitSisdr.apply(est_targets, targets, variant)
         if not return_est:
             return mean_loss
-        return mean_loss, self.reorder_source(est_targets, targets)
+        return mean_loss, self.reorder_source(est_targets, targets, variant)
 
     @staticmethod
-    def reorder_source(est_targets, targets):
+    def reorder_source(est_targets, targets, variant=_DEFAULT_VARIANT):
         """Estimates re-ordered so that source j is the estimate matched with target j (sisdr.py:309-311)."""
         lib = _lib.load()
         Bt, S, T = est_targets.shape
         est = est_targets.detach().to(torch.float32).contiguous()
         tgt = targets.detach().to(torch.float32).contiguous()
         with torch.cuda.device(est.device):
-            work, _, _ = _forward(est, tgt, False)
+            work, _, _ = _forward(est, tgt, False, variant)
             match = torch.empty((Bt, S), dtype=torch.int32, device=est.device)
             rc = lib.srf_pit_sisdr_match(_lib.ptr(work), Bt, S, _lib.ptr(match), _lib.current_stream(est.device))
             _lib.check(rc, "srf_pit_sisdr_match")

@@ -21,12 +21,18 @@ def _loss_fn():
     return sisdr_lib, sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_mtx')
 
 
-@pytest.mark.parametrize("name", sorted(MAN))
+MANV = json.load(open(os.path.join(GOLD, "LOSSV_MANIFEST.json")))     # the other PairwiseNegSDR configurations
+
+
+@pytest.mark.parametrize("name", sorted(MAN) + sorted(MANV))
 def test_pit_sisdr_matches_reference_golden(name):
-    c = MAN[name]
+    c = MAN[name] if name in MAN else MANV[name]
     z = np.load(os.path.join(GOLD, name + ".npz"))
     est_np, tgt_np = loss_oracle.make_loss_case(c["batch"], c["n_src"], c["T"], c["seed"], c["snr_db"], c["mode"])
     sisdr_lib, loss_fn = _loss_fn()
+    kw = dict(zero_mean=c.get("zero_mean", True), take_log=c.get("take_log", True))
+    sdr_type = c.get("sdr_type", "sisdr")
+    loss_fn = sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR(sdr_type, **kw), pit_from='pw_mtx')
     est = torch.tensor(est_np, device=DEV, requires_grad=True)
     tgt = torch.tensor(tgt_np, device=DEV)
     raw = loss_fn(est, tgt)
@@ -34,7 +40,7 @@ def test_pit_sisdr_matches_reference_golden(name):
     l.backward()
     assert abs(l.item() - float(z["loss"])) <= 2e-5 * max(1.0, abs(l.item()))
     assert abs(raw.item() - float(z["raw"])) <= 1e-5 * max(1.0, abs(raw.item())) + 1e-4
-    pw = sisdr_lib.PairwiseNegSDR("sisdr")(est.detach(), tgt).cpu().numpy()
+    pw = sisdr_lib.PairwiseNegSDR(sdr_type, **kw)(est.detach(), tgt).cpu().numpy()
     # at -110 dB (estimate == target) the reference's own fp32 round-off is ~1e-4 dB: tolerance relative to |pw|
     assert (np.abs(pw - z["pw"]) <= 1e-4 + 5e-6 * np.abs(z["pw"])).all()
     g = est.grad.cpu().numpy()
@@ -72,7 +78,9 @@ def test_pit_sisdr_interface_errors():
     with pytest.raises(AssertionError):
         loss_fn(e.to(DEV), torch.randn(2, 2, 99, device=DEV))
     with pytest.raises(NotImplementedError):
-        sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("snr"), pit_from='pw_mtx')(e.to(DEV), t.to(DEV))
+        sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_pt')(e.to(DEV), t.to(DEV))
+    with pytest.raises(AssertionError):
+        sisdr_lib.PairwiseNegSDR("sdr")                                     # sisdr.py:421
     with pytest.raises(ValueError):
         sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='nope')
 

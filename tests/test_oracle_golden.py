@@ -85,15 +85,23 @@ def _loss_manifest():
     return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "LOSS_MANIFEST.json")))
 
 
-@pytest.mark.parametrize("name", sorted(_loss_manifest()))
+def _lossv_manifest():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "LOSSV_MANIFEST.json")))
+
+
+@pytest.mark.parametrize("name", sorted(_loss_manifest()) + sorted(_lossv_manifest()))
 def test_loss_oracle_matches_reference_golden(name):
     import itertools
     import os
     from oracle import loss_oracle
-    c = _loss_manifest()[name]
+    c = _loss_manifest().get(name) or _lossv_manifest()[name]
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     est, tgt = loss_oracle.make_loss_case(c["batch"], c["n_src"], c["T"], c["seed"], c["snr_db"], c["mode"])
-    loss, raw, pw, match, grad = loss_oracle.loss_and_grad(est, tgt)
+    loss, raw, pw, match, grad = loss_oracle.loss_and_grad(est, tgt, sdr_type=c.get("sdr_type", "sisdr"),
+                                                           zero_mean=c.get("zero_mean", True),
+                                                           take_log=c.get("take_log", True))
     assert abs(loss - float(z["loss"])) <= 2e-5 * max(1.0, abs(loss))
     assert abs(raw - float(z["raw"])) <= 1e-5 * max(1.0, abs(raw)) + 1e-4
     assert (np.abs(pw - z["pw"]) <= 1e-4 + 5e-6 * np.abs(z["pw"])).all()

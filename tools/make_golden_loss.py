@@ -33,13 +33,27 @@ CASES = {
 }
 
 
+# the other PairwiseNegSDR configurations (sisdr.py:418-424): name: (case tuple, sdr_type, zero_mean, take_log);
+# written by `make_golden_loss.py --variants` (LOSSV_MANIFEST.json), the runner configuration above stays untouched
+VARIANTS = {
+    "lossv_snr": ((4, 2, 3000, 21, 5.0, "noisy"), "snr", True, True),
+    "lossv_sdsdr": ((3, 3, 1501, 22, 3.0, "noisy"), "sdsdr", True, True),
+    "lossv_sisdr_raw_mean": ((4, 2, 2000, 23, 8.0, "noisy"), "sisdr", False, True),
+    "lossv_sisdr_nolog": ((3, 2, 2500, 24, 6.0, "noisy"), "sisdr", True, False),
+    "lossv_snr_nolog_raw_mean": ((2, 3, 999, 25, 2.0, "noisy"), "snr", False, False),
+    "lossv_sdsdr_random": ((3, 2, 777, 26, 0.0, "random"), "sdsdr", True, True),
+}
+
+
 def main():
     sisdr = load_ref_module("sudo_rm_rf/dnn/losses/sisdr.py", "_ref_sisdr")
-    loss_fn = sisdr.PITLossWrapper(sisdr.PairwiseNegSDR("sisdr"), pit_from="pw_mtx")
-    pw_fn = sisdr.PairwiseNegSDR("sisdr")
+    variants = "--variants" in sys.argv
     out_dir = os.path.join(ROOT, "tests", "golden")
     manifest = {}
-    for name, (B, S, T, seed, snr, mode) in CASES.items():
+    todo = {k: (v, "sisdr", True, True) for k, v in CASES.items()} if not variants else VARIANTS
+    for name, ((B, S, T, seed, snr, mode), sdr_type, zm, tl) in todo.items():
+        loss_fn = sisdr.PITLossWrapper(sisdr.PairwiseNegSDR(sdr_type, zero_mean=zm, take_log=tl), pit_from="pw_mtx")
+        pw_fn = sisdr.PairwiseNegSDR(sdr_type, zero_mean=zm, take_log=tl)
         est_np, tgt_np = make_loss_case(B, S, T, seed, snr, mode)
         est = torch.tensor(est_np, requires_grad=True)
         tgt = torch.tensor(tgt_np)
@@ -56,8 +70,11 @@ def main():
                             grad_sum=g.sum(-1).astype(np.float64), grad_sqsum=(g.astype(np.float64) ** 2).sum(-1))
         manifest[name] = dict(batch=B, n_src=S, T=T, seed=seed, snr_db=snr, mode=mode, loss=float(l.item()),
                               raw=float(raw.item()))
+        if variants:
+            manifest[name].update(sdr_type=sdr_type, zero_mean=zm, take_log=tl)
         print(name, manifest[name])
-    json.dump(manifest, open(os.path.join(out_dir, "LOSS_MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    json.dump(manifest, open(os.path.join(out_dir, "LOSSV_MANIFEST.json" if variants else "LOSS_MANIFEST.json"), "w"),
+              indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
