@@ -159,6 +159,31 @@ __device__ __forceinline__ float srf_dpp_wave_sum(float v) {
   return v;
 }
 
+// fp64 variant (two 32-bit DPP moves per step); total in lane 63.  For dependent chains of small reductions, where the
+// ~100-cycle ds_bpermute steps of srf_wave_sum(double) are the critical path.
+__device__ __forceinline__ double srf_dpp_wave_sum(double v) {
+  auto step = [](double x, auto ctrl_tag) {
+    constexpr int CTRL = decltype(ctrl_tag)::ctrl, RMASK = decltype(ctrl_tag)::rmask;
+    const long long xi = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(xi & 0xffffffffLL), CTRL, RMASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(xi >> 32), CTRL, RMASK, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  };
+  struct T1 { enum { ctrl = 0x111, rmask = 0xf }; };
+  struct T2 { enum { ctrl = 0x112, rmask = 0xf }; };
+  struct T4 { enum { ctrl = 0x114, rmask = 0xf }; };
+  struct T8 { enum { ctrl = 0x118, rmask = 0xf }; };
+  struct B15 { enum { ctrl = 0x142, rmask = 0xa }; };
+  struct B31 { enum { ctrl = 0x143, rmask = 0xc }; };
+  v += step(v, T1{});
+  v += step(v, T2{});
+  v += step(v, T4{});
+  v += step(v, T8{});
+  v += step(v, B15{});
+  v += step(v, B31{});
+  return v;
+}
+
 // PReLU_a(x) = x >= 0 ? x : a x, as ONE multiply and ONE v_med3_f32 for any slope: max(x, a x) when a <= 1,
 // min(x, a x) when a > 1, i.e. the median of {x, a x, +inf} resp. {x, a x, -inf}; the third operand depends on the
 // (wave-uniform, loop-invariant) slope only.  The compare + select form costs three VALU instructions per element

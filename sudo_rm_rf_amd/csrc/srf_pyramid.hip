@@ -605,9 +605,11 @@ struct PyrFinArgs {
 };
 
 #define SRF_FIN_CPT 8   // channels per thread (C <= 256 * 8)
+// CPT = channels per thread (C <= 256 * CPT): 2 covers the published models (C = 512) and keeps the whole example's
+// moments in registers; 8 is the general fallback (moments fetched level by level).
+template <int CPT>
 __global__ __launch_bounds__(256) void srf_pyramid_finalize_kernel(PyrFinArgs a) {
   __shared__ double red[16];
-  __shared__ float bc[2];
   const long g = blockIdx.x;
   const int tid = threadIdx.x, C = a.C, D = a.D;
   if (a.in_sums && tid < 64) {   // wavefront 0: the input norm's {mean, rstd} for pass 2
@@ -618,35 +620,73 @@ __global__ __launch_bounds__(256) void srf_pyramid_finalize_kernel(PyrFinArgs a)
       a.in_mr[2 * g + 1] = r;
     }
   }
-  double alpha[SRF_FIN_CPT], kap[SRF_FIN_CPT], g0[SRF_FIN_CPT], g1[SRF_FIN_CPT], gl[SRF_FIN_CPT];
+  double alpha[CPT], kap[CPT], g0[CPT], g1[CPT], gl[CPT];
 #pragma unroll
-  for (int i = 0; i < SRF_FIN_CPT; ++i) {
+  for (int i = 0; i < CPT; ++i) {
     alpha[i] = 1.0;
     kap[i] = g0[i] = g1[i] = gl[i] = 0.0;
   }
-  for (int k = 0; k < D; ++k) {
+  // Latency, not work, is what this kernel costs (one block per example, D dependent block reductions): all of the
+  // example's moments are requested up front, and every level's coefficient loads are issued before that level's
+  // reduction so that their latency overlaps the shuffles and barriers (was 15 us per launch with the loads inside
+  // the dependent chain).
+  constexpr bool PRE = CPT <= 2;
+  double mo[PRE ? SRF_MAX_DEPTH : 1][CPT][5];
+  auto load_level = [&](int slot, int k) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = min(tid + 256 * i, C - 1);   // clamped: unconditional loads
+      const double* m = a.mom + ((g * C + c) * D + k) * 5;
+#pragma unroll
+      for (int e = 0; e < 5; ++e) mo[slot][i][e] = m[e];
+    }
+  };
+  if (PRE) {
+#pragma unroll
+    for (int k = 0; k < SRF_MAX_DEPTH; ++k) load_level(PRE ? k : 0, k < D ? k : 0);
+  }
+#pragma unroll
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) {
+    if (k >= D) break;
     const int Lk = a.L >> k;
+    const int slot = PRE ? k : 0;
+    if (!PRE) load_level(0, k);
+    // next level's coefficients (independent of this level's statistics)
+    float gam_[CPT], bet_[CPT], w_[CPT][5], bias_[CPT];
+    if (k + 1 < D) {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int c = min(tid + 256 * i, C - 1);
+        gam_[i] = a.gamma[k][c];
+        bet_[i] = a.beta[k][c];
+        bias_[i] = a.bias[k + 1][c];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) w_[i][t] = a.w[k + 1][c * 5 + t];
+      }
+    }
     double s = 0.0, q = 0.0;
 #pragma unroll
-    for (int i = 0; i < SRF_FIN_CPT; ++i) {
+    for (int i = 0; i < CPT; ++i) {
       const int c = tid + 256 * i;
       if (c < C) {
-        const double* m = a.mom + ((g * C + c) * D + k) * 5;
-        const double S1 = m[0], S2 = m[1], e0 = m[2], e1 = m[3], el = m[4];
+        const double S1 = mo[slot][i][0], S2 = mo[slot][i][1], e0 = mo[slot][i][2], e1 = mo[slot][i][3], el = mo[slot][i][4];
         s += alpha[i] * S1 + (Lk - 3) * kap[i] + g0[i] + g1[i] + gl[i];
         q += alpha[i] * alpha[i] * S2 +
              2.0 * alpha[i] * (kap[i] * (S1 - e0 - e1 - el) + g0[i] * e0 + g1[i] * e1 + gl[i] * el) +
              (Lk - 3) * kap[i] * kap[i] + g0[i] * g0[i] + g1[i] * g1[i] + gl[i] * gl[i];
       }
     }
-    s = srf_wave_sum(s);
-    q = srf_wave_sum(q);
-    if ((tid & 63) == 0) {
+    s = srf_dpp_wave_sum(s);   // VALU-only reductions: this chain is the kernel's critical path
+    q = srf_dpp_wave_sum(q);
+    if ((tid & 63) == 63) {
       red[(tid >> 6) * 2] = s;
       red[(tid >> 6) * 2 + 1] = q;
     }
     __syncthreads();
-    if (tid == 0) {
+    // every thread finalises the level itself (same inputs, same arithmetic: identical values) -- no second
+    // barrier-and-broadcast round
+    float mean_f, rstd_f;
+    {
       double ts = 0.0, tq = 0.0;
       for (int w = 0; w < 4; ++w) {
         ts += red[2 * w];
@@ -656,25 +696,24 @@ __global__ __launch_bounds__(256) void srf_pyramid_finalize_kernel(PyrFinArgs a)
       const double mean = ts / n;
       double var = tq / n - mean * mean;
       var = var < 0.0 ? 0.0 : var;
-      bc[0] = (float)mean;
-      bc[1] = (float)(1.0 / sqrt(var + 1e-8));
-      a.lvl[(g * D + k) * 2 + 0] = bc[0];
-      a.lvl[(g * D + k) * 2 + 1] = bc[1];
+      mean_f = (float)mean;
+      rstd_f = (float)(1.0 / sqrt(var + 1e-8));
+      if (tid == 0) {
+        a.lvl[(g * D + k) * 2 + 0] = mean_f;
+        a.lvl[(g * D + k) * 2 + 1] = rstd_f;
+      }
     }
-    __syncthreads();
-    const float mean_f = bc[0], rstd_f = bc[1];
     if (k + 1 < D) {
 #pragma unroll
-      for (int i = 0; i < SRF_FIN_CPT; ++i) {
+      for (int i = 0; i < CPT; ++i) {
         const int c = tid + 256 * i;
         if (c < C) {
           // exactly the fp32 coefficients pass 2 will use
-          const float af = a.gamma[k][c] * rstd_f;
-          const float bf = a.beta[k][c] - mean_f * af;
+          const float af = gam_[i] * rstd_f;
+          const float bf = bet_[i] - mean_f * af;
           const double A = (double)af, B = (double)bf;
-          const float* ww = a.w[k + 1] + c * 5;
-          const double w0 = ww[0], w1 = ww[1], w2 = ww[2], w3 = ww[3], w4 = ww[4];
-          const double bs = (double)a.bias[k + 1][c];
+          const double w0 = w_[i][0], w1 = w_[i][1], w2 = w_[i][2], w3 = w_[i][3], w4 = w_[i][4];
+          const double bs = (double)bias_[i];
           const double sw = w0 + w1 + w2 + w3 + w4;
           const double nk = bs + A * kap[i] * sw + B * sw;
           const double n0 = bs + A * (w2 * g0[i] + w3 * g1[i] + w4 * kap[i]) + B * (w2 + w3 + w4);
@@ -688,7 +727,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_finalize_kernel(PyrFinArgs a)
         }
       }
     }
-    __syncthreads();
+    __syncthreads();   // red[] is rewritten by the next level
   }
 }
 
@@ -701,6 +740,13 @@ static size_t pyr_lds_bytes(int L, int D) {
   if (lv > sizeA) sizeA = lv;
   sizeA = (sizeA + 3) & ~(size_t)3;
   return sizeof(float) * ((size_t)L + 8 + sizeA) + sizeof(double) * (4 * SRF_MAX_DEPTH * 2 + 8);
+}
+
+static void srf_pyramid_finalize_launch(const PyrFinArgs& f, int groups, int C, hipStream_t st) {
+  if (C <= 512)
+    hipLaunchKernelGGL(srf_pyramid_finalize_kernel<2>, dim3((unsigned)groups), dim3(256), 0, st, f);
+  else
+    hipLaunchKernelGGL((srf_pyramid_finalize_kernel<SRF_FIN_CPT>), dim3((unsigned)groups), dim3(256), 0, st, f);
 }
 
 bool srf_pyramid_reg_supported(int L, int D);
@@ -859,7 +905,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
     int rc = srf_pyramid_reg_launch(r, true, rows, st);
     if (rc) return rc;
     if (!(srf_debug_flags() & 128)) f.in_sums = a.in_norm.sums;
-    hipLaunchKernelGGL(srf_pyramid_finalize_kernel, dim3((unsigned)groups), dim3(256), 0, st, f);
+    srf_pyramid_finalize_launch(f, groups, C, st);
     SRF_CHECK_LAUNCH("pyramid_finalize", st);
     return srf_pyramid_reg_launch(r, false, rows, st);
   }
@@ -876,7 +922,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
     }
     hipLaunchKernelGGL(srf_pyramid_tile_kernel<true>, dim3(nb), dim3(256), tl, st, a, tile);
     SRF_CHECK_LAUNCH("pyramid_moments", st);
-    hipLaunchKernelGGL(srf_pyramid_finalize_kernel, dim3((unsigned)groups), dim3(256), 0, st, f);
+    srf_pyramid_finalize_launch(f, groups, C, st);
     SRF_CHECK_LAUNCH("pyramid_finalize", st);
     hipLaunchKernelGGL(srf_pyramid_tile_kernel<false>, dim3(nb), dim3(256), tl, st, a, tile);
     SRF_CHECK_LAUNCH("pyramid_merge", st);
@@ -915,7 +961,7 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
   const long nblk1 = cached_n1 < rows ? cached_n1 : rows, nblk2 = cached_n2 < rows ? cached_n2 : rows;
   hipLaunchKernelGGL(srf_pyramid_kernel<true>, dim3((unsigned)nblk1), dim3(256), ldsb, st, a);
   SRF_CHECK_LAUNCH("pyramid_moments", st);
-  hipLaunchKernelGGL(srf_pyramid_finalize_kernel, dim3((unsigned)groups), dim3(256), 0, st, f);
+  srf_pyramid_finalize_launch(f, groups, C, st);
   SRF_CHECK_LAUNCH("pyramid_finalize", st);
   hipLaunchKernelGGL(srf_pyramid_kernel<false>, dim3((unsigned)nblk2), dim3(256), ldsb, st, a);
   SRF_CHECK_LAUNCH("pyramid_merge", st);
