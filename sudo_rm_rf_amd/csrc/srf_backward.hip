@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, l
     return arstd * (agam * gz - am1 - xh * am2);
   };
   float n0 = 0.f, n1 = 0.f, n2 = 0.f;   // FUSE: sum g_z, sum g_z xh, slope term of the prologue norm
-  const int Lin = a.Lin, Lout = a.Lout, L4 = a.Lin >> 2;
+  const int Lin = a.Lin, L4 = a.Lin >> 2;
   auto pro = [&](float v) {
     v = fmaf(v, sc, sh);
     return act ? srf_prelu(v, slope) : v;
