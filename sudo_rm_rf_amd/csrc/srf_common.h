@@ -184,6 +184,26 @@ __device__ __forceinline__ double srf_dpp_wave_sum(double v) {
   return v;
 }
 
+// srf_finalize_stats with the bucket reduction on the VALU (DPP) instead of 24 dependent ds_bpermute steps -- for
+// kernels that finalise inside their main loop (persistent GEMM: once per tile).  Same value up to the fp64 summation
+// order (<= 1 ulp of the fp32 results).  MUST be called by a full, converged wavefront.
+__device__ __forceinline__ void srf_finalize_stats_dpp(const double* sums, long g, double inv_count, float& mean,
+                                                       float& rstd) {
+  const double2 bk = reinterpret_cast<const double2*>(sums)[g * SRF_STAT_BUCKETS + (threadIdx.x & (SRF_STAT_BUCKETS - 1))];
+  auto bcast63 = [](double x) {
+    const long long xi = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(xi & 0xffffffffLL), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(xi >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  };
+  const double s = bcast63(srf_dpp_wave_sum(bk.x)), q = bcast63(srf_dpp_wave_sum(bk.y));
+  const double m = s * inv_count;
+  double v = q * inv_count - m * m;
+  v = v < 0.0 ? 0.0 : v;
+  mean = (float)m;
+  rstd = (float)(1.0 / sqrt(v + 1e-8));
+}
+
 // PReLU_a(x) = x >= 0 ? x : a x, as ONE multiply and ONE v_med3_f32 for any slope: max(x, a x) when a <= 1,
 // min(x, a x) when a > 1, i.e. the median of {x, a x, +inf} resp. {x, a x, -inf}; the third operand depends on the
 // (wave-uniform, loop-invariant) slope only.  The compare + select form costs three VALU instructions per element

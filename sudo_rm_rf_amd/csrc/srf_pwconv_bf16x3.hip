@@ -363,20 +363,48 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   }
 
   // tile i of this block -> virtual tile id (XCD-contiguous runs, see srf_xcd_remap; nblk % 8 == 0 keeps
-  // every tile of a block on the block's own XCD)
-  // half: -1 = full tile, 0 / 1 = the half tile covering columns [64 half, 64 half + 64) of its parent tile
-  auto tile_of = [&](int i, int& m0, int& l0, long& b, int& half) {
+  // every tile of a block on the block's own XCD) -> (M tile, time tile, example).
+  // half: -1 = full tile, 0 / 1 = the half tile covering columns [64 half, 64 half + 64) of its parent tile.
+  // Consecutive tiles of a block are nblk/8 virtual ids apart, so the three cursors below (load, convert, epilogue)
+  // step their coordinates with two carries instead of dividing: the divisions by the run-time nMt / nLt cost
+  // ~80 scalar instructions per evaluation, three evaluations per tile -- 14 % of a K = 256 tile's instruction
+  // stream, on a kernel that is instruction-issue bound.
+  struct TileCur {
+    int i, v, mt, lt, b, half;
+  };
+  const int vstep = nblk >> 3;
+  const int st_b = vstep / (nMt * nLt), st_r = vstep - st_b * (nMt * nLt);
+  const int st_l = st_r / nMt, st_m = st_r - st_l * nMt;
+  auto cur_set = [&](TileCur& c, int i) {   // by division: a block's first tile and the half-tile round
     int q = blockIdx.x + i * nblk;
-    half = -1;
+    c.half = -1;
     if (nhalf && i == rounds) {
       q = rounds * nblk + ((int)blockIdx.x >> 1);
-      half = blockIdx.x & 1;
+      c.half = blockIdx.x & 1;
     }
     const int v = srf_xcd_remap(q, total);
-    m0 = (v % nMt) * X3_BM;
-    l0 = ((v / nMt) % nLt) * X3_BN;
-    b = v / (nMt * nLt);
-    return v;
+    const int t = v / nMt;
+    c.i = i;
+    c.v = v;
+    c.mt = v - t * nMt;
+    c.b = t / nLt;
+    c.lt = t - c.b * nLt;
+  };
+  auto cur_next = [&](TileCur& c) {
+    const int i = c.i + 1;
+    if (nhalf && i == rounds) {
+      cur_set(c, i);
+      return;
+    }
+    c.i = i;
+    c.v += vstep;
+    c.mt += st_m;
+    int cy = c.mt >= nMt ? 1 : 0;
+    c.mt -= cy ? nMt : 0;
+    c.lt += st_l + cy;
+    cy = c.lt >= nLt ? 1 : 0;
+    c.lt -= cy ? nLt : 0;
+    c.b += st_b + cy;
   };
 
   const int a_m = tid >> 2, a_pk = tid & 3;
@@ -385,16 +413,16 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   const int b_lds = b_n * X3_PITCH + b_kg * 2;
 
   // ---- load cursor: (tile, k offset) of the next k-tile to fetch
-  int ld_i = 0, ld_k = 0;
+  int ld_k = 0;
+  TileCur ldc;
   const float* a_src;
   const float* b_src;
   __amdgpu_buffer_rsrc_t a_rs, b_rs;     // BUF: descriptors of W and of the tile's example X_b
   int a_vo = 0, b_vo = 0;                // BUF: per-lane byte offsets inside them
   if (BUF) a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, Cout * Cin * 4, 0x00020000);
-  auto ld_tile = [&](int i) {
-    int m0, l0, hf;
-    long b;
-    tile_of(i, m0, l0, b, hf);
+  auto ld_tile = [&]() {
+    const int m0 = ldc.mt * X3_BM, l0 = ldc.lt * X3_BN;
+    const long b = ldc.b;
     if (BUF) {
       a_vo = ((m0 + a_m) * Cin + a_pk * 8) * 4;                         // rows >= Cout land beyond the descriptor: 0
       b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * Cin * L, 0, Cin * L * 4, 0x00020000);
@@ -406,7 +434,8 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
       b_src = a.x + ((size_t)b * Cin + b_kg) * L + (b_ok ? (l0 + b_n) : 0);   // clamped; never stored if !ok
     }
   };
-  ld_tile(0);
+  cur_set(ldc, 0);
+  ld_tile();
   struct Regs {
     float4 a[2];
     float b[8];
@@ -429,21 +458,23 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
     ld_k += X3_BK;
     if (ld_k == Cin) {   // wave-uniform; past the last tile the cursor re-reads that tile (harmless)
       ld_k = 0;
-      if (ld_i + 1 < ntile) ld_tile(++ld_i);
+      if (ldc.i + 1 < ntile) {
+        cur_next(ldc);
+        ld_tile();
+      }
     }
   };
 
   // ---- convert cursor: (tile, k offset) of the next k-tile to split into LDS
-  int cv_i = 0, cv_k = 0;
+  int cv_k = 0;
+  TileCur cvc;
   float a_msk = 0.f, mean = 0.f, rstd = 1.f;
-  auto cv_tile = [&](int i) {
-    int m0, l0, hf;
-    long b;
-    tile_of(i, m0, l0, b, hf);
-    a_msk = (BUF || (m0 + a_m) < Cout) ? 1.f : 0.f;
-    if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
+  auto cv_tile = [&]() {
+    a_msk = (BUF || (cvc.mt * X3_BM + a_m) < Cout) ? 1.f : 0.f;
+    if (PRO == 1 || PRO == 2) srf_finalize_stats_dpp(a.nrm.sums, cvc.b, a.inv_count, mean, rstd);
   };
-  cv_tile(0);
+  cur_set(cvc, 0);
+  cv_tile();
   auto lds_store = [&](const Regs& r, int stage) {
     char* base = smem + stage * X3_STAGE;
     const float va[8] = {r.a[0].x * a_msk, r.a[0].y * a_msk, r.a[0].z * a_msk, r.a[0].w * a_msk,
@@ -470,7 +501,10 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
     cv_k += X3_BK;
     if (cv_k == Cin) {
       cv_k = 0;
-      if (cv_i + 1 < ntile) cv_tile(++cv_i);
+      if (cvc.i + 1 < ntile) {
+        cur_next(cvc);
+        cv_tile();
+      }
     }
   };
 
@@ -517,6 +551,8 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
   __syncthreads();
   float* strip = reinterpret_cast<float*>(smem + X3_STAGE) + wave * (32 * SRF_EPI_PITCH_H);   // stage 1
   int g = 0;
+  TileCur epc;
+  cur_set(epc, 0);
   for (int i = 0; i < ntile; ++i) {
     cur_half = (nhalf && i == rounds) ? (int)(blockIdx.x & 1) : -1;
     br0 = cur_half < 0 ? b_row0 : (cur_half * 64 + wn * 32) * X3_PITCH + frag;
@@ -527,9 +563,8 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
     }
     // the tile's last k-tile sat in stage 1, which every wave has finished reading (barrier above);
     // stage 0 already holds the next tile's first k-tile
-    int m0, l0, hf;
-    long b;
-    const int v = tile_of(i, m0, l0, b, hf);
+    const int m0 = epc.mt * X3_BM, l0 = epc.lt * X3_BN, v = epc.v;
+    const long b = epc.b;
     float s = 0.f, q = 0.f;
     if (cur_half < 0) {
       srf_pw_epilogue_half(a, acc0, strip, b, m0 + wm * 32, l0 + wn * 64, lane, s, q);
@@ -547,6 +582,7 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    if (i + 1 < ntile) cur_next(epc);
     __syncthreads();   // strip reads done before the next step's split overwrites stage 1
   }
 }
