@@ -49,6 +49,8 @@ __device__ __forceinline__ void srf_split8(const float (&v)[8], bf16x8& hi, bf16
 //   * the activation tile as 2 coalesced dwordx4 loads per thread instead of 8 dword loads (what a [k][time] LDS
 //     image read back with ds_read_b64_tr_b16 would issue; tools/probes/tr_probe.hip documents that instruction):
 //     timing-only experiment inside the forward, 132 vs 137 us -- the VMEM instruction count is not the limiter.
+//   * static s_setprio 1 for the block's younger four wavefronts (persistent kernel): 164-166 vs 161 us on res_conv,
+//     125-127 vs 124 us on proj_1x1 (same-box A/B, tools/lib_ab.sh) -- slower.
 
 // ---------------------------------------------------------------------------------------------
 // One tile per block.
