@@ -121,6 +121,8 @@ def pmc_traffic(kernel_family, workload):
            "pw_conv_mfma": "srf_pw_mfma_kernel",
            "pyramid_moments": "srf_pyramid_reg_kernel<true", "pyramid_merge": "srf_pyramid_reg_kernel<false"
            }.get(kernel_family, kernel_family)
+    if kernel_family.startswith("pw_conv_bf16x3_p8<"):       # one label per prologue variant = one rocprof kernel name
+        key = "srf_pw_bf16x3_p8_kernel<%s," % kernel_family[len("pw_conv_bf16x3_p8<"):-1]
     fetch, write = {}, {}
     import csv
     rows = [r for r in csv.reader(l for l in open(path) if not l.startswith("#"))][1:]
@@ -311,13 +313,16 @@ def main():
         launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, **dims)
         per = {}
         name, ms = C.c_char_p(), C.c_float()
-        assert cnt.value == psteps * len(launches), (cnt.value, psteps, len(launches))
+        marks = []
         for i in range(cnt.value):
             lib.srf_profile_get(i, C.byref(name), C.byref(ms))
+            if not name.value.startswith(b"("):          # "(gap)": host-side idle before a forward, not a kernel
+                marks.append((name.value.decode(), ms.value))
+        assert len(marks) == psteps * len(launches), (len(marks), psteps, len(launches))
+        for i, (k, ms_i) in enumerate(marks):
             fam, nbytes, flops = launches[i % len(launches)]
-            k = name.value.decode()
             e = per.setdefault(k, {"ms": 0.0, "launches": 0, "bytes": 0.0, "flops": 0.0})
-            e["ms"] += ms.value
+            e["ms"] += ms_i
             e["launches"] += 1
             e["bytes"] += nbytes
             e["flops"] += flops

@@ -272,6 +272,9 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
   }
   SRF_CHECK_ARG((((size_t)workspace) & 255) == 0, "srf_forward: workspace must be 256-byte aligned");
   for (int i = 0; i < num_params; ++i) SRF_CHECK_ARG(P[i] != nullptr, "srf_forward: parameter %d is null", i);
+  // profiler: intervals run from mark to mark, so without this one the first kernel's interval would also hold the
+  // host-side gap since the previous forward
+  if (srf_profiling()) srf_prof_mark("(gap)", (hipStream_t)stream);
 
   const srf_config& c = p->cfg;
   const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;

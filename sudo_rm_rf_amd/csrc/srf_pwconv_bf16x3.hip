@@ -637,7 +637,10 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
         case 2: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<2>, gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
         default: hipLaunchKernelGGL(srf_pw_bf16x3_p8_kernel<3>, gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
       }
-      SRF_CHECK_LAUNCH("pw_conv_bf16x3_p8", st);
+      // profiler labels per prologue variant = per rocprofv3 kernel name (srf_pw_bf16x3_p8_kernel<PRO, ...>)
+      static const char* const kLabel[4] = {"pw_conv_bf16x3_p8<0>", "pw_conv_bf16x3_p8<1>", "pw_conv_bf16x3_p8<2>",
+                                            "pw_conv_bf16x3_p8<3>"};
+      SRF_CHECK_LAUNCH(kLabel[pro < 0 || pro > 3 ? 3 : pro], st);
       return SRF_OK;
     }
     if (abl && pro == 0) {

@@ -80,6 +80,8 @@ def main():
     nm, ms = C.c_char_p(), C.c_float()
     for i in range(cnt.value):
         lib.srf_profile_get(i, C.byref(nm), C.byref(ms))
+        if nm.value.startswith(b"("):        # "(gap)": host-side idle, not a kernel
+            continue
         e = per.setdefault(nm.value.decode(), [0.0, 0])
         e[0] += ms.value
         e[1] += 1
