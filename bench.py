@@ -187,6 +187,7 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
         opt.step()
         return l
 
+    l = step()                # set-up, not a step: plan, saved-activation and scratch buffers, optimizer state
     for _ in range(args.warmup):
         l = step()
     D.barrier(dev)
@@ -256,6 +257,7 @@ def main():
         D.barrier(dev)
 
     with torch.no_grad():
+        out = model(wav)      # set-up, not a step: plan + workspace creation and the one-off stream-split auto-tune
         for _ in range(args.warmup):
             out = model(wav)
         barrier()
