@@ -73,10 +73,15 @@ __device__ __forceinline__ void srf_conv_s2(const float (&x)[N], float (&out)[N 
                   fmaf(w[3], e[2 * j + 3], fmaf(w[2], e[2 * j + 2], fmaf(w[1], e[2 * j + 1], fmaf(w[0], e[2 * j], b)))));
 }
 
+// v <- valid ? a v + c : 0.  The mask goes into the coefficients (two selects per call) instead of one select per
+// element: lanes outside the row compute 0 * v + 0 (v is finite: it comes from clamped loads of real data), lanes
+// inside compute exactly fmaf(v, a, c) as before.  Both pyramid kernels are VALU-bound; the per-element selects were
+// 15 % of their VALU instructions.
 template <int N>
 __device__ __forceinline__ void srf_affine_mask(float (&v)[N], float a, float c, bool valid) {
+  const float am = valid ? a : 0.f, cm = valid ? c : 0.f;
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = valid ? fmaf(v[i], a, c) : 0.f;
+  for (int i = 0; i < N; ++i) v[i] = fmaf(v[i], am, cm);
 }
 
 template <int N>
@@ -109,7 +114,8 @@ __device__ __forceinline__ void srf_pyr_edges(double* m5, const float (&v)[N], i
 // PERSIST: wavefronts loop over a contiguous task range with next-task prefetch (measured faster for
 // pass 1, slower for pass 2 whose one-task-per-wave form keeps 8 waves per SIMD resident).
 template <bool MOMENTS, int CH, bool PERSIST = MOMENTS>
-__global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
+// (CH = 16: >= 6 wavefronts per SIMD -- the persistent pass 1 sits right at the 80-VGPR boundary)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 6 : 1))) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   __shared__ float4 pyr_strip[MOMENTS ? 1 : 4 * 60 * (CH / 4 + 1)];   // pass 2: store transposition
   const int lane = threadIdx.x & 63;
   const int L = a.L, D = a.D, C = a.C;
@@ -211,16 +217,18 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
       o[4 * i + 2] = v.z;
       o[4 * i + 3] = v.w;
     }
+    const float scm = valid ? sc : 0.f, shm = valid ? sh : 0.f;   // mask in the coefficients: PReLU(0) = 0
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      float v = fmaf(o[i], sc, sh);
+      float v = fmaf(o[i], scm, shm);
       if (act) v = srf_prelu(v, slope);
-      o[i] = valid ? v : 0.f;
+      o[i] = v;
     }
     srf_conv_s1<CH>(o, x0, lc[0].w, lc[0].b);
+    const float vmask = valid ? 1.f : 0.f;
     if (MOMENTS) {
 #pragma unroll
-      for (int i = 0; i < CH; ++i) x0[i] = valid ? x0[i] : 0.f;
+      for (int i = 0; i < CH; ++i) x0[i] *= vmask;
     } else {
       srf_affine_mask<CH>(x0, lc[0].a, lc[0].c, valid);   // n_0 = GlobLN_0(d_0)
     }
