@@ -93,7 +93,7 @@ class _TrainStep(torch.autograd.Function):
         x = wav.detach().to(torch.float32).contiguous()
         batch, _, T = x.shape
         dev = x.device
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), engine._run_lock(dev):
             plan = engine.plan_for(batch, T, dev)
             saved_bytes, scratch_bytes = plan.train_sizes()
             saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
@@ -103,7 +103,7 @@ class _TrainStep(torch.autograd.Function):
             rc = lib.srf_forward_train(plan.handle, table, len(params), _lib.ptr(x), _lib.ptr(out), _lib.ptr(saved),
                                        saved_bytes, _lib.ptr(scratch), scratch_bytes, _lib.current_stream(dev))
             _lib.check(rc, "srf_forward_train")
-        ctx.plan, ctx.saved_buf, ctx.x = plan, saved, x
+        ctx.plan, ctx.saved_buf, ctx.x, ctx.engine = plan, saved, x, engine
         ctx.save_for_backward(*params)
         engine.last_plan = plan
         return out
@@ -121,7 +121,7 @@ class _TrainStep(torch.autograd.Function):
         for p, n in zip(params, sizes):
             grads.append(flat[off:off + n].view_as(p))
             off += n
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), ctx.engine._run_lock(dev):
             scratch = plan.train_scratch()
             ptab = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
             gtab = (C.c_void_p * len(params))(*[t.data_ptr() for t in grads])
@@ -145,9 +145,26 @@ class ModelEngine:
         self.multi_stream = True          # bench.py switches it off for its per-kernel profiling pass
         self._side_streams = {}
         self._split_choice = {}
+        self._run_locks = {}
+
+    def _run_lock(self, device):
+        """One re-entrant lock per device: a forward is a chain of dependent launches into a workspace, so the launches
+        of two Python threads calling the same module on the same GPU must not interleave (the reference's forward
+        is re-entrant); threads on different GPUs (DataParallel replicas share this object) do not
+        contend."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        with self._lock:
+            lk = self._run_locks.get(idx)
+            if lk is None:
+                lk = self._run_locks[idx] = threading.RLock()
+        return lk
 
     def plan_for(self, batch, T, device, lane=0):
-        """lane: plans of different stream lanes never share a workspace, even for equal sub-batch sizes."""
+        """lane: plans of different stream lanes never share a workspace, even for equal sub-batch sizes.  Lane 0 (work
+        launched on the caller's current stream) is additionally keyed by that stream: callers on different streams
+        get different workspaces."""
+        if lane == 0:
+            lane = (0, torch.cuda.current_stream(device).cuda_stream)
         key = (device.index if device.index is not None else torch.cuda.current_device(), batch, T, lane)
         with self._lock:
             plan = self._plans.get(key)
@@ -206,7 +223,7 @@ class ModelEngine:
         batch, _, T = x.shape
         if batch == 0 or T == 0:
             raise RuntimeError("empty input %s" % (tuple(wav.shape),))
-        with torch.cuda.device(x.device):
+        with torch.cuda.device(x.device), self._run_lock(x.device):
             plan = self.plan_for(batch, T, x.device)
             if plan.num_params != len(params):
                 raise _lib.SrfError("state_dict has %d tensors, plan expects %d" %

@@ -206,3 +206,45 @@ def test_two_stream_split_is_bit_identical(manifest):
         auto = model(wav)          # auto-tuned path
         assert torch.equal(auto, ref)
         assert eng._split_choice
+
+
+@pytest.mark.gpu
+def test_forward_is_reentrant_across_threads_and_streams(manifest):
+    """The reference's forward is re-entrant (DataParallel calls it from one thread per replica; any
+    caller may use its own stream).  Four threads call ONE module concurrently -- two on the default stream, two on
+    their own streams -- and every result equals the sequential one bit for bit."""
+    import threading
+    cfg, sd, wav, _ = load_case(manifest, "cfg1_improved_u8")
+    model = build(cfg, sd)
+    # batches 8 / 9 take the two-stream split path (several C calls per forward), 2 / 3 the single srf_forward call
+    xs = [torch.from_numpy(weights_mix((8, 3, 9, 2)[i], 8000 + 160 * i, seed=50 + i)).to(DEV) for i in range(4)]
+    with torch.no_grad():
+        want = [model(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(DEV) if i >= 2 else torch.cuda.current_stream(DEV)
+            with torch.no_grad(), torch.cuda.stream(st):
+                for _ in range(6):
+                    y = model(xs[i])
+                got[i] = y.clone()
+                st.synchronize()
+        except Exception as e:          # surfaced in the main thread
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(4):
+        assert torch.equal(got[i], want[i]), i
+
+
+def weights_mix(batch, T, seed):
+    from oracle import weights
+    return weights.make_mixture(batch, T, seed=seed)
