@@ -132,6 +132,20 @@ class _TrainStep(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+def _weights(module):
+    """The module's weight tensors in state_dict() order.  For an ordinary module that is exactly
+    state_dict(keep_vars=True).values(); a torch.nn.DataParallel replica keeps its (broadcast, non-leaf) weights in
+    `_former_parameters` of every sub-module and reports an EMPTY state_dict (torch/nn/parallel/replicate.py), so the
+    tree is walked in the same pre-order state_dict uses (run_improved_sudormrf.py:118 trains through such replicas)."""
+    if not getattr(module, "_is_replica", False):
+        return list(module.state_dict(keep_vars=True).values())
+    out = []
+    for m in module.modules():
+        # (a replica's _parameters only keeps the None placeholders, e.g. the bias of a bias-free conv)
+        out.extend(v for v in getattr(m, "_former_parameters", {}).values() if v is not None)
+    return out
+
+
 class ModelEngine:
     """Per-model state: plan cache (per device / batch / length) and the parameter pointer table."""
 
@@ -188,7 +202,7 @@ class ModelEngine:
         return arr
 
     def _run_train(self, module, wav, expected_channels):
-        params = list(module.state_dict(keep_vars=True).values())
+        params = _weights(module)
         for p in params:
             if p.device != wav.device or p.dtype != torch.float32 or not p.is_contiguous():
                 raise _lib.SrfError("all parameters must be contiguous float32 on %s" % wav.device)
@@ -209,12 +223,15 @@ class ModelEngine:
             raise _lib.SrfError(
                 "sudo_rm_rf_amd runs on an MI355X only: input is on %s.  There is deliberately no CPU "
                 "fallback (use the reference implementation for CPU inference)." % wav.device)
-        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+        # (from the state_dict tensors, not module.parameters(): DataParallel replicas hold their weights as plain
+        # tensors -- views that require grad through the Broadcast node -- and report no parameters at all)
+        weights = _weights(module)
+        wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in weights)
         # model.train() + grad mode = the training step (what the reference's runner does before its loop,
         # run_improved_sudormrf.py:144); model.eval() always takes the fused inference path
         if wants_grad and module.training:
             return self._run_train(module, wav, expected_channels)
-        params = [p.detach() for p in module.state_dict(keep_vars=True).values()]
+        params = [p.detach() for p in weights]
         for p in params:
             if p.device != wav.device or p.dtype != torch.float32 or not p.is_contiguous():
                 raise _lib.SrfError("all parameters must be contiguous float32 on %s" % wav.device)

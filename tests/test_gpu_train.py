@@ -205,3 +205,37 @@ def test_fused_clip_adam_matches_torch(clip):
         for name in ("exp_avg", "exp_avg_sq"):
             a, b = sa[k][name], sb[k][name]
             assert ((a - b).abs() <= 1e-7 + 1e-4 * a.abs()).all(), name
+
+
+def test_data_parallel_replicas_forward_and_train():
+    """run_improved_sudormrf.py:118 wraps the model in torch.nn.DataParallel: replicas hold their weights as plain
+    (non-Parameter) tensors behind a Broadcast node and are called from one thread each.  Two replicas on the one
+    available GPU: same outputs as the module itself, and the gradients reach the original parameters."""
+    from torch.nn.parallel import parallel_apply, replicate
+    cfg = ModelConfig("improved", 16, 32, 2, 3, 21, 24, 2)
+    sd = weights.make_state_dict(cfg, seed=21)
+    model = build(cfg, sd).train()
+    xs = [torch.from_numpy(weights.make_mixture(2, 800, seed=30 + i)).to(DEV) for i in range(2)]
+    # reference gradients: the module itself, one example batch after the other
+    model.zero_grad()
+    want_out = []
+    for x in xs:
+        y = model(x)
+        want_out.append(y.detach().clone())
+        y.square().sum().backward()
+    want_grad = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    replicas = replicate(model, [0, 0])
+    assert not list(replicas[0].parameters())            # the situation the engine has to cope with
+    outs = parallel_apply(replicas, [(x,) for x in xs], devices=[0, 0])
+    for y, w in zip(outs, want_out):
+        assert y.requires_grad and torch.equal(y.detach(), w)
+    sum(y.square().sum() for y in outs).backward()
+    for p, w in zip(model.parameters(), want_grad):
+        assert p.grad is not None
+        scale = w.abs().max().clamp_min(1e-12)
+        assert ((p.grad - w).abs().max() / scale).item() <= 1e-5
+    # inference under DataParallel proper (single device id: the wrapper calls the module directly)
+    dp = torch.nn.DataParallel(model.eval(), device_ids=[0])
+    with torch.no_grad():
+        assert torch.equal(dp(xs[0]), build(cfg, sd).eval()(xs[0]))
