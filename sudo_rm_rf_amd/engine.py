@@ -208,6 +208,10 @@ class ModelEngine:
                 raise _lib.SrfError("all parameters must be contiguous float32 on %s" % wav.device)
         if wav.shape[0] == 0 or wav.shape[-1] == 0:
             raise RuntimeError("empty input %s" % (tuple(wav.shape),))
+        if wav.requires_grad:
+            # srf_backward produces the parameter gradients only; returning None here would be a silent zero
+            raise NotImplementedError("the HIP training step does not produce the gradient w.r.t. the input waveform "
+                                      "(no runner of the reference needs it): detach the input")
         return _TrainStep.apply(self, module.num_sources * expected_channels, wav, *params)
 
     def run(self, module, wav, expected_channels):

@@ -239,3 +239,12 @@ def test_data_parallel_replicas_forward_and_train():
     dp = torch.nn.DataParallel(model.eval(), device_ids=[0])
     with torch.no_grad():
         assert torch.equal(dp(xs[0]), build(cfg, sd).eval()(xs[0]))
+
+
+def test_input_gradient_is_refused_not_silently_dropped():
+    cfg = ModelConfig("improved", 16, 32, 1, 2, 21, 24, 2)
+    model = build(cfg, weights.make_state_dict(cfg, seed=3)).train()
+    x = torch.from_numpy(weights.make_mixture(2, 400, seed=4)).to(DEV).requires_grad_()
+    with pytest.raises(NotImplementedError):
+        model(x)
+    assert model(x.detach()).requires_grad
