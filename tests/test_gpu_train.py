@@ -248,3 +248,37 @@ def test_input_gradient_is_refused_not_silently_dropped():
     with pytest.raises(NotImplementedError):
         model(x)
     assert model(x.detach()).requires_grad
+
+
+def test_distributed_data_parallel_wrapper_single_rank():
+    """torch DistributedDataParallel around the module (world size 1, RCCL): its gradient hooks fire on the gradients
+    the HIP backward returns, and the result equals the plain module's."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    cfg = ModelConfig("improved", 16, 32, 1, 2, 21, 24, 2)
+    sd = weights.make_state_dict(cfg, seed=41)
+    x = torch.from_numpy(weights.make_mixture(2, 400, seed=42)).to(DEV)
+    ref = build(cfg, sd).train()
+    ref(x).square().sum().backward()
+    want = [p.grad.clone() for p in ref.parameters()]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device(DEV))
+    except Exception as e:      # an RCCL / rendezvous problem of the box is not what this test is about
+        pytest.skip("could not create a 1-rank RCCL process group: %r" % (e,))
+    try:
+        ddp = DDP(build(cfg, sd).train(), device_ids=[0])
+        ddp(x).square().sum().backward()
+        for p, w in zip(ddp.module.parameters(), want):
+            assert p.grad is not None and torch.equal(p.grad, w)
+    finally:
+        dist.destroy_process_group()
