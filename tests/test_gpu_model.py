@@ -248,3 +248,27 @@ def test_forward_is_reentrant_across_threads_and_streams(manifest):
 def weights_mix(batch, T, seed):
     from oracle import weights
     return weights.make_mixture(batch, T, seed=seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["improved", "groupcomm"])
+def test_degenerate_inputs_match_oracle(variant):
+    """Silence (zero variance in the first GlobLN: rstd = 1e4 from the 1e-8 epsilon), a constant offset and a
+    large-amplitude mixture: same outputs as the oracle, relative to the output scale."""
+    from oracle import weights
+    from oracle.schema import ModelConfig
+    cfg = (ModelConfig("improved", 16, 32, 2, 3, 21, 24, 2) if variant == "improved"
+           else ModelConfig("groupcomm", 32, 64, 2, 3, 21, 24, 2, 1, 4))
+    sd = weights.make_state_dict(cfg, seed=8)
+    model = build(cfg, sd)
+    sdt = torch_oracle.to_torch(sd)
+    g = torch.Generator().manual_seed(5)
+    cases = {"silence": torch.zeros(2, 1, 1600), "constant": torch.full((2, 1, 1600), 0.37),
+             "loud": torch.randn(2, 1, 1600, generator=g) * 1e3, "tiny": torch.randn(2, 1, 1600, generator=g) * 1e-6}
+    for name, wav in cases.items():
+        with torch.no_grad():
+            want = torch_oracle.forward(cfg, {k: v.double() for k, v in sdt.items()}, wav.double())
+            got = model(wav.to(DEV)).cpu().double()
+        assert torch.isfinite(got).all(), name
+        scale = max(want.abs().max().item(), 1e-6)
+        assert (got - want).abs().max().item() <= 2e-4 * scale + 1e-6, (name, (got - want).abs().max().item(), scale)
