@@ -602,6 +602,8 @@ struct PyrFinArgs {
   double in_inv_count;
   float* in_mr;
   int C, L, D;
+  double* lv_sums[SRF_MAX_DEPTH];   // training forward: every level's {sum d_k, sum d_k^2} goes to bucket 0 of its
+                                    // GlobLN statistic slot [groups][SRF_STAT_BUCKETS][2] (zeroed by the caller), or null
 };
 
 #define SRF_FIN_CPT 8   // channels per thread (C <= 256 * 8)
@@ -701,6 +703,11 @@ __global__ __launch_bounds__(256) void srf_pyramid_finalize_kernel(PyrFinArgs a)
       if (tid == 0) {
         a.lvl[(g * D + k) * 2 + 0] = mean_f;
         a.lvl[(g * D + k) * 2 + 1] = rstd_f;
+        if (a.lv_sums[k]) {   // what the un-fused path's per-level statistics would hold (consumer: the backward)
+          double* dst = a.lv_sums[k] + (size_t)g * SRF_STAT_BUCKETS * 2;
+          dst[0] = ts;
+          dst[1] = tq;
+        }
       }
     }
     if (k + 1 < D) {
@@ -802,34 +809,30 @@ static bool pyr_pick_tile(int L, int D, PyrTile* t) {
 }
 
 // register-resident kernels (srf_pyramid_reg.hip)
-struct PyrRegArgs {
-  const float* y1;
-  float* d0;
-  float* merged;
-  SrfNormDev in_norm;
-  const float* in_mr;
-  double in_inv_count;
-  const float* w[SRF_MAX_DEPTH];
-  const float* bias[SRF_MAX_DEPTH];
-  const float* gamma[SRF_MAX_DEPTH];
-  const float* beta[SRF_MAX_DEPTH];
-  const float* lvl;
-  double* mom;
-  double* out_sums;
-  int rows;
-  int rpw;
-  int C, L, D, tiles, own;
-  int abl;
-};
-bool srf_pyramid_reg_supported(int L, int D);
-int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st);
+#include "srf_pyr.h"
 
 static bool g_pyr_attr_set = false;
+
+// lv_out / lv_sums (both or neither; register-resident kernels only -- srf_pyramid_reg_supported): the training
+// forward's extra outputs, see PyrRegArgs::lv_out and PyrFinArgs::lv_sums.
+int srf_pyramid_impl(const float* y1, float* merged, const srf_norm* in_norm, const float* const* w,
+                     const float* const* bias, const float* const* gamma, const float* const* beta, int groups, int C,
+                     int L, int D, void* scratch, double* out_sums, float* const* lv_out, double* const* lv_sums,
+                     void* stream);
 
 extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_norm,
                            const float* const* w, const float* const* bias, const float* const* gamma,
                            const float* const* beta, int groups, int C, int L, int D, void* scratch,
                            double* out_sums, void* stream) {
+  return srf_pyramid_impl(y1, merged, in_norm, w, bias, gamma, beta, groups, C, L, D, scratch, out_sums, nullptr, nullptr,
+                          stream);
+}
+
+int srf_pyramid_impl(const float* y1, float* merged, const srf_norm* in_norm, const float* const* w,
+                     const float* const* bias, const float* const* gamma, const float* const* beta, int groups, int C,
+                     int L, int D, void* scratch, double* out_sums, float* const* lv_out, double* const* lv_sums,
+                     void* stream) {
+  SRF_CHECK_ARG((lv_out == nullptr) == (lv_sums == nullptr), "srf_pyramid: level outputs and level sums come together");
   SRF_CHECK_ARG(y1 && merged && w && bias && gamma && beta && scratch, "srf_pyramid: null pointer");
   SRF_CHECK_ARG(groups > 0 && C > 0 && L > 0, "srf_pyramid: bad sizes");
   SRF_CHECK_ARG(srf_pyramid_supported(C, L, D), "srf_pyramid: unsupported shape C=%d L=%d D=%d", C, L, D);
@@ -871,8 +874,12 @@ extern "C" int srf_pyramid(const float* y1, float* merged, const srf_norm* in_no
   f.C = C;
   f.L = L;
   f.D = D;
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) f.lv_sums[k] = (lv_sums && k < D) ? lv_sums[k] : nullptr;
+  SRF_CHECK_ARG(!lv_out || (!(srf_debug_flags() & (64 | 128)) && srf_pyramid_reg_supported(L, D)),
+                "srf_pyramid: level outputs need the register-resident kernels");
   if (!(srf_debug_flags() & 64) && srf_pyramid_reg_supported(L, D)) {
     PyrRegArgs r;
+    for (int k = 0; k < SRF_MAX_DEPTH; ++k) r.lv_out[k] = (lv_out && k < D) ? lv_out[k] : nullptr;
     r.y1 = y1;
     r.d0 = a.d0;
     r.merged = merged;

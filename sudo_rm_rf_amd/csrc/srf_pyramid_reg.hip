@@ -11,27 +11,8 @@
 // cone of the deepest level reaches 30 (62) level-0 samples = 2 chunks); halo lanes recompute what the
 // neighbouring wavefront owns.  Global accesses are 4 (8) float4 per lane at a 64-B (128-B) lane
 // stride: every byte of a line is used by the same wavefront, L1 merges the pieces.
-#include "srf_common.h"
+#include "srf_pyr.h"
 
-struct PyrRegArgs {
-  const float* y1;     // pass 1 input
-  float* d0;           // unused by the register kernels (the LDS kernels of srf_pyramid.hip stage level 0 here)
-  float* merged;       // pass 2 output (may alias y1)
-  SrfNormDev in_norm;  // proj_1x1 GlobLN (+PReLU)
-  const float* in_mr;  // [groups][2] pre-finalised {mean, rstd} of in_norm (non-persistent pass 1 only)
-  double in_inv_count; // 1 / (C * L)
-  const float* w[SRF_MAX_DEPTH];
-  const float* bias[SRF_MAX_DEPTH];
-  const float* gamma[SRF_MAX_DEPTH];
-  const float* beta[SRF_MAX_DEPTH];
-  const float* lvl;    // [groups][D][2] {mean, rstd} per level (pass 2)
-  double* mom;         // [rows][D][5] (pass 1; zeroed by the host)
-  double* out_sums;    // merged statistics (pass 2)
-  int rows;            // groups * C
-  int rpw;             // rows per (persistent) wavefront
-  int C, L, D, tiles, own;   // own = own chunks per tile
-  int abl;             // diagnostics: 1 = plain stores instead of moment atomics, 2 = no wave reductions
-};
 
 template <int N>
 __device__ __forceinline__ void srf_zero(float (&v)[N]) {
@@ -108,12 +89,55 @@ __device__ __forceinline__ void srf_pyr_edges(double* m5, const float (&v)[N], i
   if (ci == nchunks - 1) m5[4] = (double)v[N - 1];
 }
 
+// Own chunk j = lane - 2 of a wavefront -> global row, through the wave-private strip: chunk j sits at float4 offset
+// j*(NF+1) (odd pitch in 16-B units: conflict-free both ways), then every store instruction writes 64 consecutive
+// float4 = 1 KB.  Ends with a wavefront barrier so the strip can be reused.
+template <int CH>
+__device__ __forceinline__ void srf_pyr_store_chunks(float4* strip, const float (&v)[CH], bool own, float* row_base,
+                                                     int first_chunk, int cnt, int lane) {
+  constexpr int NF = CH / 4, PF = NF + 1;
+  const int j = lane - 2;
+  if (own) {
+#pragma unroll
+    for (int i = 0; i < NF; ++i) strip[j * PF + i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float4* dst = reinterpret_cast<float4*>(row_base + (size_t)first_chunk * CH);
+#pragma unroll
+  for (int it = 0; it < (60 * NF + 63) / 64; ++it) {
+    const int f = it * 64 + lane;
+    if (f < cnt * NF) dst[f] = strip[(f / NF) * PF + (f % NF)];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// a lane's N consecutive values of a deeper level (N * 4 bytes, naturally aligned: neighbouring lanes are contiguous)
+template <int N>
+__device__ __forceinline__ void srf_pyr_store_level(float* dst, const float (&v)[N]) {
+  if constexpr (N >= 4) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i)
+      reinterpret_cast<float4*>(dst)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  } else if constexpr (N == 2) {
+    *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+  } else {
+    dst[0] = v[0];
+  }
+}
+
 // MOMENTS: pass 1 (y1 -> raw cascade -> row moments; writes nothing else).  !MOMENTS: pass 2 (y1 -> level 0
 // again, normalised cascade -> merged).  Recomputing level 0 (5 MAC/elem) is cheaper than the d0 round trip
 // through HBM that an earlier version made (pass 1 measured 138 us with the d0 store, 81 us without).
 // PERSIST: wavefronts loop over a contiguous task range with next-task prefetch (measured faster for
 // pass 1, slower for pass 2 whose one-task-per-wave form keeps 8 waves per SIMD resident).
-template <bool MOMENTS, int CH, bool PERSIST = MOMENTS>
+// SAVE (pass 2 only): also write every level's raw conv output d_k -- what the training backward needs -- so the
+// training forward is the same two fused passes instead of D depthwise kernels + a merge kernel (7.75 -> 4.94 C*L of
+// traffic per block).
+template <bool MOMENTS, int CH, bool PERSIST = MOMENTS, bool SAVE = false>
 // (CH = 16: >= 6 wavefronts per SIMD -- the persistent pass 1 sits right at the 80-VGPR boundary)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 6 : 1))) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   __shared__ float4 pyr_strip[MOMENTS ? 1 : 4 * 60 * (CH / 4 + 1)];   // pass 2: store transposition
@@ -225,6 +249,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 
       o[i] = v;
     }
     srf_conv_s1<CH>(o, x0, lc[0].w, lc[0].b);
+    if (SAVE) srf_pyr_store_chunks<CH>(pyr_strip + (threadIdx.x >> 6) * (60 * (CH / 4 + 1)), x0, own,
+                                       a.lv_out[0] + (size_t)row * L, tile * a.own, min(a.own, nchunks - tile * a.own),
+                                       lane);
     const float vmask = valid ? 1.f : 0.f;
     if (MOMENTS) {
 #pragma unroll
@@ -260,6 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 
   }
   if (D > 1) {
     srf_conv_s2<CH>(x0, x1, lc[1].w, lc[1].b);
+    if (SAVE && own) srf_pyr_store_level<CH / 2>(a.lv_out[1] + (size_t)row * (L >> 1) + (size_t)ci * (CH / 2), x1);
     srf_affine_mask<CH / 2>(x1, lc[1].a, lc[1].c, valid);
     if (MOMENTS && own) {
       srf_acc_moments<CH / 2>(x1, s1[1], s2[1]);
@@ -268,6 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 
   }
   if (D > 2) {
     srf_conv_s2<CH / 2>(x1, x2, lc[2].w, lc[2].b);
+    if (SAVE && own) srf_pyr_store_level<CH / 4>(a.lv_out[2] + (size_t)row * (L >> 2) + (size_t)ci * (CH / 4), x2);
     srf_affine_mask<CH / 4>(x2, lc[2].a, lc[2].c, valid);
     if (MOMENTS && own) {
       srf_acc_moments<CH / 4>(x2, s1[2], s2[2]);
@@ -276,6 +305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 
   }
   if (D > 3) {
     srf_conv_s2<CH / 4>(x2, x3, lc[3].w, lc[3].b);
+    if (SAVE && own) srf_pyr_store_level<CH / 8>(a.lv_out[3] + (size_t)row * (L >> 3) + (size_t)ci * (CH / 8), x3);
     srf_affine_mask<CH / 8>(x3, lc[3].a, lc[3].c, valid);
     if (MOMENTS && own) {
       srf_acc_moments<CH / 8>(x3, s1[3], s2[3]);
@@ -284,6 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 
   }
   if (D > 4) {
     srf_conv_s2<CH / 8>(x3, x4, lc[4].w, lc[4].b);
+    if (SAVE && own) srf_pyr_store_level<CH / 16>(a.lv_out[4] + (size_t)row * (L >> 4) + (size_t)ci * (CH / 16), x4);
     srf_affine_mask<CH / 16>(x4, lc[4].a, lc[4].c, valid);
     if (MOMENTS && own) {
       srf_acc_moments<CH / 16>(x4, s1[4], s2[4]);
@@ -293,6 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 
   if constexpr (CH >= 32) {
     if (D > 5) {
       srf_conv_s2<CH / 16>(x4, x5, lc[5].w, lc[5].b);
+      if (SAVE && own) srf_pyr_store_level<CH / 32>(a.lv_out[5] + (size_t)row * (L >> 5) + (size_t)ci * (CH / 32), x5);
       srf_affine_mask<CH / 32>(x5, lc[5].a, lc[5].c, valid);
       if (MOMENTS && own) {
         srf_acc_moments<CH / 32>(x5, s1[5], s2[5]);
@@ -357,32 +389,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 
       mq = fmaf(v, v, mq);
     }
     // Store through a wave-private LDS strip so that every store instruction writes 1 KB of consecutive
-    // addresses (a lane's own 64/128 B at a 64/128-B lane stride measured 17-22 us slower per launch):
-    // own chunk j sits at float4 offset j*(NF+1) (odd pitch in 16-B units: conflict-free both ways).
-    constexpr int NF = CH / 4, PF = NF + 1;
-    float4* strip = pyr_strip + wave * (60 * PF);
-    const int j = lane - 2;
-    if (own) {
-#pragma unroll
-      for (int i = 0; i < NF; ++i)
-        strip[j * PF + i] = make_float4(outv[4 * i], outv[4 * i + 1], outv[4 * i + 2], outv[4 * i + 3]);
-    } else {
+    // addresses (a lane's own 64/128 B at a 64/128-B lane stride measured 17-22 us slower per launch).
+    if (!own) {
       ms = 0.f;
       mq = 0.f;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      const int first = tile * a.own;
-      const int cnt = min(a.own, nchunks - first);   // own chunks of this tile inside the row
-      float4* dst = reinterpret_cast<float4*>(a.merged + (size_t)row * L + first * CH);
-#pragma unroll
-      for (int it = 0; it < (60 * NF + 63) / 64; ++it) {
-        const int f = it * 64 + lane;
-        if (f < cnt * NF) dst[f] = strip[(f / NF) * PF + (f % NF)];
-      }
-    }
+    srf_pyr_store_chunks<CH>(pyr_strip + wave * (60 * (CH / 4 + 1)), outv, own, a.merged + (size_t)row * L, tile * a.own,
+                             min(a.own, nchunks - tile * a.own), lane);
     if (a.out_sums) {
       const double ds = srf_wave_sum((double)ms), dq = srf_wave_sum((double)mq);
       if (lane == 0) {
@@ -441,11 +454,17 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
     a.rpw = 1;
     grid = dim3((unsigned)a.C, (unsigned)((a.tiles + 3) / 4), (unsigned)(rows / a.C));
   }
+  const bool save = !moments && a.lv_out[0] != nullptr;
+  if (save)
+    for (int k = 0; k < a.D; ++k)
+      SRF_CHECK_ARG(a.lv_out[k] && srf_aligned16(a.lv_out[k]), "srf_pyramid: level output %d missing / unaligned", k);
   if (CH == 16) {
     if (moments && persist)
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, true>), grid, dim3(256), 0, st, a);
     else if (moments)
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, false>), grid, dim3(256), 0, st, a);
+    else if (save)
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 16, false, true>), grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 16, false>), grid, dim3(256), 0, st, a);
   } else {
@@ -453,9 +472,11 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32, true>), grid, dim3(256), 0, st, a);
     else if (moments)
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 32, false>), grid, dim3(256), 0, st, a);
+    else if (save)
+      hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 32, false, true>), grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<false, 32, false>), grid, dim3(256), 0, st, a);
   }
-  SRF_CHECK_LAUNCH(moments ? "pyramid_moments" : "pyramid_merge", st);
+  SRF_CHECK_LAUNCH(moments ? "pyramid_moments" : (save ? "pyramid_merge_save" : "pyramid_merge"), st);
   return SRF_OK;
 }

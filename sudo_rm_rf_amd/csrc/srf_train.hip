@@ -22,6 +22,11 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
                      int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch,
                      int mode, void* stream);
 bool srf_dwconv5_bwd_rowwise_ok(int Lin, int stride, const void* const* ptrs, int nptrs);
+bool srf_pyramid_reg_supported(int L, int D);
+int srf_pyramid_impl(const float* y1, float* merged, const srf_norm* in_norm, const float* const* w,
+                     const float* const* bias, const float* const* gamma, const float* const* beta, int groups, int C,
+                     int L, int D, void* scratch, double* out_sums, float* const* lv_out, double* const* lv_sums,
+                     void* stream);
 int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups, int C,
                          int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch, const float* gadd,
                          void* gln_scratch, int* fused, const float* ax, const srf_norm* anorm, const void* a_scratch,
@@ -205,6 +210,12 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
   }
   const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;
   const int G = gc ? c.group_size : 1, Bg = p->Bg, nB = p->nB, nC = p->nC;
+  // fused pyramid with level outputs (register-resident kernels only); its scratch lives in the backward's gradient
+  // buffers gf | go | gd, idle during the forward.  Debug flag 16 (as in srf_forward) selects the per-level kernels.
+  const size_t F_ = sizeof(float);
+  const bool fused_pyr = !(srf_debug_flags() & (16 | 64 | 128)) && srf_kernel_mode() != 1 &&
+                         srf_pyramid_supported(nC, (int)L, D) && srf_pyramid_reg_supported((int)L, D) &&
+                         srf_pyramid_scratch_bytes(Bg, nC, (int)L, D) <= (s.gd + F_ * Bt * c.in_channels * L) - s.gf;
   for (int i = 0; i < U; ++i) {
     const float* const* Pb = P + p->p_block0 + (size_t)i * p->p_block_stride;
     const float* const* Pu = Pb + p->p_ublock_off;
@@ -227,6 +238,30 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
     }
     rc = srf_pw_conv(xin, Pu[0], Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0), 0, nullptr, 0, stream);
     if (rc) return rc;
+    // The pyramid: the two fused passes of the inference path with the per-level conv outputs d_k and their
+    // statistics written on the side (what the backward reads) when the register-resident kernels cover the shape;
+    // otherwise D depthwise kernels + the merge kernel.
+    if (fused_pyr) {
+      const float* wv[SRF_MAX_DEPTH];
+      const float* bv[SRF_MAX_DEPTH];
+      const float* gv_[SRF_MAX_DEPTH];
+      const float* bev[SRF_MAX_DEPTH];
+      float* lv_out[SRF_MAX_DEPTH];
+      double* lv_sums[SRF_MAX_DEPTH];
+      for (int k = 0; k < D; ++k) {
+        const float* const* Pk = Pu + 5 + 4 * k;
+        wv[k] = Pk[0];
+        bv[k] = Pk[1];
+        gv_[k] = Pk[2];
+        bev[k] = Pk[3];
+        lv_out[k] = (float*)(blk + t.lv[k]);
+        lv_sums[k] = slot(s0 + 1 + k);
+      }
+      const srf_norm in{slot(s0), Pu[2], Pu[3], Pu[4]};
+      rc = srf_pyramid_impl(y1, merged, &in, wv, bv, gv_, bev, Bg, nC, L, D, sc + s.gf, slot(s0 + 1 + D), lv_out,
+                            lv_sums, stream);
+      if (rc) return rc;
+    } else {
     const float* levels[SRF_MAX_DEPTH];
     srf_norm norms[SRF_MAX_DEPTH];
     for (int k = 0; k < D; ++k) {
@@ -254,6 +289,7 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
     }
     rc = srf_merge(levels, norms, D, merged, Bg, nC, L, slot(s0 + 1 + D), stream);
     if (rc) return rc;
+    }
     const float* const* Pf = Pu + 5 + 4 * D;
     srf_norm fn{slot(s0 + 1 + D), Pf[0], Pf[1], Pf[2]};
     rc = srf_pw_conv(merged, Pf[3], Pf[4], xbuf(i + 1), Bg, nC, nB, L, &fn, xin, nullptr, 0, nullptr, 0, stream);

@@ -177,6 +177,7 @@ def check_grads_against_golden(named_grads, z, tol):
         rel = max(rel, abs(np.sqrt((g ** 2).sum()) - np.sqrt(gsq)) / max(np.sqrt(gsq), 1e-12))
         if rel > worst[1]:
             worst = (k, float(rel))
+    print("worst relative gradient error vs the reference: %s %.3e (tolerance %.1e)" % (worst[0], worst[1], tol))
     assert worst[1] <= tol, worst
 
 
