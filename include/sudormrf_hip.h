@@ -93,7 +93,16 @@ const char* srf_last_error(void);
  *   2 = fast paths, but 1x1 convs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32). */
 void srf_set_kernel_mode(int mode);
 int srf_get_kernel_mode(void);
-void srf_set_debug_flags(int flags); /* bit0: main GEMM kernel without instruction-interleave hints */
+/* Diagnostics / A-B switches between kernel variants that compute the same result (default 0 = the shipped paths):
+ *   8        pre-packed weights for the split-bf16 GEMM            16        per-level depthwise + merge kernels instead
+ *   32 / 64  LDS pyramid kernels instead of the register ones                of the fused pyramid (inference and training)
+ *   128      non-persistent pyramid pass 1                         256       no half-tile tail in the persistent GEMM
+ *   1024     TAC forward with one time step per lane               2048      one-tile-per-block GEMM everywhere
+ *   bits 12-13, 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating)
+ *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
+ *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)
+ *   1<<29 / 1<<30  chunked depthwise-backward / scalar GlobLN-backward kernels and no backward fusion */
+void srf_set_debug_flags(int flags);
 
 /* In-library profiler (bench.py): between begin/end every kernel launched through this library is
  * followed by a HIP event on the caller's stream; end() synchronises the stream and get(i) returns
