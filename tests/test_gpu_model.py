@@ -109,10 +109,14 @@ def test_batch32_examples_are_independent_at_full_size(manifest):
     model = build(cfg, sd)
     reps = np.concatenate([wav] * 16, axis=0)            # 32 examples: golden inputs interleaved
     assert reps.shape[0] == 32
-    with torch.no_grad():
-        out = model(torch.from_numpy(reps).to(DEV)).cpu().numpy()
-    for i in range(32):
-        assert np.abs(out[i] - gold["out"][i % 2]).max() <= TOL, i
+    x = torch.from_numpy(reps).to(DEV)
+    eng = model._engine()
+    for multi in (False, True):          # the single-stream forward AND whatever batch split the auto-tuner picks
+        eng.multi_stream = multi
+        with torch.no_grad():
+            out = model(x).cpu().numpy()
+        for i in range(32):
+            assert np.abs(out[i] - gold["out"][i % 2]).max() <= TOL, (multi, i)
 
 
 def test_run_to_run_determinism(manifest):

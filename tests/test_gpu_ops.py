@@ -165,6 +165,39 @@ def test_pw_conv_buffer_and_pointer_loads_agree(Bt, Cin, Cout, L, pro):
         check(a, want, 5e-5, "pw_conv buffer loads")
 
 
+@pytest.mark.parametrize("Bt,Cin,Cout,L", [(32, 512, 256, 1600), (16, 256, 512, 3200)])   # 1664 / 1600 tiles: persistent
+@pytest.mark.parametrize("pro", [0, 1, 2, 3])
+def test_pw_conv_persistent_variants(Bt, Cin, Cout, L, pro):
+    """Every prologue instantiation of the persistent split-bf16 GEMM at model-sized K, in the form that is dispatched
+    (buffer loads), the pointer form (flag 1<<27) and the one-tile-per-block kernel (flag 2048): all against an fp64
+    reference and against each other.  (The whole-model tests auto-tune a batch split, so they do not necessarily run
+    the persistent kernel for every conv.)"""
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+    x = dev32(rnd(Bt, Cin, L, seed=40, scale=1.3, shift=0.2))
+    w, bias = dev32(rnd(Cout, Cin, 1, seed=41, scale=Cin ** -0.5)), dev32(rnd(Cout, seed=42, scale=0.2))
+    res = dev32(rnd(Bt, Cout, L, seed=43))
+    kw, xin = {}, x.double().cpu()
+    if pro in (1, 2):
+        gamma, beta = rnd(Cin, seed=44, scale=0.3, shift=1.0), rnd(Cin, seed=45, scale=0.3)
+        kw.update(in_sums=sums64(xin).to(DEV), in_gamma=dev32(gamma), in_beta=dev32(beta))
+        xin = gln64(xin, gamma, beta)
+    if pro in (2, 3):
+        kw.update(in_prelu=dev32(torch.tensor([0.17], dtype=torch.float64)))
+        xin = torch.where(xin >= 0, xin, 0.17 * xin)
+    want = F.conv1d(xin, w.double().cpu(), bias.double().cpu()) + res.double().cpu()
+    outs = {}
+    try:
+        for name, flags in (("dispatched", 0), ("pointer loads", 1 << 27), ("one tile per block", 2048)):
+            ops.set_debug_flags(flags)
+            outs[name] = ops.pw_conv(x, w, bias, residual=res, **kw)
+    finally:
+        ops.set_debug_flags(0)
+    for name, got in outs.items():
+        check(got, want, 1e-4, "persistent pw_conv pro=%d (%s)" % (pro, name))
+    assert torch.equal(outs["dispatched"], outs["pointer loads"])
+
+
 def test_pw_conv_mask_epilogue(mode):
     from sudo_rm_rf_amd import ops
     Bt, Cin, N, S, L = 2, 64, 48, 2, 260
