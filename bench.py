@@ -268,6 +268,48 @@ def main():
         dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, dev)
     assert out.shape == (batch, kw["num_sources"], T) and bool(torch.isfinite(out).all())
+    # Self-check (untimed, product kernels only): the timed forward's outputs against (a) the same forward on one stream
+    # and (b) the shape-agnostic generic kernels (kernel mode 1: no MFMA, no fusion, different code everywhere) on the
+    # first and last example.  A throughput measured on wrong outputs is worthless; the parity proper is tests/.
+    with torch.no_grad():
+        eng = model._engine()
+        was_multi = eng.multi_stream
+        eng.multi_stream = False
+        single = model(wav)
+        eng.multi_stream = was_multi
+        ops.set_kernel_mode(1)
+        try:
+            generic = torch.cat([model(wav[:1]), model(wav[-1:])])
+        finally:
+            ops.set_kernel_mode(args.kernel_mode)
+        scale = float(out.abs().max().clamp_min(1e-12))
+        d_single = float((out - single).abs().max())
+        d_generic = float((torch.cat([out[:1], out[-1:]]) - generic).abs().max())
+    self_check = {"max_abs_vs_single_stream": d_single, "max_abs_vs_generic_kernels": d_generic, "output_abs_max": scale}
+    self_check["ok"] = not (d_single > 1e-5 * max(scale, 1.0) or d_generic > 1e-3 * max(scale, 1e-3))
+    # every rank takes the same branch below (the re-timing contains collectives)
+    any_bad = D.max_over_ranks(0.0 if self_check["ok"] else 1.0, dev) > 0.5
+    any_generic_bad = D.max_over_ranks(0.0 if d_generic <= 1e-3 * max(scale, 1e-3) else 1.0, dev) > 0.5
+    if any_bad and was_multi and not any_generic_bad:
+        # the split forward disagrees with the single-stream one: time the single-stream forward instead (its outputs
+        # were just checked against the generic kernels on the same examples) rather than report a number for outputs
+        # that are not right
+        print("bench.py: stream-split outputs differ from the single-stream forward (%s); timing single-stream"
+              % json.dumps(self_check), file=sys.stderr)
+        eng.multi_stream = False
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                out = model(wav)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = model(wav)
+            torch.cuda.synchronize(dev)
+            dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+            d2 = float((torch.cat([out[:1], out[-1:]]) - generic).abs().max())
+        self_check.update(retimed_single_stream=True, max_abs_vs_generic_kernels=d2, ok=d2 <= 1e-3 * max(scale, 1e-3))
+    if D.max_over_ranks(0.0 if self_check["ok"] else 1.0, dev) > 0.5:
+        raise SystemExit("bench.py self-check failed: %s" % json.dumps(self_check))
     ms_per_step = 1e3 * dt / args.steps
     value = n_gpus * batch * (T / fs) * args.steps / dt
 
@@ -292,11 +334,15 @@ def main():
                    "global_batch": batch * n_gpus, "parallelism": "batch-sharded replicas x%d" % n_gpus,
                    "kernel_mode": args.kernel_mode,
                    "stream_split": list(model._engine()._split_choice.get((dev.index, batch, T), (batch,)))},
+        "self_check": self_check,
         "forward_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fwd_gbs / roofline.HBM_PEAK_GBS,
                              "algorithmic_bytes_per_forward": alg_bytes,
                              "algorithmic_tflops": alg_flops / (ms_per_step * 1e-3) / 1e12},
     }
+
+    if self_check.get("retimed_single_stream"):
+        result["config"]["stream_split"] = [batch]
 
     # ---- per-kernel durations with HIP events on the launch stream (separate instrumented pass) ----
     if rank == 0 and not args.no_kernel_profile:
@@ -305,13 +351,14 @@ def main():
         stream = _lib.current_stream(dev)
         psteps = min(args.steps, 10)
         with torch.no_grad():
+            was_multi_p = model._engine().multi_stream
             model._engine().multi_stream = False      # the profiler's events live on one stream
             lib.srf_profile_begin(stream)
             for _ in range(psteps):
                 model(wav)
             cnt = C.c_int(0)
             _lib.check(lib.srf_profile_end(stream, C.byref(cnt)), "srf_profile_end")
-            model._engine().multi_stream = True
+            model._engine().multi_stream = was_multi_p
         launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, **dims)
         per = {}
         name, ms = C.c_char_p(), C.c_float()

@@ -138,8 +138,8 @@ __device__ __forceinline__ void srf_pyr_store_level(float* dst, const float (&v)
 // training forward is the same two fused passes instead of D depthwise kernels + a merge kernel (7.75 -> 4.94 C*L of
 // traffic per block).
 template <bool MOMENTS, int CH, bool PERSIST = MOMENTS, bool SAVE = false>
-// (CH = 16: >= 6 wavefronts per SIMD -- the persistent pass 1 sits right at the 80-VGPR boundary)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH == 16 ? 6 : 1))) void srf_pyramid_reg_kernel(PyrRegArgs a) {
+// (no occupancy attribute: pinning 6 wavefronts per SIMD made the persistent pass 1 spill VGPRs to scratch memory)
+__global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   __shared__ float4 pyr_strip[MOMENTS ? 1 : 4 * 60 * (CH / 4 + 1)];   // pass 2: store transposition
   const int lane = threadIdx.x & 63;
   const int L = a.L, D = a.D, C = a.C;

@@ -156,7 +156,12 @@ class ModelEngine:
         self._lock = threading.Lock()
         self._warned_grad = False
         self.last_plan = None
-        self.multi_stream = True          # bench.py switches it off for its per-kernel profiling pass
+        # Batch split over two streams (see _forward_split).  On by default for the Improved model only: for GroupComm
+        # models back-to-back split forwards produced wrong outputs for a few examples of a sub-batch (intermittent,
+        # 5e-4; single-stream forwards are always right, tools/check_modes.py) and the cause is not understood yet,
+        # so they stay on one stream unless SRF_STREAM_SPLIT_GROUPCOMM=1.  (bench.py switches the split off for its
+        # per-kernel profiling pass.)
+        self.multi_stream = cfg_tuple[0] != "groupcomm" or os.environ.get("SRF_STREAM_SPLIT_GROUPCOMM") == "1"
         self._side_streams = {}
         self._split_choice = {}
         self._run_locks = {}
