@@ -114,7 +114,9 @@ def test_batch32_examples_are_independent_at_full_size(manifest, case):
     assert reps.shape[0] == 32
     x = torch.from_numpy(reps).to(DEV)
     eng = model._engine()
-    for multi in (False, True):          # the single-stream forward AND whatever batch split the auto-tuner picks
+    # the single-stream forward AND, where the engine uses it (Improved models), whatever batch split the auto-tuner
+    # picks; GroupComm models stay on one stream by default (engine.ModelEngine.multi_stream)
+    for multi in ((False, True) if eng.multi_stream else (False,)):
         eng.multi_stream = multi
         with torch.no_grad():
             out = model(x).cpu().numpy()
