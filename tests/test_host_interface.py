@@ -249,3 +249,43 @@ def test_checkpoint_whole_module_pickle_and_dataparallel(tmp_path):
             assert torch.equal(v, v2)
     with pytest.raises(TypeError):
         checkpoint.load_checkpoint(m.state_dict())      # bare state_dict without a model to load into
+
+
+def test_weights_of_a_data_parallel_style_replica_follow_state_dict_order():
+    """torch.nn.DataParallel replicas report an empty state_dict and no parameters; the engine collects their weights
+    from `_former_parameters` of every sub-module in state_dict (pre-)order.  Emulated on the CPU exactly the way
+    torch/nn/parallel/replicate.py builds a replica (the GPU test runs real replicas)."""
+    from collections import OrderedDict
+    import torch
+    import sudo_rm_rf.dnn.models.groupcomm_sudormrf_v2 as gc
+    import sudo_rm_rf.dnn.models.improved_sudormrf as imp
+    from sudo_rm_rf_amd.engine import _weights
+    for model in (imp.SuDORMRF(out_channels=16, in_channels=32, num_blocks=2, upsampling_depth=3, enc_kernel_size=21,
+                               enc_num_basis=24, num_sources=2),
+                  gc.GroupCommSudoRmRf(in_audio_channels=1, out_channels=32, in_channels=64, num_blocks=2,
+                                       upsampling_depth=3, enc_kernel_size=21, enc_num_basis=24, num_sources=2,
+                                       group_size=4)):
+        modules = list(model.modules())
+        index = {m: i for i, m in enumerate(modules)}
+        replicas = []
+        for m in modules:
+            r = m._replicate_for_data_parallel()
+            r._former_parameters = OrderedDict()
+            replicas.append(r)
+        for i, m in enumerate(modules):
+            for key, child in m._modules.items():
+                setattr(replicas[i], key, None if child is None else replicas[index[child]])
+            for key, p in m._parameters.items():
+                if p is None:
+                    replicas[i]._parameters[key] = None
+                else:
+                    copy = p.detach().clone().requires_grad_()       # stands in for the Broadcast output
+                    setattr(replicas[i], key, copy)
+                    replicas[i]._former_parameters[key] = copy
+        rep = replicas[0]
+        assert len(rep.state_dict()) == 0 and not list(rep.parameters())
+        got, want = _weights(rep), list(model.state_dict(keep_vars=True).values())
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and torch.equal(a.detach(), b.detach())
+        assert [id(t) for t in _weights(model)] == [id(t) for t in want]
