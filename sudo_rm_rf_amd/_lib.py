@@ -10,7 +10,8 @@ import threading
 import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension binds to the same runtime)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libsudormrf_hip.so")
+# SRF_LIB: an alternative build of the same library (same-box A/B of kernel variants, tools/); default = the in-tree build
+LIB_PATH = os.environ.get("SRF_LIB") or os.path.join(_PKG, "libsudormrf_hip.so")
 ABI_VERSION = 9
 STAT_BUCKETS = 64
 

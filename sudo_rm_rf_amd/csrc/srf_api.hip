@@ -6,6 +6,8 @@
 // in one workspace buffer.  All launches go to the caller's stream; nothing synchronises.
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -15,7 +17,7 @@
 // error string / kernel mode
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
-static int g_kernel_mode = 0;
+static std::atomic<int> g_kernel_mode{0};   // process-wide diagnostics switch (tests, bench A/B); per-thread override below
 
 void srf_set_error(const char* fmt, ...) {
   va_list ap;
@@ -25,15 +27,46 @@ void srf_set_error(const char* fmt, ...) {
 }
 // per-thread override (srf_forward_train runs its GEMMs in exact fp32 by default, see srf_train.hip)
 static thread_local int g_kernel_mode_override = -1;
-int srf_kernel_mode() { return g_kernel_mode_override >= 0 ? g_kernel_mode_override : g_kernel_mode; }
+int srf_kernel_mode() { return g_kernel_mode_override >= 0 ? g_kernel_mode_override : g_kernel_mode.load(std::memory_order_relaxed); }
 int srf_kernel_mode_override(int mode) {
   const int prev = g_kernel_mode_override;
   g_kernel_mode_override = mode;
   return prev;
 }
-static int g_debug_flags = 0;
-int srf_debug_flags() { return g_debug_flags; }
-extern "C" void srf_set_debug_flags(int f) { g_debug_flags = f; }
+static std::atomic<int> g_debug_flags{0};   // process-wide diagnostics switch: kernel-variant A/B only, never set by the product path
+int srf_debug_flags() { return g_debug_flags.load(std::memory_order_relaxed); }
+extern "C" void srf_set_debug_flags(int f) { g_debug_flags.store(f, std::memory_order_relaxed); }
+
+// ---- per-device caches (see srf_common.h) ----------------------------------------------------------
+static std::mutex g_dev_mu;
+static int g_dev_cus[SRF_MAX_DEVICES];
+static long g_dev_occ[SRF_MAX_DEVICES][SRF_OCC_SLOTS];
+static bool g_dev_occ_set[SRF_MAX_DEVICES][SRF_OCC_SLOTS];
+
+int srf_current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+int srf_device_cus() {
+  const int dev = srf_current_device();
+  if (dev < 0 || dev >= SRF_MAX_DEVICES) return 256;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (!g_dev_cus[dev]) {
+    hipDeviceProp_t prop;
+    g_dev_cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return g_dev_cus[dev];
+}
+long srf_device_cached(int slot, long (*compute)(void*), void* arg) {
+  const int dev = srf_current_device();
+  if (dev < 0 || dev >= SRF_MAX_DEVICES || slot < 0 || slot >= SRF_OCC_SLOTS) return compute(arg);
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (!g_dev_occ_set[dev][slot]) {
+    g_dev_occ[dev][slot] = compute(arg);
+    g_dev_occ_set[dev][slot] = true;
+  }
+  return g_dev_occ[dev][slot];
+}
 
 // ---- in-library HIP-event profiler: one event after every kernel launch on the caller's stream ------
 struct ProfMark {
@@ -89,8 +122,8 @@ extern "C" int srf_profile_get(int i, const char** name, float* ms) {
 
 extern "C" const char* srf_last_error(void) { return g_err; }
 extern "C" int srf_abi_version(void) { return SRF_ABI_VERSION; }
-extern "C" void srf_set_kernel_mode(int mode) { g_kernel_mode = (mode == 1 || mode == 2) ? mode : 0; }
-extern "C" int srf_get_kernel_mode(void) { return g_kernel_mode; }
+extern "C" void srf_set_kernel_mode(int mode) { g_kernel_mode.store((mode == 1 || mode == 2) ? mode : 0, std::memory_order_relaxed); }
+extern "C" int srf_get_kernel_mode(void) { return g_kernel_mode.load(std::memory_order_relaxed); }
 
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
 int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T,

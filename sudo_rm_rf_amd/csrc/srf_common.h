@@ -17,6 +17,16 @@ int srf_kernel_mode_override(int mode);   // per-thread override (-1 = none); re
 int srf_debug_flags();  // bit0: x3p kernel without sched_group_barrier hints
 bool srf_profiling();
 void srf_prof_mark(const char* name, hipStream_t st);
+// Per-device launch geometry caches (srf_api.hip).  The library is called from one thread per GPU (DataParallel replicas,
+// SURVEY.md §8b), so nothing device-dependent may live in a plain function-static: these are indexed by the CALLING
+// thread's current device and guarded by a mutex.
+#define SRF_MAX_DEVICES 64
+int srf_current_device();                       // hipGetDevice, -1 on error
+int srf_device_cus();                           // multiProcessorCount of the current device (256 if the query fails)
+// Slot `slot` (0 .. SRF_OCC_SLOTS-1) of the current device's occupancy cache: returns the cached value or, when empty,
+// evaluates `compute` once (under the lock) and stores it.
+#define SRF_OCC_SLOTS 16
+long srf_device_cached(int slot, long (*compute)(void*), void* arg);
 
 #define SRF_CHECK_ARG(cond, ...)          \
   do {                                    \

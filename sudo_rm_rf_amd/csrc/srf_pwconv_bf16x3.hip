@@ -610,14 +610,7 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
     // Persistent blocks (2 per CU) whenever every block gets >= 3 tiles; fewer tiles and the idle slots
     // of the last round cost more than the pipelining across tiles gains (decoder frame GEMM: 800 tiles).
     // Debug flag 2048 forces the one-tile-per-block kernel.
-    static int cached_cus = 0;
-    if (!cached_cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      cached_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                       ? prop.multiProcessorCount : 256;
-    }
-    long nb = 2L * cached_cus;
+    long nb = 2L * srf_device_cus();
     nb -= nb % 8;
     if (!abl && !(srf_debug_flags() & 2048) && nb >= 8 && total >= 3 * nb) {
       dim3 gridp((unsigned)nb);
@@ -629,15 +622,14 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
       // leftover tiles of the last round as half tiles when they fill at most half of it (debug flag 256: off)
       const long rem = total % nb;
       const int nhalf = (rem > 0 && 2 * rem <= nb && !(srf_debug_flags() & 256)) ? (int)(2 * rem) : 0;
-      // PRO 1 (GlobLN without PReLU: the bottleneck conv, one launch per forward) stays on the pointer form and its
-      // buffer-load instantiation is not built: it produced wrong results at the model's shapes in every run (with a
-      // per-tile and with a loop-invariant descriptor alike -- most likely a code-generation problem of that one
-      // instantiation), while the other three are bit-identical to their pointer forms over repeated runs
-      // (tools/pw_stress.py).  tests/test_gpu_ops.py::test_pw_conv_persistent_variants pins every instantiation that
-      // IS dispatched against an fp64 reference and against its pointer form.
-      if (srf_pw_buffer_ok(a) && pro != 1) {
+      // (Round 1 shipped without the <1, true> instantiation: it "computed wrong tiles in every run".  Cause, found in
+      // round 2: the SLP vectorizer had packed that prologue's scale computation into v_pk_mul_f32 ... op_sel:[0,1], a form
+      // that returns wrong low results in lanes 48..63 next to other wavefronts' MFMAs on gfx950 -- see build.py's ISA
+      // lint.  This file is compiled with -fno-slp-vectorize now and all four prologues use buffer loads.)
+      if (srf_pw_buffer_ok(a)) {
         switch (pro) {
           case 0: hipLaunchKernelGGL((srf_pw_bf16x3_p8_kernel<0, true>), gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
+          case 1: hipLaunchKernelGGL((srf_pw_bf16x3_p8_kernel<1, true>), gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
           case 2: hipLaunchKernelGGL((srf_pw_bf16x3_p8_kernel<2, true>), gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
           default: hipLaunchKernelGGL((srf_pw_bf16x3_p8_kernel<3, true>), gridp, block8, 0, st, ap, nMt, nLt, (int)total, nhalf); break;
         }

@@ -811,7 +811,6 @@ static bool pyr_pick_tile(int L, int D, PyrTile* t) {
 // register-resident kernels (srf_pyramid_reg.hip)
 #include "srf_pyr.h"
 
-static bool g_pyr_attr_set = false;
 
 // lv_out / lv_sums (both or neither; register-resident kernels only -- srf_pyramid_reg_supported): the training
 // forward's extra outputs, see PyrRegArgs::lv_out and PyrFinArgs::lv_sums.
@@ -936,36 +935,25 @@ int srf_pyramid_impl(const float* y1, float* merged, const srf_norm* in_norm, co
     return SRF_OK;
   }
   const size_t ldsb = pyr_lds_bytes(L, D);
-  if (ldsb > 64 * 1024 && !g_pyr_attr_set) {
+  // (Fallback path -- shapes neither the register-resident nor the wave-per-tile kernels take.  No cached state: the
+  // dynamic-LDS attribute is per device and the occupancy depends on L, so both are simply evaluated per call; a
+  // function-static cache here was wrong for one thread per GPU)
+  if (ldsb > 64 * 1024) {
     SRF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&srf_pyramid_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SRF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&srf_pyramid_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    g_pyr_attr_set = true;
   }
   // persistent grids: exactly as many blocks as are co-resident (registers + LDS), rows strided
   auto resident_blocks = [&](const void* fn) -> long {
-    int per_cu = 0, dev = 0;
-    static int cus = 0;
+    int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, ldsb) != hipSuccess || per_cu < 1)
       per_cu = 1;
-    if (!cus) {
-      hipDeviceProp_t prop;
-      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                ? prop.multiProcessorCount
-                : 256;
-    }
-    const long n = (long)per_cu * cus;
+    const long n = (long)per_cu * srf_device_cus();
     return n < rows ? n : rows;
   };
-  static long cached_n1 = 0, cached_n2 = 0;
-  static size_t cached_lds = 0;
-  if (cached_lds != ldsb) {
-    cached_n1 = resident_blocks(reinterpret_cast<const void*>(&srf_pyramid_kernel<true>));
-    cached_n2 = resident_blocks(reinterpret_cast<const void*>(&srf_pyramid_kernel<false>));
-    cached_lds = ldsb;
-  }
-  const long nblk1 = cached_n1 < rows ? cached_n1 : rows, nblk2 = cached_n2 < rows ? cached_n2 : rows;
+  const long nblk1 = resident_blocks(reinterpret_cast<const void*>(&srf_pyramid_kernel<true>));
+  const long nblk2 = resident_blocks(reinterpret_cast<const void*>(&srf_pyramid_kernel<false>));
   hipLaunchKernelGGL(srf_pyramid_kernel<true>, dim3((unsigned)nblk1), dim3(256), ldsb, st, a);
   SRF_CHECK_LAUNCH("pyramid_moments", st);
   srf_pyramid_finalize_launch(f, groups, C, st);

@@ -432,17 +432,18 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
   a.rows = (int)rows;
   // pass 1 persistent (grid = co-resident wavefronts, cached occupancy query) unless debug flag 128
   const bool persist = moments && !(srf_debug_flags() & 128);
-  static long cached_waves[2] = {0, 0};
-  long& cw = cached_waves[CH == 16 ? 0 : 1];
-  if (persist && !cw) {
-    int dev = 0, cus = 256, per_cu = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    const void* fn = CH == 16 ? (const void*)&srf_pyramid_reg_kernel<true, 16, true>
-                              : (const void*)&srf_pyramid_reg_kernel<true, 32, true>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-    cw = (long)cus * per_cu * 4;
+  // co-resident wavefronts of the persistent pass 1 on THIS device (per-device cache, srf_common.h)
+  long cw = 0;
+  if (persist) {
+    struct Q { int ch; } q{CH};
+    cw = srf_device_cached(CH == 16 ? 0 : 1, [](void* p) -> long {
+      const int ch = static_cast<Q*>(p)->ch;
+      int per_cu = 0;
+      const void* fn = ch == 16 ? (const void*)&srf_pyramid_reg_kernel<true, 16, true>
+                                : (const void*)&srf_pyramid_reg_kernel<true, 32, true>;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+      return (long)srf_device_cus() * per_cu * 4;
+    }, &q);
   }
   dim3 grid;
   if (persist) {

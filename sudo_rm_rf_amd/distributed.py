@@ -63,6 +63,17 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
+def gather_over_ranks(value, device=None):
+    """Every rank's scalar as a list (rank order) on every rank -- bench.py's per-rank step times."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(value)]
+    ws = dist.get_world_size()
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    parts = [torch.empty_like(t) for _ in range(ws)]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def separate_sharded(model, mixtures, gather=False):
     """Run `model` on this rank's shard of `mixtures` [global_batch, ch, T] (every rank passes the same
     global tensor or at least its own rows).  Returns the local estimates, or with gather=True the

@@ -94,3 +94,24 @@ def test_single_process_is_a_no_op():
     D.barrier(torch.device("cpu"))
     x = torch.randn(3, 1, 10)
     assert torch.equal(D.separate_sharded(lambda t: t * 2, x), x * 2)
+
+
+def test_bench_launcher_spawns_ranks_on_cpu():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run must become the launcher itself (one rank per GPU, the
+    driver's own command line): --launch-check runs that path up to the first kernel -- spawn, rendezvous (gloo: no GPU
+    here), rank binding, barrier, max-over-ranks and per-rank gather -- and prints one JSON line on rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["launch_check"] and d["n_gpus"] == 2 and d["requested_gpus"] == 2
+    assert d["max_over_ranks"] == 2.0 and d["per_rank"] == [0.0, 1.0]
