@@ -60,12 +60,17 @@ int srf_device_cus() {
 long srf_device_cached(int slot, long (*compute)(void*), void* arg) {
   const int dev = srf_current_device();
   if (dev < 0 || dev >= SRF_MAX_DEVICES || slot < 0 || slot >= SRF_OCC_SLOTS) return compute(arg);
-  std::lock_guard<std::mutex> lk(g_dev_mu);
-  if (!g_dev_occ_set[dev][slot]) {
-    g_dev_occ[dev][slot] = compute(arg);
-    g_dev_occ_set[dev][slot] = true;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (g_dev_occ_set[dev][slot]) return g_dev_occ[dev][slot];
   }
-  return g_dev_occ[dev][slot];
+  // evaluated OUTSIDE the lock (compute may call srf_device_cus(), which takes it); two threads racing here compute the
+  // same value for the same device
+  const long v = compute(arg);
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  g_dev_occ[dev][slot] = v;
+  g_dev_occ_set[dev][slot] = true;
+  return v;
 }
 
 // ---- in-library HIP-event profiler: one event after every kernel launch on the caller's stream ------

@@ -3,10 +3,10 @@
 set -u
 OUT=gpurun_out/${1:-check}; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -q -m gpu -p no:cacheprovider --tb=short -x ${K:+-k "$K"} > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+timeout ${TEST_TIMEOUT:-600} python -m pytest tests -q -m gpu -p no:cacheprovider --tb=short -x --timeout 120 ${K:+-k "$K"} > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -15 $OUT/pytest_gpu.log | cut -c1-300
 for w in ${WORKLOADS:-cfg2_improved_u16 cfg3_groupcomm_u8}; do
-  timeout 600 python bench.py --workload $w --steps 30 --warmup 5 ${BENCH_ARGS:-} > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "bench $w rc=$?"
+  timeout 240 python bench.py --workload $w --steps 30 --warmup 5 ${BENCH_ARGS:-} > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "bench $w rc=$?"
   python - $OUT/bench_$w.json <<'PY'
 import json, sys
 try:
