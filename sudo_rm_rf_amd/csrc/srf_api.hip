@@ -327,9 +327,9 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
   int rc;
 
   SRF_CHECK_HIP(hipMemsetAsync(stats, 0, p->stats_bytes, st));
-  // split + lay out every 1x1 weight for the split-precision GEMM, one launch (kernel mode 0 only)
-  // (the packed 256x128 kernel measured slower than the 128x128 8-wave kernel: opt-in via debug flag 8)
-  const bool use_pack = srf_kernel_mode() == 0 && (srf_debug_flags() & 8) && !p->pk_param.empty();
+  // split + lay out every 1x1 weight for the 256 x 128 split-precision GEMM (srf_pwconv_x3v.hip), one launch per forward
+  // (kernel mode 0 only; debug flag 8 = without: the 128 x 128 kernels that split W on the fly)
+  const bool use_pack = srf_kernel_mode() == 0 && !(srf_debug_flags() & 8) && !p->pk_param.empty();
   if (use_pack) {
     std::vector<const float*> pw(p->pk_param.size());
     std::vector<void*> pd(p->pk_param.size());

@@ -88,3 +88,62 @@ __device__ __forceinline__ void srf_pw_epilogue_strip(const PwArgs& a, const f32
     }
   }
 }
+
+// ---- 32 x 32 variant (one accumulator tile per call), shared by the persistent kernels ----
+constexpr int SRF_EPI_PITCH_H = 36;
+
+// one 32x32 accumulator tile -> rows x 128 B float4 stores (see srf_pw_epilogue_strip)
+__device__ __forceinline__ void srf_pw_epilogue_half(const PwArgs& a, const f32x16& acc, float* strip, long b,
+                                                     int m_base, int l_base, int lane, float& s, float& q) {
+  const int col = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+    strip[row * SRF_EPI_PITCH_H + col] = acc[r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int c4 = (lane & 7) * 4;
+  const int l = l_base + c4;
+  const bool l_ok = l < a.L;
+  const size_t lc = l_ok ? l : 0;
+  const int mulC = a.mul_channels;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 8 + (lane >> 3);
+    const int m = m_base + row;
+    const bool ok = l_ok && m < a.Cout;
+    const int mc = m < a.Cout ? m : 0;
+    float4 v = *reinterpret_cast<const float4*>(strip + row * SRF_EPI_PITCH_H + c4);
+    const float bs = a.bias[mc];
+    v.x += bs;
+    v.y += bs;
+    v.z += bs;
+    v.w += bs;
+    const size_t idx = ((size_t)b * a.Cout + mc) * a.L + lc;
+    if (a.residual) {
+      const float4 rv = *reinterpret_cast<const float4*>(a.residual + idx);
+      v.x += rv.x;
+      v.y += rv.y;
+      v.z += rv.z;
+      v.w += rv.w;
+    }
+    if (a.epi_mask & 1) {
+      const float4 e = *reinterpret_cast<const float4*>(a.mul + ((size_t)b * mulC + (mc % mulC)) * a.L + lc);
+      v.x = fmaxf(v.x, 0.f) * e.x;
+      v.y = fmaxf(v.y, 0.f) * e.y;
+      v.z = fmaxf(v.z, 0.f) * e.z;
+      v.w = fmaxf(v.w, 0.f) * e.w;
+    }
+    if (ok) {
+      *reinterpret_cast<float4*>(a.y + idx) = v;
+      s += (v.x + v.y) + (v.z + v.w);
+      q = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, q))));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+

@@ -204,17 +204,17 @@ __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int
 }
 
 int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st);
-int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
-size_t srf_x3p_packed_bytes(int Cout, int Cin);
-bool srf_x3p_supported(int Cin, int Cout, int L);
+int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
+size_t srf_x3v_packed_bytes(int Cout, int Cin);
+bool srf_x3v_supported(int Cin, int Cout, int L);
 int srf_pw_small_launch(const PwArgs& a, hipStream_t st);
 bool srf_pw_small_supported(int Cin, int Cout, int L);
-int srf_x3p_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n,
+int srf_x3v_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n,
                         hipStream_t st);
 
 extern "C" size_t srf_packed_pw_weight_bytes(int Cout, int Cin) {
-  if (Cout <= 0 || Cin <= 0 || !srf_x3p_supported(Cin, Cout, 4)) return 0;
-  return srf_x3p_packed_bytes(Cout, Cin);
+  if (Cout <= 0 || Cin <= 0 || !srf_x3v_supported(Cin, Cout, 4)) return 0;
+  return srf_x3v_packed_bytes(Cout, Cin);
 }
 
 extern "C" int srf_pack_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin,
@@ -224,7 +224,7 @@ extern "C" int srf_pack_pw_weights(const float* const* w, void* const* packed, c
     SRF_CHECK_ARG(w[i] && packed[i] && srf_packed_pw_weight_bytes(Cout[i], Cin[i]) > 0 &&
                       srf_aligned16(packed[i]),
                   "srf_pack_pw_weights: entry %d unsupported (Cout=%d Cin=%d)", i, Cout[i], Cin[i]);
-  return srf_x3p_pack_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
+  return srf_x3v_pack_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
 }
 
 extern "C" int srf_pw_conv(const float* x, const float* w, const float* bias, float* y, int Bt, int Cin,
@@ -269,8 +269,12 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
   if (mode != 1 && !(a.epi_mask & 1) && srf_pw_small_supported(Cin, Cout, L) && srf_aligned16(x) &&
       srf_aligned16(y) && (!residual || srf_aligned16(residual)))
     return srf_pw_small_launch(a, st);
-  if (mfma_ok && mode == 0 && w_packed && srf_x3p_supported(Cin, Cout, L) && srf_aligned16(w_packed))
-    return srf_pw_x3p_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
+  // 256 x 128 tiles with pre-split weights: whenever the packed image is there and the launch fills the chip (fewer tiles
+  // than CUs: the 128 x 128 kernels below make twice as many)
+  if (mfma_ok && mode == 0 && w_packed && srf_x3v_supported(Cin, Cout, L) && srf_aligned16(w_packed) &&
+      (long)Bt * Cin * L * 4 < (1L << 31) && !(srf_debug_flags() & 4) &&
+      (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus())
+    return srf_pw_x3v_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
   if (mfma_ok && mode == 0 && (Cin % 64 == 0)) return srf_pw_bf16x3_launch(a, pro_sel, st);
   if (mfma_ok) {
     const int nMt = (Cout + PW_BM - 1) / PW_BM, nLt = (L + PW_BN - 1) / PW_BN;

@@ -193,9 +193,15 @@ def test_pw_conv_persistent_variants(Bt, Cin, Cout, L, pro):
             outs[name] = ops.pw_conv(x, w, bias, residual=res, **kw)
     finally:
         ops.set_debug_flags(0)
+    # the 256 x 128 kernel with pre-split weights (what srf_forward dispatches: srf_pwconv_x3v.hip)
+    packed = ops.pack_pw_weight(w)
+    assert packed is not None
+    outs["packed 256x128"] = ops.pw_conv(x, w, bias, residual=res, packed=packed, **kw)
     for name, got in outs.items():
         check(got, want, 1e-4, "persistent pw_conv pro=%d (%s)" % (pro, name))
     assert torch.equal(outs["dispatched"], outs["pointer loads"])
+    # same arithmetic (same splits, same per-accumulator summation order over k): bitwise equal to the 128 x 128 kernels
+    assert torch.equal(outs["packed 256x128"], outs["dispatched"])
 
 
 def test_pw_conv_mask_epilogue(mode):

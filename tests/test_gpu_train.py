@@ -130,7 +130,8 @@ def test_online_remix_matches_the_runner_lines(B, S, T):
     assert (src.cpu().double() - want_src).abs().max() <= 2e-5
 
 
-@pytest.mark.parametrize("name", ["train_tiny_improved", "train_improved_mfma", "train_tiny_groupcomm"])
+@pytest.mark.parametrize("name", ["train_tiny_improved", "train_improved_mfma", "train_tiny_groupcomm",
+                                  "train_cfg2_shape", "train_cfg3_shape", "train_cfg4_shape"])
 def test_training_step_matches_reference_golden(name):
     """The runner's step (model.train(); loss = clamp(PIT-SI-SDR(model(mix)[, mixture consistency], clean));
     backward) through the reference's import paths against gradients the reference itself produced
@@ -149,6 +150,8 @@ def test_training_step_matches_reference_golden(name):
     assert abs(l.item() - float(z["loss"])) <= 1e-3
     # the training forward runs its GEMMs in exact fp32 (srf_train.hip): every gradient within 2e-4 of the
     # reference's own fp32 backward (measured <= 7e-6 on the MFMA-shaped case)
+    # (the *_shape cases are the BASELINE configurations 2 / 3 / 4 at their own widths and depths -- U16/N512/D5,
+    # GroupComm U8, U36/N2048/D6 with the CH = 32 SAVE pyramid and the K = 2048 weight gradients -- at short T)
     check_grads_against_golden([(k, p.grad.cpu().numpy()) for k, p in model.state_dict(keep_vars=True).items()],
                                z, 2e-4)
 

@@ -51,10 +51,19 @@ CASES = [
     ("cfg3_groupcomm_u8", CONFIGS["cfg3_groupcomm_u8"], 1, 32000, 30, 30),
     ("cfg4_improved_u36_n2048", CONFIGS["cfg4_improved_u36_n2048"], 1, 32000, 40, 40),
     ("cfg5_improved_u36_n4096", CONFIGS["cfg5_improved_u36_n4096"], 1, 128000, 50, 50),
+    # the reference's own __main__ smoke configurations (shape-only checks there):
+    #   improved_sudormrf.py:321-332  U16 / N512, batch 3, T = 32079 (pad path)
+    #   groupcomm_sudormrf_v2.py:421-442  D = 7, K = 91, N = 2048, S = 4, 10 s @ 16 kHz
+    ("main_improved_b3_pad", CONFIGS["cfg2_improved_u16"], 3, 32079, 60, 60),
+    ("main_groupcomm_d7_k91", ModelConfig("groupcomm", 256, 512, 16, 7, 91, 2048, 4, 1, 16), 1, 160000, 61, 61),
 ]
 
 
 def main():
+    # --only a,b: (re)generate just these cases and merge them into the committed manifest
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     torch.manual_seed(0)
     ref_imp = load_ref_module("sudo_rm_rf/dnn/models/improved_sudormrf.py", "_ref_improved_sudormrf")
     ref_gc = load_ref_module("sudo_rm_rf/dnn/models/groupcomm_sudormrf_v2.py", "_ref_groupcomm_sudormrf_v2")
@@ -63,7 +72,11 @@ def main():
     os.makedirs(outdir, exist_ok=True)
     manifest = {"generator": "tools/make_golden.py", "torch": torch.__version__,
                 "reference": "etzinis/sudo_rm_rf @ /root/reference", "cases": {}}
+    if only and os.path.exists(os.path.join(outdir, "MANIFEST.json")):
+        manifest["cases"] = json.load(open(os.path.join(outdir, "MANIFEST.json")))["cases"]
     for name, cfg, batch, T, wseed, iseed in CASES:
+        if only and name not in only:
+            continue
         t0 = time.time()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -84,7 +97,7 @@ def main():
         with torch.no_grad():
             out = model(torch.from_numpy(wav))
             arrays = {"out": out.numpy().astype(np.float32)}
-            if cfg.variant == "groupcomm" and A == 1:
+            if cfg.variant == "groupcomm" and A == 1 and not name.startswith("main_"):
                 mc = ref_mc.apply(out, torch.from_numpy(wav))
                 arrays["out_mixture_consistency"] = mc.numpy().astype(np.float32)
         np.savez(os.path.join(outdir, name + ".npz"), **arrays)
