@@ -430,7 +430,7 @@ def main():
             cnt = C.c_int(0)
             _lib.check(lib.srf_profile_end(stream, C.byref(cnt)), "srf_profile_end")
             model._engine().multi_stream = was_multi_p
-        launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, **dims)
+        launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, packed=not (args.debug_flags & 8), **dims)
         per = {}
         name, ms = C.c_char_p(), C.c_float()
         marks = []
@@ -457,7 +457,7 @@ def main():
         if dom.startswith("pw_conv"):
             # fp32-equivalent FLOPs; the split-precision kernel issues 3 bf16 MFMAs per product block, so
             # its matrix-pipe peak is (bf16 dense peak)/3 in fp32-equivalent terms
-            split = dom.startswith("pw_conv_bf16x3")
+            split = dom.startswith("pw_conv_bf16x3") or dom.startswith("pw_conv_x3v")
             peak = roofline.MFMA_BF16_PEAK_TFLOPS / 3 if split else roofline.MFMA_F32_PEAK_TFLOPS
             rl = {"kernel": dom, "bound": "mfma", "achieved": kd["TFLOPs"], "peak": peak,
                   "unit": "TFLOP/s", "frac": kd["TFLOPs"] / peak, "traffic": None,

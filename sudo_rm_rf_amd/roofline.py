@@ -65,14 +65,24 @@ def pyramid_tiled(L, D):
     return best != L
 
 
-def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0):
+def _packable(cin, cout):
+    """Mirror of srf_x3v_supported(): 1x1 convs whose weights srf_forward pre-splits (srf_pwconv_x3v.hip)."""
+    return cin % 64 == 0 and cin >= 128 and cout >= 192
+
+
+def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, packed=True):
     """(family, algorithmic_bytes, flops) for every kernel launch of one srf_forward, in launch order
     (mirrors srf_api.hip).  Bytes = tensors each kernel must read + write once, fp32."""
     L = frames(T, K, D)
     SA = S * A
     Bg, nB, nC = Bt * G, B // G, C // G
     f = 4.0
-    out = [("encoder", f * Bt * (A * T + N * L), 2.0 * Bt * N * A * K * L)]
+    out = []
+    convs = [(N, B)] + [(nB, nC), (nC, nB)] * U + [(B, SA * N)]
+    pk = [(ci, co) for ci, co in convs if _packable(ci, co)]
+    if kernel_mode == 0 and packed and pk:      # one launch per forward: fp32 weights -> bf16 hi|lo tile images
+        out.append(("pack_pw_weights", sum(8.0 * ci * co for ci, co in pk), 0.0))
+    out.append(("encoder", f * Bt * (A * T + N * L), 2.0 * Bt * N * A * K * L))
 
     def pw(cin, cout, bt, extra_in=0):
         return ("pw_conv", f * bt * L * (cin + cout + extra_in), 2.0 * bt * cin * cout * L)

@@ -15,7 +15,8 @@ TOL = 1e-4   # north_star tolerance, max-abs
 
 ALL_CASES = ["tiny_improved", "tiny_improved_d1", "tiny_improved_short", "tiny_groupcomm", "tiny_groupcomm_a2",
              "cfg1_improved_u8", "cfg1_improved_u8_pad", "cfg2_improved_u16", "cfg3_groupcomm_u8",
-             "cfg4_improved_u36_n2048", "cfg5_improved_u36_n4096"]
+             "cfg4_improved_u36_n2048", "cfg5_improved_u36_n4096",
+             "main_improved_b3_pad", "main_groupcomm_d7_k91"]
 
 
 def build(cfg, sd):

@@ -12,7 +12,7 @@ from oracle.schema import CONFIGS, num_params, state_dict_schema
 
 TINY = ["tiny_improved", "tiny_improved_d1", "tiny_improved_short", "tiny_groupcomm", "tiny_groupcomm_a2"]
 FULL = ["cfg1_improved_u8", "cfg1_improved_u8_pad", "cfg2_improved_u16", "cfg3_groupcomm_u8",
-        "cfg4_improved_u36_n2048"]
+        "cfg4_improved_u36_n2048", "main_improved_b3_pad", "main_groupcomm_d7_k91"]
 
 
 def test_param_counts_match_readme():
