@@ -152,8 +152,13 @@ def test_training_step_matches_reference_golden(name):
     # reference's own fp32 backward (measured <= 7e-6 on the MFMA-shaped case)
     # (the *_shape cases are the BASELINE configurations 2 / 3 / 4 at their own widths and depths -- U16/N512/D5,
     # GroupComm U8, U36/N2048/D6 with the CH = 32 SAVE pyramid and the K = 2048 weight gradients -- at short T)
+    # Bars: 2e-4 for the small fixtures (golden = the reference's fp32 backward).  For the BASELINE-shape fixtures the
+    # golden is the fp64 reference and depth matters (U16 / U36 blocks, split-bf16 backward GEMMs at 2^-17 per product):
+    # 2e-3, or 4 x what the reference's own fp32 backward deviates by for that kind of parameter (PReLU slopes: ~1e-2).
+    # Measured round 2: worst 7.8e-4 (cfg 2 shape), 1.4e-3 (cfg 3 shape), 5.1e-4 / 1.8e-2 on a slope (cfg 4 shape).
+    big = name.endswith("_shape")
     check_grads_against_golden([(k, p.grad.cpu().numpy()) for k, p in model.state_dict(keep_vars=True).items()],
-                               z, 2e-4)
+                               z, 2e-3 if big else 2e-4, fp32_yardstick=4.0 if big else 0.0)
 
 
 def test_fast_training_forward_flag():

@@ -166,19 +166,33 @@ def train_case(name):
     return cfg, sd, mix, tgt, z
 
 
-def check_grads_against_golden(named_grads, z, tol):
-    worst = ("", 0.0)
+def check_grads_against_golden(named_grads, z, tol, fp32_yardstick=0.0):
+    """Every gradient within `tol` (relative to the tensor's largest entry) of the golden one.  fp32_yardstick > 0 (GPU
+    tests of the BASELINE-shape fixtures, whose goldens come from the fp64 reference): the bar of a parameter is raised to
+    yardstick x the worst deviation of the REFERENCE'S OWN fp32 backward from fp64 among the parameters of its kind
+    ("d:" entries; kind = name with the block / level indices wildcarded) -- scalar gradients such as PReLU slopes are sums
+    over ~1e6 terms and carry 1e-2 of fp32 noise in the reference itself."""
+    import re
+    named_grads = list(named_grads)
+    kind_dev = {}
+    if fp32_yardstick > 0:
+        for k, _ in named_grads:
+            if "d:" + k in z:
+                kind = re.sub(r"\d+", "#", k)
+                kind_dev[kind] = max(kind_dev.get(kind, 0.0), float(z["d:" + k]))
+    worst = ("", 0.0, 0.0)
     for k, g in named_grads:
         g = np.asarray(g, dtype=np.float64)
+        bar = max(tol, fp32_yardstick * kind_dev.get(re.sub(r"\d+", "#", k), 0.0))
         step, gmax, gsum, gsq = z["n:" + k]
         smp = g.reshape(-1)[::int(step)][:z["g:" + k].shape[0]]
         scale = max(gmax, 1e-12)
         rel = np.abs(smp - z["g:" + k]).max() / scale
         rel = max(rel, abs(np.sqrt((g ** 2).sum()) - np.sqrt(gsq)) / max(np.sqrt(gsq), 1e-12))
-        if rel > worst[1]:
-            worst = (k, float(rel))
-    print("worst relative gradient error vs the reference: %s %.3e (tolerance %.1e)" % (worst[0], worst[1], tol))
-    assert worst[1] <= tol, worst
+        if rel / bar > worst[1] / max(worst[2], 1e-300) or not worst[0]:
+            worst = (k, float(rel), float(bar))
+    print("worst gradient error relative to its bar: %s %.3e (bar %.1e)" % worst)
+    assert worst[1] <= worst[2], worst
 
 
 @pytest.mark.parametrize("name", sorted(_train_manifest()))

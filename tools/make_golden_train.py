@@ -95,8 +95,24 @@ def main():
         l = torch.clamp(loss_fn(rec, tgt), min=-30.0, max=30.0)
         l.backward()
         arrays = {"loss": np.float32(l.item())}
+        g32 = None
+        if f64:
+            # the same step by the reference in its native fp32: how far its OWN gradients are from the fp64 ones, per
+            # parameter ("d:" entries) -- the yardstick for what an fp32 implementation can be asked to reproduce
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m32 = (ref_imp.SuDORMRF if cfg.variant == "improved" else ref_gc.GroupCommSudoRmRf)(**cfg.ctor_kwargs())
+            m32.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            m32.train()
+            rec32 = m32(mix.float())
+            if cfg.variant == "groupcomm":
+                rec32 = ref_mc.apply(rec32, mix.float())
+            torch.clamp(loss_fn(rec32, tgt.float()), min=-30.0, max=30.0).backward()
+            g32 = {k: p.grad.numpy().astype(np.float64) for k, p in m32.state_dict(keep_vars=True).items()}
         for k, p in model.state_dict(keep_vars=True).items():
             g = p.grad.numpy()
+            if g32 is not None:
+                arrays["d:" + k] = np.float64(np.abs(g32[k] - g).max() / max(np.abs(g).max(), 1e-300))
             smp, step = sample(g, BIG_SAMPLE if name.endswith("_shape") else SAMPLE)
             arrays["g:" + k] = smp.astype(np.float32)
             arrays["n:" + k] = np.array([step, float(np.abs(g).max()), float(g.astype(np.float64).sum()),
