@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus DMA of the pipeline tail must not outlive the block's LDS
 }
 
-// (Measured and removed, git history has it: the same pipeline as TWO independent 256-thread blocks per CU -- 256 x 64 tiles,
+// (Measured and removed again: the same pipeline as TWO independent 256-thread blocks per CU -- 256 x 64 tiles,
 // 4 wavefronts, 2 LDS stages of 40 KB -- so that one block's epilogue and operand waits sit under the other's MFMAs.  Correct
 // at the first run, but slower inside the forward: res_conv 144 vs 130 us, proj_1x1 133 vs 119 us, mask 287 vs 251 us; it
 // doubles the L2 -> LDS weight traffic and halves the reuse of every fragment of W.)
