@@ -397,7 +397,8 @@ def main():
                                (args.workload, batch, T, T / fs, fs),
                    "global_batch": batch * n_gpus, "parallelism": "batch-sharded replicas x%d" % n_gpus,
                    "kernel_mode": args.kernel_mode,
-                   "stream_split": list(model._engine()._split_choice.get((dev.index, batch, T), (batch,)))},
+                   "stream_split": list(model._engine()._split_choice.get((dev.index, batch, T), (batch,))),
+                   "hip_graph_replay": bool(model._engine()._graphs)},
         "self_check": self_check,
         "step_ms": {"median": per_step_ms[len(per_step_ms) // 2], "p10": per_step_ms[int(0.1 * (len(per_step_ms) - 1))],
                     "p90": per_step_ms[int(round(0.9 * (len(per_step_ms) - 1)))], "min": per_step_ms[0],
@@ -422,14 +423,17 @@ def main():
         stream = _lib.current_stream(dev)
         psteps = min(args.steps, 10)
         with torch.no_grad():
-            was_multi_p = model._engine().multi_stream
-            model._engine().multi_stream = False      # the profiler's events live on one stream
+            from sudo_rm_rf_amd import engine as engine_mod
+            was_multi_p, was_graph = model._engine().multi_stream, engine_mod._GRAPH_MODE
+            model._engine().multi_stream = False      # the profiler's events live on one stream ...
+            engine_mod._GRAPH_MODE = "off"            # ... and on eager launches (a replayed graph records none)
             lib.srf_profile_begin(stream)
             for _ in range(psteps):
                 model(wav)
             cnt = C.c_int(0)
             _lib.check(lib.srf_profile_end(stream, C.byref(cnt)), "srf_profile_end")
             model._engine().multi_stream = was_multi_p
+            engine_mod._GRAPH_MODE = was_graph
         launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, packed=not (args.debug_flags & 8), **dims)
         per = {}
         name, ms = C.c_char_p(), C.c_float()

@@ -130,6 +130,22 @@ extern "C" int srf_abi_version(void) { return SRF_ABI_VERSION; }
 extern "C" void srf_set_kernel_mode(int mode) { g_kernel_mode.store((mode == 1 || mode == 2) ? mode : 0, std::memory_order_relaxed); }
 extern "C" int srf_get_kernel_mode(void) { return g_kernel_mode.load(std::memory_order_relaxed); }
 
+// Zero fill as a kernel of our own rather than hipMemsetAsync: the inference forward is replayed from a captured HIP graph
+// for small batches (engine.py), and a graph made of kernel nodes only replayed correctly where one with memset nodes did
+// not (NaN outputs after an unrelated host-synchronising copy, ROCm 7.0 runtime; tools/diag_graph.py).  16-byte granules.
+__global__ __launch_bounds__(256) void srf_zero_kernel(uint4* __restrict__ p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+static int srf_zero_launch(void* p, size_t bytes, hipStream_t st) {
+  SRF_CHECK_ARG(srf_aligned16(p) && bytes % 16 == 0, "internal: zero fill needs 16-byte granules");
+  const size_t n16 = bytes / 16;
+  if (!n16) return SRF_OK;
+  const size_t blocks = (n16 + 255) / 256;
+  hipLaunchKernelGGL(srf_zero_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (uint4*)p, n16);
+  SRF_CHECK_LAUNCH("zero_fill", st);
+  return SRF_OK;
+}
+
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
 int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T,
                            hipStream_t st);
@@ -159,7 +175,8 @@ extern "C" int srf_decoder(const float* v, const float* w, float* out, int Bt, i
   float* z = zb + align_up((size_t)M, 64);
   int rc = srf_transpose_launch(w, wt, Ci, M, st);
   if (rc) return rc;
-  SRF_CHECK_HIP(hipMemsetAsync(zb, 0, sizeof(float) * M, st));
+  rc = srf_zero_launch(zb, sizeof(float) * align_up((size_t)M, 64), st);
+  if (rc) return rc;
   rc = srf_pw_conv(v, wt, zb, z, Bt, Ci, M, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
   if (rc) return rc;
   return srf_overlap_add_launch(z, out, Bt, Co, K, L, T, st);
@@ -326,7 +343,8 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
   auto slot = [&](int s) { return stats + (size_t)s * Bg * SRF_STAT_BUCKETS * 2; };
   int rc;
 
-  SRF_CHECK_HIP(hipMemsetAsync(stats, 0, p->stats_bytes, st));
+  rc = srf_zero_launch(stats, p->stats_bytes, st);
+  if (rc) return rc;
   // split + lay out every 1x1 weight for the 256 x 128 split-precision GEMM (srf_pwconv_x3v.hip), one launch per forward
   // (kernel mode 0 only; debug flag 8 = without: the 128 x 128 kernels that split W on the fly)
   const bool use_pack = srf_kernel_mode() == 0 && !(srf_debug_flags() & 8) && !p->pk_param.empty();

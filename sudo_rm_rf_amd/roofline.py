@@ -77,7 +77,7 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, p
     SA = S * A
     Bg, nB, nC = Bt * G, B // G, C // G
     f = 4.0
-    out = []
+    out = [("zero_fill", 16.0 * 64 * Bg * (1 + U * (D + 2 + (1 if variant == "groupcomm" else 0))), 0.0)]   # GlobLN statistic slots
     convs = [(N, B)] + [(nB, nC), (nC, nB)] * U + [(B, SA * N)]
     pk = [(ci, co) for ci, co in convs if _packable(ci, co)]
     if kernel_mode == 0 and packed and pk:      # one launch per forward: fp32 weights -> bf16 hi|lo tile images
@@ -110,6 +110,7 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, p
         out.append(pw(nC, nB, Bg, extra_in=nB))
     out.append(pw(B, SA * N, Bt, extra_in=N))
     out.append(("transpose", f * 2 * SA * N * SA * K, 0.0))
+    out.append(("zero_fill", f * 64 * ((SA * K + 63) // 64), 0.0))   # the frame GEMM's zero bias
     out.append(pw(SA * N, SA * K, Bt))
     out.append(("overlap_add", f * Bt * (SA * K * L + SA * T), 3.0 * Bt * SA * T))
     return out

@@ -320,3 +320,38 @@ def test_degenerate_inputs_match_oracle(variant):
         assert torch.isfinite(got).all(), name
         scale = max(want.abs().max().item(), 1e-6)
         assert (got - want).abs().max().item() <= 2e-4 * scale + 1e-6, (name, (got - want).abs().max().item(), scale)
+
+
+@pytest.mark.gpu
+def test_small_forward_graph_replay(manifest):
+    """With SRF_GRAPH=auto the engine replays a captured HIP graph after a few calls of one small (batch, T).  The
+    replayed outputs equal the eager ones bit for bit, follow in-place weight updates (the graph reads the same tensors),
+    and a new weight tensor (new pointer) gets a new capture."""
+    from sudo_rm_rf_amd import engine as engine_mod
+    cfg, sd, wav, gold = load_case(manifest, "cfg1_improved_u8")
+    model = build(cfg, sd)
+    x = torch.from_numpy(wav).to(DEV)
+    eng = model._engine()
+    old = engine_mod._GRAPH_MODE
+    try:
+        with torch.no_grad():
+            engine_mod._GRAPH_MODE = "off"
+            eager = model(x).clone()
+            engine_mod._GRAPH_MODE = "auto"
+            outs = [model(x).clone() for _ in range(engine_mod._GRAPH_AFTER + 3)]
+            assert len(eng._graphs) == 1
+            for o in outs:
+                assert torch.equal(o, eager)
+            x2 = torch.from_numpy(weights_mix(1, wav.shape[-1], seed=123)).to(DEV)
+            engine_mod._GRAPH_MODE = "off"
+            want2 = model(x2).clone()
+            engine_mod._GRAPH_MODE = "auto"
+            assert torch.equal(model(x2), want2)                  # same graph, new input
+            model.bottleneck.bias.mul_(1.5)                       # in-place update: same pointer, graph sees the new values
+            engine_mod._GRAPH_MODE = "off"
+            want3 = model(x).clone()
+            engine_mod._GRAPH_MODE = "auto"
+            assert torch.equal(model(x), want3)
+            assert np.abs(eager.cpu().numpy() - gold["out"]).max() <= TOL
+    finally:
+        engine_mod._GRAPH_MODE = old
