@@ -27,6 +27,10 @@ FILE_FLAGS = {
     "srf_pwconv_x3v.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_wgrad.hip": ["-fno-slp-vectorize"],
     "srf_pwconv.hip": ["-fno-slp-vectorize"],
+    # register-resident pyramid: the SLP vectorizer trades two v_fma_f32 for one v_pk_fma_f32 plus a v_mov that builds the
+    # operand pair (same VALU count, dearer instructions: tools/probes/valu_rate_probe.hip measures 4.6 vs 5.5 cycles);
+    # same-box A/B on cfg 2: pass 1 70.0 -> 63.7 us, pass 2 unchanged
+    "srf_pyramid_reg.hip": ["-fno-slp-vectorize"],
 }
 
 # ISA lint (gfx950 erratum found in round 2, tools/probes/pk_opsel_probe.hip): a VOP3P packed-fp32 instruction whose SRC1

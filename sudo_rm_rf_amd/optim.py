@@ -21,7 +21,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.last_grad_norm = None          # device scalar: total gradient norm before clipping (last step)
 
     def _table(self, gi, group, plist):
-        key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist))
+        # the device table holds raw pointers: key on every tensor it points at (load_state_dict replaces the state tensors)
+        key = (gi, tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                          self.state[p]["exp_avg_sq"].data_ptr()) for p in plist))
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == key:
             return cached[1:]
@@ -62,7 +64,8 @@ class FusedClipAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-            step = self.state[plist[0]]["step"] + 1
+            # torch.optim.Adam's state_dict keeps `step` as a float tensor: accept it
+            step = int(self.state[plist[0]]["step"]) + 1
             for p in plist:
                 self.state[p]["step"] = step
             tens, chs, buckets, norm = self._table(gi, group, plist)
@@ -75,3 +78,7 @@ class FusedClipAdam(torch.optim.Optimizer):
             _lib.check(rc, "srf_clip_adam_step")
             self.last_grad_norm = norm
         return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables.clear()

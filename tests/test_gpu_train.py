@@ -186,6 +186,37 @@ def test_fast_training_forward_flag():
     assert (num / den) ** 0.5 <= 2e-2          # whole-gradient relative error (measured 3e-3)
 
 
+def test_fused_clip_adam_state_dict_round_trips_with_torch_adam():
+    """A torch.optim.Adam state_dict (float-tensor `step`) loads into FusedClipAdam mid-run and the next steps agree; the
+    device pointer table is rebuilt for the replaced state tensors (stale table after load_state_dict)."""
+    from sudo_rm_rf_amd import optim
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 32, 1), (64,), (5000,)]
+    pa = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    ref = torch.optim.Adam(pa, lr=1e-3)
+    fused = optim.FusedClipAdam(pb, lr=1e-3, clip_grad_norm=0.0)
+    for it in range(4):
+        grads = [torch.randn(*s, generator=g).to(DEV) for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad = gr.clone()
+            q.grad = gr.clone()
+        ref.step()
+        if it == 0:
+            fused.step()                      # builds the table on the first state tensors
+        if it == 1:                           # adopt torch's state (new tensors, float step) and parameters
+            fused.load_state_dict(ref.state_dict())
+            with torch.no_grad():
+                for p, q in zip(pa, pb):
+                    q.copy_(p)
+        if it >= 2:
+            fused.step()
+            for p, q in zip(pa, pb):
+                assert (p - q).abs().max().item() <= 2e-6, it
+    assert int(fused.state[pb[0]]["step"]) == int(ref.state[pa[0]]["step"]) == 4
+    ref.load_state_dict(fused.state_dict())   # and back
+
+
 @pytest.mark.parametrize("clip", [5.0, 0.05, 0.0])
 def test_fused_clip_adam_matches_torch(clip):
     """optim.FusedClipAdam == clip_grad_norm_ + torch.optim.Adam (run_improved_sudormrf.py:172-176) over 3 steps."""

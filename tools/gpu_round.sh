@@ -44,10 +44,12 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
       python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile ) > "$OUT/rocprof.log" 2>&1
   echo "rocprof rc=$?"
   f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f" | cut -c1-160
+  if [ "${SKIP_PROF2S:-0}" != "1" ]; then
   echo "== rocprofv3 kernel trace (default: auto-tuned two-stream split)"
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof2s" -o bench -- \
       python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile ) > "$OUT/rocprof2s.log" 2>&1
   echo "rocprof(2 streams) rc=$?"
+  fi
   # keep the merged-back payload small: the raw kernel traces can be large
   find "$OUT/prof" "$OUT/prof2s" -name "*kernel_trace.csv" -delete
 fi
