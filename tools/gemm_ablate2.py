@@ -26,7 +26,7 @@ def run(flags, n=30):
     return e0.elapsed_time(e1) * 1e3 / n
 for abl, nm in names.items():
     print("%-40s %8.1f us" % (nm, run(abl << 16)), flush=True)
-print("%-40s %8.1f us" % ("hipcc's instruction order (flag 2)", run(2)))
+
 print("%-40s %8.1f us" % ("half-tile tail (flag 256)", run(256)))
 kw.pop("residual")
 print("%-40s %8.1f us" % ("full, no residual", run(0)))
