@@ -11,6 +11,15 @@
 // cone of the deepest level reaches 30 (62) level-0 samples = 2 chunks); halo lanes recompute what the
 // neighbouring wavefront owns.  Global accesses are 4 (8) float4 per lane at a 64-B (128-B) lane
 // stride: every byte of a line is used by the same wavefront, L1 merges the pieces.
+//
+// Round 2, measured and removed again (code in git history / the round's notes): TWO rows per lane -- channel c of
+// examples g and g + Bt/2 -- so that every conv tap, mask, moment and merge is a packed-fp32 instruction on naturally aligned
+// (row A, row B) register pairs (weights as scalar pairs broadcast through op_sel on src0, interleave free on load).
+// Bit-compatible results, 39 % fewer VALU instructions per row in pass 2 and 29 % in pass 1 -- and no gain: pass 2 stayed
+// at 83-84 us (it moves 419 MB at 5.0 TB/s: the read + write stream is what bounds it, not the VALU), pass 1 went from 61
+// to 69 us (155 instead of 71 registers: 3 instead of 6 wavefronts per SIMD to cover the loads, and a v_pk_fma_f32 holds the
+// SIMD ~5.5 cycles against 4.6 for a v_fma_f32, tools/probes/valu_rate_probe.hip).  What did help pass 1: building this
+// file WITHOUT the SLP vectorizer (70 -> 62 us: its v_pk_fma_f32 came with a v_mov per operand pair), see build.py.
 #include "srf_pyr.h"
 
 
