@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 9
+#define SRF_ABI_VERSION 10
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -355,6 +355,38 @@ int srf_online_remix(const float* clean, const int* src_b, const int* src_s, int
 int srf_opt_chunk_size(void);
 int srf_clip_adam_step(const void* tensors, const void* chunks, int n_chunks, double* buckets, float max_norm, float lr,
                        float beta1, float beta2, float eps, int step, float* norm_out, void* stream);
+
+/* Input feeder.  Replaces, for this path, the reference's Dataset.__getitem__ + torch DataLoader
+ * (dataset_loader/wham.py:171-226): a pool of host threads reads the WAV files of a batch in parallel -- mixture = stream
+ * 0, then the sources; one crop start per example, shared by its files (:183-186,:201); float32 values exactly as
+ * scipy.io.wavfile.read + torch.tensor(dtype=float32) give them; zero pad to time_samples (:157-166) -- straight into
+ * CALLER-OWNED buffers (pinned host memory if the copy to the device is to be asynchronous):
+ *   wave [batch][n_streams][time_samples] float32, len [batch] int32 (valid samples), stat [batch][2] float32 = {mean,
+ *   unbiased std} of the mixture over the range the reference normalises it on (the crop when it crops, else the whole
+ *   file: it truncates after normalising, :183-191).
+ * paths: n_items * n_streams file names, item-major.  augment: random crop start when a file is longer than time_samples
+ * (splitmix64 of seed, epoch and item: reproducible, unlike the reference's time-seeded numpy generator).  shuffle /
+ * drop_last: the DataLoader's (get_generator, :219-224).
+ * srf_feeder_submit queues the next batch of the epoch (returns 1, queues nothing, when the epoch is exhausted);
+ * srf_feeder_wait blocks until the OLDEST submitted batch is complete and hands its buffers back.  Any number of batches may
+ * be in flight.  srf_wav_info / srf_wav_read: the reader on its own (RIFF/WAVE mono, PCM 8/16/24/32, IEEE float 32/64). */
+typedef struct srf_feeder srf_feeder;
+int srf_wav_info(const char* path, int* rate, int* channels, int* bits, long* frames);
+int srf_wav_read(const char* path, long start, long n, float* dst, long* frames);
+int srf_feeder_create(const char* const* paths, int n_items, int n_streams, int time_samples, int batch, int n_threads,
+                      int augment, int shuffle, int drop_last, unsigned long long seed, srf_feeder** out);
+void srf_feeder_destroy(srf_feeder* f);
+long srf_feeder_batches_per_epoch(const srf_feeder* f);
+long srf_feeder_item_frames(const srf_feeder* f, int item);
+int srf_feeder_start_epoch(srf_feeder* f, int epoch);
+int srf_feeder_submit(srf_feeder* f, float* wave, int* len, float* stat);
+int srf_feeder_wait(srf_feeder* f, float** wave, int** len, float** stat, int* n_valid);
+/* The Dataset's normalisation on a whole batch, on the device (wham.py:189-217): raw [B][n_streams][T] as delivered by the
+ * feeder -> mix [B][T], src [B][n_streams-1][T].  normalize = 0: copy; 1: every stream (x - mean)/(std + eps) over its valid
+ * samples (the mixture with `stat`), zero pad, then (x - mean_T)/(mix_std + eps) with the population std of the padded
+ * mixture. */
+int srf_feeder_normalize(const float* raw, const int* len, const float* stat, int B, int n_streams, int T, int normalize,
+                         float eps, float* mix, float* src, void* stream);
 
 #ifdef __cplusplus
 }
