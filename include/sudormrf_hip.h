@@ -126,6 +126,14 @@ int srf_plan_num_launches(const srf_plan* plan);  /* kernel launches per forward
 int srf_forward(const srf_plan* plan, const float* const* params, int num_params,
                 const float* wav, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The whole caller-side inference recipe in ONE forward (README.md:100-114): per-example {mean,
+ * unbiased std} of the RAW mixture (written to `stats`, [batch][2] device floats), normalisation folded into the encoder's
+ * load, "estimates * std + mean" and -- mixture_consistency != 0, as the README prescribes for the GroupComm models --
+ * mixture_consistency.apply against the normalised mixture folded into the decoder's overlap-add.  Single-channel
+ * mixtures (in_audio_channels = 1).  Same buffers and rules as srf_forward. */
+int srf_separate(const srf_plan* plan, const float* const* params, int num_params, const float* wav, float* out,
+                 float* stats, int mixture_consistency, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Copy an intermediate of the LAST srf_forward on this workspace into dst (for parity tests).
  * what: 0 = encoder output [Bt,N,L], 1 = separation-module output [Bt,B,L], 2 = masked [Bt,S*A*N,L]. */
 int srf_debug_fetch(const srf_plan* plan, const void* workspace, int what, float* dst, size_t dst_floats,
@@ -224,6 +232,7 @@ int srf_mixture_consistency_magsq(const float* pr, const float* mix, float* out,
  *                        mixture_consistency.apply(out, mix_norm) (uniform), as the README prescribes for the
  *                        GroupComm models.  est,out: [Bt,S,T]; stats: [Bt][2]; mix_norm: [Bt,1,T]. */
 int srf_wav_normalize(const float* wav, float* out, float* stats, int rows, int T, void* stream);
+int srf_wav_stats(const float* wav, float* stats, int rows, int T, void* stream);   /* the statistics alone */
 int srf_wav_denormalize(const float* est, const float* stats, const float* mix_norm, float* out, int Bt, int S,
                         int T, void* stream);
 

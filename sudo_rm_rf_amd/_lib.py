@@ -91,6 +91,8 @@ _PROTOS = {
     "srf_opt_chunk_size": (_i, []),
     "srf_clip_adam_step": (_i, [_vp, _vp, _i, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp, _vp]),
     "srf_wav_normalize": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "srf_wav_stats": (_i, [_vp, _vp, _i, _i, _vp]),
+    "srf_separate": (_i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "srf_wav_denormalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srf_dwconv5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp]),
     "srf_pyramid_supported": (_i, [_i, _i, _i]),

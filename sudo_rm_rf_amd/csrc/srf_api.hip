@@ -147,8 +147,11 @@ static int srf_zero_launch(void* p, size_t bytes, hipStream_t st) {
 }
 
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
-int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T,
-                           hipStream_t st);
+int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T, const float* stats,
+                           const float* wav, int mc, hipStream_t st);
+int srf_encoder_impl(const float* wav, const float* w, float* out, double* sums, int Bt, int A, int T, int N, int K, int L,
+                     const float* in_stats, void* stream);
+extern "C" int srf_wav_stats(const float* wav, float* stats, int rows, int T, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // decoder = transpose(weight) -> frame GEMM (K2) -> overlap-add + crop
@@ -161,8 +164,15 @@ extern "C" size_t srf_decoder_scratch_floats(int Bt, int Ci, int Co, int K, int 
   return align_up(M * Ci, 64) + align_up(M, 64) + align_up((size_t)Bt * M * L, 64);
 }
 
+static int srf_decoder_impl(const float* v, const float* w, float* out, int Bt, int Ci, int Co, int K, int L, int T,
+                            float* scratch, const float* post_stats, const float* post_wav, int post_mc, void* stream);
 extern "C" int srf_decoder(const float* v, const float* w, float* out, int Bt, int Ci, int Co, int K,
                            int L, int T, float* scratch, void* stream) {
+  return srf_decoder_impl(v, w, out, Bt, Ci, Co, K, L, T, scratch, nullptr, nullptr, 0, stream);
+}
+// post_stats / post_wav / post_mc: the callers' rescale (+ mixture consistency) folded into the overlap-add (srf_separate)
+static int srf_decoder_impl(const float* v, const float* w, float* out, int Bt, int Ci, int Co, int K, int L, int T,
+                            float* scratch, const float* post_stats, const float* post_wav, int post_mc, void* stream) {
   SRF_CHECK_ARG(v && w && out && scratch, "srf_decoder: null pointer");
   SRF_CHECK_ARG(Bt > 0 && Ci > 0 && Co > 0 && L > 0 && T > 0, "srf_decoder: bad sizes");
   SRF_CHECK_ARG(K >= 3 && (K & 1), "srf_decoder: kernel size must be odd (got %d)", K);
@@ -179,7 +189,7 @@ extern "C" int srf_decoder(const float* v, const float* w, float* out, int Bt, i
   if (rc) return rc;
   rc = srf_pw_conv(v, wt, zb, z, Bt, Ci, M, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
   if (rc) return rc;
-  return srf_overlap_add_launch(z, out, Bt, Co, K, L, T, st);
+  return srf_overlap_add_launch(z, out, Bt, Co, K, L, T, post_stats, post_wav, post_mc, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -316,8 +326,31 @@ extern "C" int srf_plan_num_launches(const srf_plan* p) { return p ? p->n_launch
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+static int srf_forward_impl(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
+                            void* workspace, size_t workspace_bytes, const float* wav_stats, int mixture_consistency,
+                            void* stream);
 extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_params, const float* wav,
                            float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  return srf_forward_impl(p, P, num_params, wav, out, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+// The reference's caller-side inference recipe as ONE pass (README.md:100-114, experiments/simple_whamr_evaluation.py:
+// 142-148): stats = per-row {mean, unbiased std} of the raw mixture (srf_wav_stats), the encoder normalises on load, the
+// decoder's overlap-add rescales the estimates with the mixture's statistics and -- mixture_consistency != 0, what the README
+// prescribes for the GroupComm models -- applies mixture_consistency.apply against the normalised mixture.  wav: the RAW
+// mixture [Bt, in_audio_channels, T]; stats: [Bt * in_audio_channels][2] device floats (written here).
+extern "C" int srf_separate(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
+                            float* stats, int mixture_consistency, void* workspace, size_t workspace_bytes, void* stream) {
+  SRF_CHECK_ARG(p && wav && stats, "srf_separate: null pointer");
+  SRF_CHECK_ARG(p->A == 1, "srf_separate: the recipe is defined for single-channel mixtures (in_audio_channels = %d)", p->A);
+  int rc = srf_wav_stats(wav, stats, p->Bt * p->A, p->T, stream);
+  if (rc) return rc;
+  return srf_forward_impl(p, P, num_params, wav, out, workspace, workspace_bytes, stats, mixture_consistency, stream);
+}
+
+static int srf_forward_impl(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
+                            void* workspace, size_t workspace_bytes, const float* wav_stats, int mixture_consistency,
+                            void* stream) {
   SRF_CHECK_ARG(p && P && wav && out && workspace, "srf_forward: null pointer");
   SRF_CHECK_ARG(num_params == p->n_params, "srf_forward: expected %d parameter tensors, got %d",
                 p->n_params, num_params);
@@ -364,7 +397,7 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
 
   // ---- front end: encoder (+ ln statistics), ln folded into the bottleneck GEMM's operand load
   float* enc = fptr(p->off_enc);
-  rc = srf_encoder(wav, P[0], enc, slot(0), Bt, p->A, p->T, N, K, L, stream);
+  rc = srf_encoder_impl(wav, P[0], enc, slot(0), Bt, p->A, p->T, N, K, L, wav_stats, stream);
   if (rc) return rc;
   float* cur = fptr(p->off_xa);
   float* nxt = fptr(p->off_xb);
@@ -467,7 +500,8 @@ extern "C" int srf_forward(const srf_plan* p, const float* const* P, int num_par
                             &pre, nullptr, nullptr, 1, enc, N, stream);
     if (rc) return rc;
   }
-  rc = srf_decoder(masked, Pt[3], out, Bt, p->SA * N, p->SA, K, L, p->T, fptr(p->off_dec), stream);
+  rc = srf_decoder_impl(masked, Pt[3], out, Bt, p->SA * N, p->SA, K, L, p->T, fptr(p->off_dec), wav_stats, wav,
+                        mixture_consistency, stream);
   return rc;
 }
 

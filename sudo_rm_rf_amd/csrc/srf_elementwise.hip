@@ -218,10 +218,50 @@ __global__ __launch_bounds__(256) void srf_overlap_add_kernel(const float* __res
   out[((size_t)b * Co + o) * T + t] = acc;
 }
 
-int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T,
-                           hipStream_t st) {
-  dim3 grid((T + 255) / 256, Co, Bt);
-  hipLaunchKernelGGL(srf_overlap_add_kernel, grid, dim3(256), 0, st, z, out, Co, K, L, T);
+// The same with the callers' post-processing folded in (README.md:106-114): out = est * std + mean and, with `mc`,
+// mixture_consistency.apply(out, normalised mixture) -- the mixture re-normalised on the fly from the raw waveform.  One
+// thread owns all Co sources of a time step (two sweeps over its <= 3 * Co inputs instead of a [Co] array).
+__global__ __launch_bounds__(256) void srf_overlap_add_post_kernel(const float* __restrict__ z, float* __restrict__ out,
+                                                                   int Co, int K, int L, int T,
+                                                                   const float* __restrict__ stats,
+                                                                   const float* __restrict__ wav, int mc) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const long b = blockIdx.y;
+  const int h = K / 2;
+  const int q = t / h, r = t - q * h;
+  const float mean = stats[2 * b], sd = stats[2 * b + 1];
+  const bool t0 = r == 0 && q >= 1 && q - 1 < L, t1 = q < L, t2 = q + 1 < L;
+  auto est = [&](int o) {
+    const float* zb = z + ((size_t)b * Co * K + (size_t)o * K) * L;
+    float acc = 0.f;
+    if (t0) acc += zb[(size_t)(2 * h) * L + (q - 1)];
+    if (t1) acc += zb[(size_t)(r + h) * L + q];
+    if (t2) acc += zb[(size_t)r * L + (q + 1)];
+    return acc * sd + mean;
+  };
+  float corr = 0.f;
+  if (mc) {
+    float tot = 0.f;
+    for (int o = 0; o < Co; ++o) tot += est(o);
+    corr = ((wav[b * (long)T + t] - mean) / (sd + 1e-9f) - tot) * (1.f / (float)Co);
+  }
+  for (int o = 0; o < Co; ++o) {
+    const float v = est(o);
+    out[((size_t)b * Co + o) * T + t] = mc ? v + corr : v;
+  }
+}
+
+// stats: null = plain overlap-add; else [Bt][2] {mean, std} of the raw mixture `wav` [Bt][T] (mc: also mixture consistency)
+int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T, const float* stats,
+                           const float* wav, int mc, hipStream_t st) {
+  if (stats) {
+    dim3 grid((T + 255) / 256, Bt);
+    hipLaunchKernelGGL(srf_overlap_add_post_kernel, grid, dim3(256), 0, st, z, out, Co, K, L, T, stats, wav, mc);
+  } else {
+    dim3 grid((T + 255) / 256, Co, Bt);
+    hipLaunchKernelGGL(srf_overlap_add_kernel, grid, dim3(256), 0, st, z, out, Co, K, L, T);
+  }
   SRF_CHECK_LAUNCH("overlap_add", st);
   return SRF_OK;
 }
@@ -265,9 +305,18 @@ __global__ __launch_bounds__(256) void srf_wav_normalize_kernel(const float* __r
     stats[2 * r] = fm;
     stats[2 * r + 1] = fs;
   }
+  if (!y) return;   // statistics only (srf_wav_stats: the normalisation itself happens in the encoder's load)
   const float den = fs + 1e-9f;
   float* yr = y + r * (long)T;
   for (int i = tid; i < T; i += 256) yr[i] = (xr[i] - fm) / den;
+}
+
+extern "C" int srf_wav_stats(const float* wav, float* stats, int rows, int T, void* stream) {
+  SRF_CHECK_ARG(wav && stats && rows > 0 && T > 0, "srf_wav_stats: bad arguments");
+  hipLaunchKernelGGL(srf_wav_normalize_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, wav, (float*)nullptr,
+                     stats, T);
+  SRF_CHECK_LAUNCH("wav_stats", stream);
+  return SRF_OK;
 }
 
 extern "C" int srf_wav_normalize(const float* wav, float* out, float* stats, int rows, int T, void* stream) {

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void srf_encoder_fast_kernel(const float* __re
                                                                const float* __restrict__ w,
                                                                float* __restrict__ out,
                                                                double* __restrict__ sums, int T, int N,
-                                                               int L) {
+                                                               int L, const float* __restrict__ in_stats) {
   constexpr int H = KT / 2;
   constexpr int FR = 128;                  // frames per block
   constexpr int WIN = (FR - 1) * H + KT;   // samples needed by FR frames
@@ -24,9 +24,12 @@ __global__ __launch_bounds__(256) void srf_encoder_fast_kernel(const float* __re
   const int b = blockIdx.y;
   const int l0 = blockIdx.x * FR;
   const float* xb = wav + (size_t)b * T;
+  // in_stats (caller-side recipe folded in, README.md:100-104): the model sees (x - mean) / (std + 1e-9); the conv's zero
+  // padding applies to the NORMALISED signal
+  const float im = in_stats ? in_stats[2 * b] : 0.f, iden = in_stats ? in_stats[2 * b + 1] + 1e-9f : 1.f;
   for (int i = threadIdx.x; i < WIN; i += 256) {
     const int t = H * l0 - H + i;
-    win[i] = (t >= 0 && t < T) ? xb[t] : 0.f;
+    win[i] = (t >= 0 && t < T) ? (in_stats ? (xb[t] - im) / iden : xb[t]) : 0.f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -73,7 +76,8 @@ __global__ __launch_bounds__(256) void srf_encoder_generic_kernel(const float* _
                                                                   const float* __restrict__ w,
                                                                   float* __restrict__ out,
                                                                   double* __restrict__ sums, int A,
-                                                                  int T, int N, int K, int L) {
+                                                                  int T, int N, int K, int L,
+                                                                  const float* __restrict__ in_stats) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* red = reinterpret_cast<double*>(smem_raw);        // 8 doubles
   float* win = reinterpret_cast<float*>(smem_raw + 64);     // [A][WIN]
@@ -85,7 +89,12 @@ __global__ __launch_bounds__(256) void srf_encoder_generic_kernel(const float* _
   for (int i = threadIdx.x; i < A * WIN; i += 256) {
     const int a = i / WIN, j = i - a * WIN;
     const int t = H * l0 - H + j;
-    win[i] = (t >= 0 && t < T) ? wav[((size_t)b * A + a) * T + t] : 0.f;
+    float v = 0.f;
+    if (t >= 0 && t < T) {
+      v = wav[((size_t)b * A + a) * T + t];
+      if (in_stats) v = (v - in_stats[2 * ((size_t)b * A + a)]) / (in_stats[2 * ((size_t)b * A + a) + 1] + 1e-9f);
+    }
+    win[i] = v;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -108,8 +117,15 @@ __global__ __launch_bounds__(256) void srf_encoder_generic_kernel(const float* _
   if (sums) srf_block_stats_atomic<4>(ds, dq, srf_stat_slot(sums, b, blockIdx.x), red);
 }
 
+int srf_encoder_impl(const float* wav, const float* w, float* out, double* sums, int Bt, int A, int T, int N, int K, int L,
+                     const float* in_stats, void* stream);
 extern "C" int srf_encoder(const float* wav, const float* w, float* out, double* sums, int Bt, int A,
                            int T, int N, int K, int L, void* stream) {
+  return srf_encoder_impl(wav, w, out, sums, Bt, A, T, N, K, L, nullptr, stream);
+}
+// in_stats: null, or [Bt * A][2] {mean, std} per input row: the input is normalised on load (srf_separate)
+int srf_encoder_impl(const float* wav, const float* w, float* out, double* sums, int Bt, int A, int T, int N, int K, int L,
+                     const float* in_stats, void* stream) {
   SRF_CHECK_ARG(wav && w && out, "srf_encoder: null pointer");
   SRF_CHECK_ARG(Bt > 0 && A > 0 && T > 0 && N > 0 && L > 0, "srf_encoder: bad sizes");
   SRF_CHECK_ARG(K >= 3 && (K & 1), "srf_encoder: enc_kernel_size must be odd (got %d)", K);
@@ -117,14 +133,14 @@ extern "C" int srf_encoder(const float* wav, const float* w, float* out, double*
   hipStream_t st = (hipStream_t)stream;
   if (srf_kernel_mode() != 1 && A == 1 && K == 21) {
     dim3 grid((L + 127) / 128, Bt);
-    hipLaunchKernelGGL(srf_encoder_fast_kernel<21>, grid, dim3(256), 0, st, wav, w, out, sums, T, N, L);
+    hipLaunchKernelGGL(srf_encoder_fast_kernel<21>, grid, dim3(256), 0, st, wav, w, out, sums, T, N, L, in_stats);
   } else {
     const int H = K / 2;
     const size_t lds = 64 + sizeof(float) * (size_t)A * ((64 - 1) * H + K);
     SRF_CHECK_ARG(lds <= 64 * 1024, "srf_encoder: window does not fit LDS (A=%d K=%d)", A, K);
     dim3 grid((L + 63) / 64, Bt);
     hipLaunchKernelGGL(srf_encoder_generic_kernel, grid, dim3(256), lds, st, wav, w, out, sums, A, T, N,
-                       K, L);
+                       K, L, in_stats);
   }
   SRF_CHECK_LAUNCH("encoder", st);
   return SRF_OK;

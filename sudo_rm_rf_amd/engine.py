@@ -86,6 +86,14 @@ class Plan:
                              _lib.current_stream(wav.device))
         _lib.check(rc, "srf_forward")
 
+    def separate(self, param_ptrs, wav, out, stats, mixture_consistency):
+        """srf_separate: statistics of the raw mixture, normalise-on-load, forward, rescale (+ mixture consistency)."""
+        lib = _lib.load()
+        rc = lib.srf_separate(self.handle, param_ptrs, self.num_params, _lib.ptr(wav), _lib.ptr(out), _lib.ptr(stats),
+                              int(bool(mixture_consistency)), _lib.ptr(self.workspace), self.workspace_bytes,
+                              _lib.current_stream(wav.device))
+        _lib.check(rc, "srf_separate")
+
     def debug_fetch(self, what, shape):
         dst = torch.empty(shape, dtype=torch.float32, device=self.device)
         rc = _lib.load().srf_debug_fetch(self.handle, _lib.ptr(self.workspace), what, _lib.ptr(dst),
@@ -298,6 +306,29 @@ class ModelEngine:
                 return out
             out = torch.empty((batch, out_ch, T), dtype=torch.float32, device=x.device)
             self._forward_split(self._splits(batch, T, x, out, table), x, out, table)
+            self.last_plan = plan
+        return out
+
+    def separate(self, module, mixture, mixture_consistency):
+        """The reference's caller-side recipe around model() (README.md:100-114) as one srf_separate call: mixture
+        [batch, 1, time] RAW (un-normalised) on the MI355X -> estimates [batch, num_sources, time] in the mixture's scale."""
+        if mixture.device.type != "cuda":
+            raise _lib.SrfError("sudo_rm_rf_amd runs on an MI355X only: input is on %s" % mixture.device)
+        params = [p.detach() for p in _weights(module)]
+        for p in params:
+            if p.device != mixture.device or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.SrfError("all parameters must be contiguous float32 on %s" % mixture.device)
+        x = mixture.detach().to(torch.float32).contiguous()
+        batch, _, T = x.shape
+        if batch == 0 or T == 0:
+            raise RuntimeError("empty input %s" % (tuple(mixture.shape),))
+        with torch.cuda.device(x.device), self._run_lock(x.device):
+            plan = self.plan_for(batch, T, x.device)
+            if plan.num_params != len(params):
+                raise _lib.SrfError("state_dict has %d tensors, plan expects %d" % (len(params), plan.num_params))
+            out = torch.empty((batch, module.num_sources, T), dtype=torch.float32, device=x.device)
+            stats = torch.empty((batch, 2), dtype=torch.float32, device=x.device)
+            plan.separate(self._param_table(params, x.device), x, out, stats, mixture_consistency)
             self.last_plan = plan
         return out
 

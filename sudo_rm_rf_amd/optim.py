@@ -80,5 +80,10 @@ class FusedClipAdam(torch.optim.Optimizer):
         return loss
 
     def load_state_dict(self, state_dict):
+        """Accepts torch.optim.Adam's state_dict as well: its param groups carry no clip_grad_norm (this optimizer's own
+        value is kept) and its `step` is a float tensor (cast on use); the device pointer table is rebuilt."""
+        keep = [g["clip_grad_norm"] for g in self.param_groups]
         super().load_state_dict(state_dict)
+        for g, c in zip(self.param_groups, keep):
+            g.setdefault("clip_grad_norm", c)
         self._tables.clear()

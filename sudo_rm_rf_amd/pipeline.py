@@ -3,8 +3,10 @@
 README.md:100-114 (and experiments/simple_whamr_evaluation.py:142-148) wrap every model() call in the same
 lines: per-example mean/std normalisation of the mixture, the forward, rescaling of the estimates with the
 mixture's statistics and -- for the GroupComm models -- mixture consistency.  On a GPU those are 5-7 extra
-passes over [batch, sources, time] tensors in separate ATen kernels; here they are two small HIP kernels
-(srf_wav_normalize / srf_wav_denormalize) around srf_forward."""
+passes over [batch, sources, time] tensors in separate ATen kernels; here they are folded INTO the forward
+(srf_separate): one statistics kernel over the raw mixture, the normalisation in the encoder's operand load, the
+rescale and the mixture consistency in the decoder's overlap-add.  The stand-alone kernels (srf_wav_normalize /
+srf_wav_denormalize, ``ops``) remain for callers that need the normalised mixture itself."""
 import torch
 
 from . import ops
@@ -24,6 +26,8 @@ def separate(model, mixture, mixture_consistency=None):
         mixture_consistency = type(model).__name__ == "GroupCommSudoRmRf"
     x = mixture.detach().to(torch.float32).contiguous()
     with torch.no_grad():
-        norm, stats = ops.wav_normalize(x)
+        if getattr(model, "in_audio_channels", 1) == 1 and hasattr(model, "_engine"):
+            return model._engine().separate(model, x, bool(mixture_consistency))
+        norm, stats = ops.wav_normalize(x)          # (multi-channel front ends: the three-kernel form)
         est = model(norm)
         return ops.wav_denormalize(est, stats, norm if mixture_consistency else None)

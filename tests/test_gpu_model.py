@@ -169,15 +169,17 @@ def test_submodule_forwards(manifest):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("K", [11, 21], ids=["generic-encoder", "k21-encoder"])
 @pytest.mark.parametrize("variant", ["improved", "groupcomm"])
-def test_separate_pipeline_matches_reference_recipe(variant):
-    """sudo_rm_rf_amd.pipeline.separate == the README's normalise / model / rescale (/ mixture consistency)
-    lines evaluated with the oracle model on the CPU (README.md:100-114)."""
+def test_separate_pipeline_matches_reference_recipe(variant, K):
+    """sudo_rm_rf_amd.pipeline.separate (srf_separate: statistics kernel, normalise in the encoder's load, rescale and
+    mixture consistency in the overlap-add) == the README's normalise / model / rescale (/ mixture consistency) lines
+    evaluated with the oracle model on the CPU (README.md:100-114), and == the three-kernel form around model()."""
     from oracle import weights
     from oracle.schema import ModelConfig
-    from sudo_rm_rf_amd import pipeline
-    cfg = (ModelConfig("improved", 16, 32, 2, 3, 11, 24, 2) if variant == "improved"
-           else ModelConfig("groupcomm", 16, 32, 2, 3, 11, 24, 2, 1, 4))
+    from sudo_rm_rf_amd import ops, pipeline
+    cfg = (ModelConfig("improved", 16, 32, 2, 3, K, 24, 2) if variant == "improved"
+           else ModelConfig("groupcomm", 16, 32, 2, 3, K, 24, 2, 1, 4))
     sd = weights.make_state_dict(cfg, seed=5)
     model = build(cfg, sd)
     g = torch.Generator().manual_seed(11)
@@ -191,6 +193,11 @@ def test_separate_pipeline_matches_reference_recipe(variant):
     got = pipeline.separate(model, mix.to(DEV))
     err = (got.cpu() - want).abs().max().item()
     assert err <= 1e-4, err
+    with torch.no_grad():
+        nrm, stats = ops.wav_normalize(mix.to(DEV).unsqueeze(1))
+        unfused = ops.wav_denormalize(model(nrm), stats, nrm if variant == "groupcomm" else None)
+    assert (got - unfused).abs().max().item() <= 2e-5
+    assert torch.equal(pipeline.separate(model, mix.to(DEV).unsqueeze(1)), got)          # [batch, 1, time] form
 
 
 @pytest.mark.gpu
