@@ -86,4 +86,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         for g, c in zip(self.param_groups, keep):
             g.setdefault("clip_grad_norm", c)
+        # torch hands the donor's `step` tensors over by reference (Optimizer.load_state_dict does not clone them for
+        # non-capturable optimizers): an int of our own, or the donor's next step() would advance ours as well
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = int(st["step"])
         self._tables.clear()
