@@ -556,6 +556,10 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char
 // 119 us for proj_1x1, whose two pieces per step spill ~100 registers.  With 64 + 64 accumulators + 32 fragment registers
 // the 256-register budget of two wavefronts per SIMD leaves no room for the k-loop's own pipeline, and the extra ~75 VALU
 // + ~80 SALU instructions per step eat what the overlap wins.  Code: git history, round 2.)
+// (Measured and removed again, round 2: launches with fewer tiles than CUs -- small batches -- dealt out entirely as quarter
+// tiles (rounds = 0: 100 instead of 25-50 busy CUs for a batch-1 GEMM).  Slower than the 128 x 128 kernels they replace:
+// cfg 1 batch 1 0.87 vs 0.79 ms per forward, cfg 2 at batch 4 2.14 vs 1.75 ms -- a quarter tile streams the whole 256-row
+// weight image for a quarter of the MFMA work.)
 // (Measured and removed again: the same pipeline as TWO independent 256-thread blocks per CU -- 256 x 64 tiles,
 // 4 wavefronts, 2 LDS stages of 40 KB -- so that one block's epilogue and operand waits sit under the other's MFMAs.  Correct
 // at the first run, but slower inside the forward: res_conv 144 vs 130 us, proj_1x1 133 vs 119 us, mask 287 vs 251 us; it

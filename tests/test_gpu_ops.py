@@ -165,7 +165,8 @@ def test_pw_conv_buffer_and_pointer_loads_agree(Bt, Cin, Cout, L, pro):
         check(a, want, 5e-5, "pw_conv buffer loads")
 
 
-@pytest.mark.parametrize("Bt,Cin,Cout,L", [(32, 512, 256, 1600), (16, 256, 512, 3200)])   # 1664 / 1600 tiles: persistent
+@pytest.mark.parametrize("Bt,Cin,Cout,L", [(32, 512, 256, 1600), (16, 256, 512, 3200),     # 1664 / 1600 tiles: persistent
+                                           (1, 512, 256, 3200), (2, 256, 512, 1632), (1, 128, 1024, 416)])   # small: quarter tiles
 @pytest.mark.parametrize("pro", [0, 1, 2, 3])
 def test_pw_conv_persistent_variants(Bt, Cin, Cout, L, pro):
     """Every prologue instantiation of the persistent split-bf16 GEMM at model-sized K, in the form that is dispatched
