@@ -83,7 +83,9 @@ static std::vector<ProfMark> g_marks;
 static std::vector<hipEvent_t> g_pool;
 static std::vector<float> g_ms;
 
-bool srf_profiling() { return g_prof; }
+static thread_local int g_prof_hold = 0;   // > 0: launches of a multi-launch operation are not marked one by one
+bool srf_profiling() { return g_prof && g_prof_hold == 0; }
+void srf_prof_hold(int delta) { g_prof_hold += delta; }
 void srf_prof_mark(const char* name, hipStream_t st) {
   hipEvent_t ev;
   if (!g_pool.empty()) {

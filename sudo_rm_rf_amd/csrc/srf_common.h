@@ -16,6 +16,7 @@ int srf_kernel_mode();  // 0 = fast paths, 1 = generic kernels only, 2 = fast pa
 int srf_kernel_mode_override(int mode);   // per-thread override (-1 = none); returns the previous override
 int srf_debug_flags();  // bit0: x3p kernel without sched_group_barrier hints
 bool srf_profiling();
+void srf_prof_hold(int delta);   // +1 / -1 around all but the last launch of an operation that is one profiler interval
 void srf_prof_mark(const char* name, hipStream_t st);
 // Per-device launch geometry caches (srf_api.hip).  The library is called from one thread per GPU (DataParallel replicas,
 // SURVEY.md §8b), so nothing device-dependent may live in a plain function-static: these are indexed by the CALLING

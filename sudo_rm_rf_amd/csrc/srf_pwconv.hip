@@ -275,6 +275,33 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
       (long)Bt * Cin * L * 4 < (1L << 31) && !(srf_debug_flags() & 4) &&
       (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus())
     return srf_pw_x3v_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
+  // An activation tensor beyond the 2 GB reach of the kernel's 32-bit buffer offsets (cfg 5's bottleneck: 16 x 4096 x 12800
+  // floats = 3.4 GB) goes out as several launches over runs of whole examples: examples are independent, every per-example
+  // pointer (statistics slots included) just moves along.
+  if (mfma_ok && mode == 0 && w_packed && srf_x3v_supported(Cin, Cout, L) && srf_aligned16(w_packed) &&
+      (long)Bt * Cin * L * 4 >= (1L << 31) && (long)Cin * L * 4 < (1L << 31) && !(srf_debug_flags() & 4)) {
+    const int cap = (int)(((1L << 31) - 1) / ((long)Cin * L * 4));   // examples one launch can address
+    const int nch = (Bt + cap - 1) / cap, per = (Bt + nch - 1) / nch;  // balanced runs of whole examples
+    const int last = Bt - (nch - 1) * per;
+    if ((long)last * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus()) {
+      for (int b0 = 0; b0 < Bt; b0 += per) {
+        PwArgs c = a;
+        c.Bt = Bt - b0 < per ? Bt - b0 : per;
+        c.x = a.x + (size_t)b0 * Cin * L;
+        c.y = a.y + (size_t)b0 * Cout * L;
+        if (a.residual) c.residual = a.residual + (size_t)b0 * Cout * L;
+        if (a.mul) c.mul = a.mul + (size_t)b0 * a.mul_channels * L;
+        if (a.out_sums) c.out_sums = a.out_sums + (size_t)b0 * SRF_STAT_BUCKETS * 2;
+        if (a.nrm.sums) c.nrm.sums = a.nrm.sums + (size_t)b0 * SRF_STAT_BUCKETS * 2;
+        const bool more = b0 + per < Bt;    // (one profiler interval for the whole operation: only the last launch is marked)
+        if (more) srf_prof_hold(+1);
+        const int rc = srf_pw_x3v_launch(c, reinterpret_cast<const char*>(w_packed), pro_sel, st);
+        if (more) srf_prof_hold(-1);
+        if (rc) return rc;
+      }
+      return SRF_OK;
+    }
+  }
   if (mfma_ok && mode == 0 && (Cin % 64 == 0)) return srf_pw_bf16x3_launch(a, pro_sel, st);
   if (mfma_ok) {
     const int nMt = (Cout + PW_BM - 1) / PW_BM, nLt = (L + PW_BN - 1) / PW_BN;

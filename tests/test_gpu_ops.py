@@ -205,6 +205,34 @@ def test_pw_conv_persistent_variants(Bt, Cin, Cout, L, pro):
     assert torch.equal(outs["packed 256x128"], outs["dispatched"])
 
 
+def test_pw_conv_beyond_2gb_is_chunked_over_examples():
+    """An activation tensor beyond the 256 x 128 kernel's 32-bit buffer reach (cfg 5's bottleneck: 3.4 GB) goes out as
+    several launches over runs of whole examples: same outputs and same per-example statistics as the 64-bit pointer
+    kernels, including the input-norm prologue whose statistic slots move with the run."""
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+    Bt, Cin, Cout, L = 3, 512, 256, 358400                      # 2.2 GB of activations, 0.73 GB per example
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(Bt, Cin, L, generator=g, device=DEV) * 1.2 + 0.1
+    x[1] *= 3.0          # per-example statistics must not be mixed up (the prologue normalises with them: outputs would differ)
+    w = torch.randn(Cout, Cin, 1, generator=g, device=DEV) * Cin ** -0.5
+    bias = torch.randn(Cout, generator=g, device=DEV) * 0.2
+    res = torch.randn(Bt, Cout, L, generator=g, device=DEV)
+    kw = dict(in_sums=ops.gln_stats(x, Bt), in_gamma=torch.rand(Cin, generator=g, device=DEV) + 0.5,
+              in_beta=torch.randn(Cin, generator=g, device=DEV) * 0.3, in_prelu=torch.tensor([0.2], device=DEV), residual=res)
+    packed = ops.pack_pw_weight(w)
+    s_a, s_b = ops.new_sums(Bt, DEV), ops.new_sums(Bt, DEV)
+    got = ops.pw_conv(x, w, bias, packed=packed, out_sums=s_a, **kw)
+    try:
+        ops.set_debug_flags(4)                                   # without the 256 x 128 kernel: 64-bit pointer form
+        want = ops.pw_conv(x, w, bias, packed=packed, out_sums=s_b, **kw)
+    finally:
+        ops.set_debug_flags(0)
+    assert torch.equal(got, want)
+    ta, tb = s_a.sum(1), s_b.sum(1)                              # [example][{sum, sumsq}]
+    assert ((ta - tb).abs() <= 1e-7 * tb.abs().clamp_min(1.0)).all()      # (fp32 partial sums in a different order)
+
+
 def test_pw_conv_mask_epilogue(mode):
     from sudo_rm_rf_amd import ops
     Bt, Cin, N, S, L = 2, 64, 48, 2, 260
