@@ -192,6 +192,7 @@ def test_fast_training_forward_flag():
 def test_fused_clip_adam_state_dict_round_trips_with_torch_adam():
     """A torch.optim.Adam state_dict (float-tensor `step`) loads into FusedClipAdam mid-run and the next steps agree; the
     device pointer table is rebuilt for the replaced state tensors (stale table after load_state_dict)."""
+    import copy
     from sudo_rm_rf_amd import optim
     g = torch.Generator().manual_seed(11)
     shapes = [(64, 32, 1), (64,), (5000,)]
@@ -208,7 +209,8 @@ def test_fused_clip_adam_state_dict_round_trips_with_torch_adam():
         if it == 0:
             fused.step()                      # builds the table on the first state tensors
         if it == 1:                           # adopt torch's state (new tensors, float step) and parameters
-            fused.load_state_dict(ref.state_dict())
+            # (a deep copy, as a checkpoint file would be: torch's load_state_dict keeps the donor's tensors by reference)
+            fused.load_state_dict(copy.deepcopy(ref.state_dict()))
             with torch.no_grad():
                 for p, q in zip(pa, pb):
                     q.copy_(p)
@@ -217,7 +219,7 @@ def test_fused_clip_adam_state_dict_round_trips_with_torch_adam():
             for p, q in zip(pa, pb):
                 assert (p - q).abs().max().item() <= 2e-6, it
     assert int(fused.state[pb[0]]["step"]) == int(ref.state[pa[0]]["step"]) == 4
-    ref.load_state_dict(fused.state_dict())   # and back
+    ref.load_state_dict(copy.deepcopy(fused.state_dict()))   # and back
 
 
 @pytest.mark.parametrize("clip", [5.0, 0.05, 0.0])
