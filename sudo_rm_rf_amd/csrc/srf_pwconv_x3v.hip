@@ -121,7 +121,7 @@ __device__ __forceinline__ void v_split8(const float (&v)[8], bf16x8& hi, bf16x8
 // quarter of a tile per block instead of a whole tile on R blocks (res_conv at batch 32: 800 tiles on 256 CUs = 3.125 rounds,
 // was 4).  A quarter tile uses all eight wavefronts as 8 (M) x 1 (N), one 32 x 32 accumulator each; its columns sit at rows
 // 0..31 of the B images, lanes beyond column 31 fetch nothing (out-of-range buffer offsets return 0 without a memory access).
-template <int PRO, int ABL = 0>
+template <int PRO, int ABL = 0, int KS = 0>
 __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt,
                                                             int total, int rounds, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta) {
@@ -313,6 +313,36 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char
         f.bl[ks][t] = *reinterpret_cast<const bf16x8*>(base + V_B_IMG + b_off[t][ks]);
       }
   };
+  auto read_frags_ks = [&](Frags& f, int stage, int ks, auto full_tag) __attribute__((always_inline)) {
+    constexpr int NT = decltype(full_tag)::value ? 2 : 1;
+    const char* base = smem + stage * V_STAGE;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f.ah[ks][t] = *reinterpret_cast<const bf16x8*>(base + a_off[t][ks]);
+      f.al[ks][t] = *reinterpret_cast<const bf16x8*>(base + V_A_IMG + a_off[t][ks]);
+      f.bh[ks][t] = *reinterpret_cast<const bf16x8*>(base + b_off[t][ks]);
+      f.bl[ks][t] = *reinterpret_cast<const bf16x8*>(base + V_B_IMG + b_off[t][ks]);
+    }
+  };
+  auto mma_ks = [&](const Frags& f, int ks, auto full_tag) __attribute__((always_inline)) {
+    if (ABL & 4) return;
+    constexpr int NT = decltype(full_tag)::value ? 2 : 1;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[ks][mi], f.bh[ks][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ks][mi], f.bl[ks][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ks][mi], f.bh[ks][ni], acc[mi][ni], 0, 0, 0);
+  };
   auto mma_tile = [&](const Frags& f, auto full_tag) __attribute__((always_inline)) {
     if (ABL & 4) {
       asm volatile("" ::"v"(f.ah[0][0]), "v"(f.al[1][0]), "v"(f.bh[0][0]), "v"(f.bl[1][0]));
@@ -366,11 +396,24 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char
     int k1, k2, k3;
     const TileP t1 = pick(kt + 1, k1), t2 = pick(kt + 2, k2), t3 = pick(kt + 3, k3);
     Frags f;
-    read_frags(f, s0, full_tag);
-    lds_store(nx, t1, k1, s1);
-    gload_a(t2, k2, s2);
-    gload_b(nx, t3, k3);
-    mma_tile(f, full_tag);
+    if constexpr (KS == 1) {
+      // second k-sub-step's fragments read behind the first one's MFMAs: 32 instead of 64 fragment registers.  Same-box A/B on
+      // cfg 2: the kernels with a GlobLN prologue (res_conv 131 -> 127 us, bottleneck 116 -> 113: their 9 / 1 spilled
+      // registers are gone) gain, proj_1x1 (no prologue, 8 k-steps) loses (121 -> 129) and stays on the hoisted form
+      read_frags_ks(f, s0, 0, full_tag);
+      lds_store(nx, t1, k1, s1);
+      gload_a(t2, k2, s2);
+      gload_b(nx, t3, k3);
+      mma_ks(f, 0, full_tag);
+      read_frags_ks(f, s0, 1, full_tag);
+      mma_ks(f, 1, full_tag);
+    } else {
+      read_frags(f, s0, full_tag);
+      lds_store(nx, t1, k1, s1);
+      gload_a(t2, k2, s2);
+      gload_b(nx, t3, k3);
+      mma_tile(f, full_tag);
+    }
     asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     s0 = s1;
@@ -580,6 +623,8 @@ int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
     bool good = true;
     const void* fns[] = {(const void*)&srf_pw_x3v_kernel<0>, (const void*)&srf_pw_x3v_kernel<1>,
                          (const void*)&srf_pw_x3v_kernel<2>, (const void*)&srf_pw_x3v_kernel<3>,
+                         (const void*)&srf_pw_x3v_kernel<0, 0, 1>, (const void*)&srf_pw_x3v_kernel<1, 0, 1>,
+                         (const void*)&srf_pw_x3v_kernel<2, 0, 1>, (const void*)&srf_pw_x3v_kernel<3, 0, 1>,
                          (const void*)&srf_pw_x3v_kernel<2, 1>, (const void*)&srf_pw_x3v_kernel<2, 2>,
                          (const void*)&srf_pw_x3v_kernel<2, 3>, (const void*)&srf_pw_x3v_kernel<2, 4>,
                          (const void*)&srf_pw_x3v_kernel<2, 8>, (const void*)&srf_pw_x3v_kernel<2, 16>,
@@ -622,7 +667,10 @@ int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
     SRF_CHECK_LAUNCH("pw_conv_x3v_ablated", st);
     return SRF_OK;
   }
-#define V_LAUNCH(P) hipLaunchKernelGGL((srf_pw_x3v_kernel<P>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta)
+  // fragment-read order (see `step`): per k-sub-step for the GlobLN-prologue kernels, hoisted for the others; debug flag 2 swaps
+  const int ksv = ((pro == 1 || pro == 2) ? 1 : 0) ^ ((srf_debug_flags() & 2) ? 1 : 0);
+#define V_LAUNCH(P) do { if (ksv == 1) hipLaunchKernelGGL((srf_pw_x3v_kernel<P, 0, 1>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta); \
+    else hipLaunchKernelGGL((srf_pw_x3v_kernel<P>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta); } while (0)
   switch (pro) {
     case 0: V_LAUNCH(0); break;
     case 1: V_LAUNCH(1); break;
