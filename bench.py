@@ -47,8 +47,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)     # >= 50 timed, >= 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2_improved_u16", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--kernel-mode", type=int, default=0,
