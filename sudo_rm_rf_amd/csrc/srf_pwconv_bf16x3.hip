@@ -523,8 +523,9 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
       srf_pw_epilogue_half(a, acc0, strip, b, m0 + wm * 32, l0 + cur_half * 64 + wn * 32, lane, s, q);
     }
     if (a.out_sums) {
-      const double ds = srf_wave_sum((double)s), dq = srf_wave_sum((double)q);
-      if (lane == 0) {
+      // (DPP wave sums: VALU only; the __shfl_xor form is 24 ds_bpermute per tile on every wavefront's critical path)
+      const double ds = srf_dpp_wave_sum((double)s), dq = srf_dpp_wave_sum((double)q);
+      if (lane == 63) {
         double* dst = srf_stat_slot(a.out_sums, b, (long)v * 16 + wave + (cur_half > 0 ? 8 : 0));
         atomicAdd(dst, ds);
         atomicAdd(dst + 1, dq);

@@ -563,8 +563,9 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char
         }
     }
     if (a.out_sums) {
-      const double ds = srf_wave_sum((double)s), dq = srf_wave_sum((double)q);
-      if (lane == 0) {
+      // (DPP wave sums: VALU only; the __shfl_xor form is 24 ds_bpermute per tile on every wavefront's critical path)
+      const double ds = srf_dpp_wave_sum((double)s), dq = srf_dpp_wave_sum((double)q);
+      if (lane == 63) {
         double* dst = srf_stat_slot(a.out_sums, b, (long)v * 32 + wave + (quarter ? 8 * (cur.q + 1) : 0));
         atomicAdd(dst, ds);
         atomicAdd(dst + 1, dq);

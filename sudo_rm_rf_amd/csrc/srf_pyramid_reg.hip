@@ -406,8 +406,9 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     srf_pyr_store_chunks<CH>(pyr_strip + wave * (60 * (CH / 4 + 1)), outv, own, a.merged + (size_t)row * L, tile * a.own,
                              min(a.own, nchunks - tile * a.own), lane);
     if (a.out_sums) {
-      const double ds = srf_wave_sum((double)ms), dq = srf_wave_sum((double)mq);
-      if (lane == 0) {
+      // (DPP wave sums: VALU only; the __shfl_xor form is 24 ds_bpermute per tile on every wavefront's critical path)
+      const double ds = srf_dpp_wave_sum((double)ms), dq = srf_dpp_wave_sum((double)mq);
+      if (lane == 63) {
         double* dst = srf_stat_slot(a.out_sums, g, c * a.tiles + tile);
         atomicAdd(dst, ds);
         atomicAdd(dst + 1, dq);
