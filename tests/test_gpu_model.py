@@ -156,6 +156,36 @@ def test_arbitrary_lengths_and_dtypes(manifest):
         model(torch.zeros(2, 2, 100, device=DEV))        # wrong channel count
 
 
+def test_variable_length_inference_keeps_plans_and_memory_bounded():
+    """Real inference brings a new length with every call: the engine builds one plan per (batch, length),
+    does NOT run its split auto-tune for shapes it has not seen repeatedly, keeps at most _MAX_PLANS plans per device, and
+    the memory it holds stops growing once the LRU is full; an evicted shape that comes back still gives the same output."""
+    from oracle import weights
+    from oracle.schema import ModelConfig
+    from sudo_rm_rf_amd import engine as engine_mod
+    cfg = ModelConfig("improved", 128, 256, 4, 5, 21, 256, 2)
+    model = build(cfg, weights.make_state_dict(cfg, seed=9))
+    eng = model._engine()
+    g = torch.Generator().manual_seed(0)
+    lengths = [int(t) for t in torch.randint(24000, 40000, (30,), generator=g)]
+    first = {}
+    reserved = []
+    with torch.no_grad():
+        for i, T in enumerate(lengths):
+            wav = torch.randn(8, 1, T, generator=g).to(DEV)
+            out = model(wav)
+            assert out.shape == (8, 2, T) and torch.isfinite(out).all()
+            if i < 2:
+                first[T] = (wav, out.clone())
+            torch.cuda.synchronize()
+            reserved.append(torch.cuda.memory_reserved())
+            assert len([k for k in eng._plans if k[0] == torch.cuda.current_device()]) <= engine_mod._MAX_PLANS
+            assert not eng._split_choice, "the split auto-tune must not run for one-off shapes"
+        assert max(reserved[20:]) <= 1.25 * max(reserved[:12]) + (64 << 20), reserved
+        for T, (wav, want) in first.items():           # evicted long ago: rebuilt, same result
+            assert torch.equal(model(wav), want)
+
+
 def test_submodule_forwards(manifest):
     """UConvBlock / TAC / GlobLN called stand-alone (as pickled sub-modules may be) match the oracle."""
     cfg, sd, wav, _ = load_case(manifest, "tiny_groupcomm")
