@@ -205,7 +205,6 @@ __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int
 
 int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st);
 int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
-int srf_pw_x4w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);   // experiment: four wavefronts per block
 size_t srf_x3v_packed_bytes(int Cout, int Cin);
 bool srf_x3v_supported(int Cin, int Cout, int L);
 int srf_pw_small_launch(const PwArgs& a, hipStream_t st);
@@ -275,8 +274,7 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
   if (mfma_ok && mode == 0 && w_packed && srf_x3v_supported(Cin, Cout, L) && srf_aligned16(w_packed) &&
       (long)Bt * Cin * L * 4 < (1L << 31) && !(srf_debug_flags() & 4) &&
       (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus())
-    return (srf_debug_flags() & 2) ? srf_pw_x4w_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st)
-                                   : srf_pw_x3v_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
+    return srf_pw_x3v_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
   // An activation tensor beyond the 2 GB reach of the kernel's 32-bit buffer offsets (cfg 5's bottleneck: 16 x 4096 x 12800
   // floats = 3.4 GB) goes out as several launches over runs of whole examples: examples are independent, every per-example
   // pointer (statistics slots included) just moves along.

@@ -600,6 +600,11 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3v_kernel(PwArgs a, const char
 // 119 us for proj_1x1, whose two pieces per step spill ~100 registers.  With 64 + 64 accumulators + 32 fragment registers
 // the 256-register budget of two wavefronts per SIMD leaves no room for the k-loop's own pipeline, and the extra ~75 VALU
 // + ~80 SALU instructions per step eat what the overlap wins.  Code: git history, round 2.)
+// (Measured and removed again, round 2: the same kernel with FOUR wavefronts per block -- one per SIMD, wave tile 128 x 64,
+// 428-490 registers, 96 instead of 128 KB of LDS fragment reads per k-step, second sub-step's fragments read ahead of the
+// first MFMA.  Bit-identical at the first run and 20 % slower: res_conv 153 vs 127 us, proj_1x1 146 vs 120, mask 304 vs 262.
+// hipcc interleaves its ~250 other instructions between the step's 48 MFMAs, but with nothing else resident on the SIMD
+// every s_waitcnt and every barrier release is an MFMA bubble.  srf_pwconv_x4w.hip in the round's history.)
 // (Measured and removed again, round 2: launches with fewer tiles than CUs -- small batches -- dealt out entirely as quarter
 // tiles (rounds = 0: 100 instead of 25-50 busy CUs for a batch-1 GEMM).  Slower than the 128 x 128 kernels they replace:
 // cfg 1 batch 1 0.87 vs 0.79 ms per forward, cfg 2 at batch 4 2.14 vs 1.75 ms -- a quarter tile streams the whole 256-row
