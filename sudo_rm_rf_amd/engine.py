@@ -56,9 +56,20 @@ class Plan:
         self.frames = lib.srf_plan_frames(handle)
         self.padded_length = lib.srf_plan_padded_length(handle)
         self.num_launches = lib.srf_plan_num_launches(handle)
-        self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=device)
-        if self.workspace.data_ptr() % 256:
-            raise _lib.SrfError("torch returned a workspace that is not 256-byte aligned")
+        self._workspace = None          # allocated at first use: a plan that is only asked for its geometry costs no HBM
+
+    @property
+    def workspace(self):
+        if self._workspace is None:
+            self._workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=self.device)
+            if self._workspace.data_ptr() % 256:
+                raise _lib.SrfError("torch returned a workspace that is not 256-byte aligned")
+        return self._workspace
+
+    @property
+    def held_bytes(self):
+        """Device memory this plan currently holds (0 until its first forward)."""
+        return self.workspace_bytes if self._workspace is not None else 0
 
     def __del__(self):
         try:
@@ -203,10 +214,11 @@ class ModelEngine:
                 lk = self._run_locks[idx] = threading.RLock()
         return lk
 
-    def plan_for(self, batch, T, device, lane=0):
+    def plan_for(self, batch, T, device, lane=0, keep=()):
         """lane: plans of different stream lanes never share a workspace, even for equal sub-batch sizes.  Lane 0 (work
         launched on the caller's current stream) is additionally keyed by that stream: callers on different streams
-        get different workspaces."""
+        get different workspaces.  keep: cache keys (Plan.cache_key) of other plans the CURRENT forward is using -- the
+        sibling lanes of a split forward -- which the eviction this call may trigger must leave alone."""
         if lane == 0:
             lane = (0, torch.cuda.current_stream(device).cuda_stream)
         key = (device.index if device.index is not None else torch.cuda.current_device(), batch, T, lane)
@@ -214,24 +226,29 @@ class ModelEngine:
             plan = self._plans.get(key)
             if plan is None:
                 plan = Plan(self.cfg_tuple, batch, T, device)
+                plan.cache_key = key
                 self._plans[key] = plan
-                self._evict(key[0], keep=key)
             else:
                 self._plans.move_to_end(key)
+            self._evict(key[0], keep={key, *keep}, incoming=plan.workspace_bytes - plan.held_bytes)
         return plan
 
-    def _evict(self, dev_index, keep):
+    def _evict(self, dev_index, keep, incoming=0):
         """LRU per device: at most _MAX_PLANS plans and _MAX_WORKSPACE_BYTES of workspaces (the reference allocates and
         frees its activations on every call; a cached workspace is the same memory held a little longer).  A dropped
-        workspace goes back to torch's caching allocator, whose stream-ordered reuse keeps in-flight kernels safe."""
+        workspace goes back to torch's caching allocator, whose stream-ordered reuse keeps in-flight kernels safe.
+        `keep`: keys that stay whatever the caps say (every plan of the forward in flight: for big shapes -- cfg 5: 11.8 GB
+        whole, 2 x 6 GB halves -- the lanes of a split would otherwise evict each other on every call); `incoming`: bytes
+        the plan being handed out is about to allocate."""
         mine = [k for k in self._plans if k[0] == dev_index]
-        total = sum(self._plans[k].workspace_bytes for k in mine)
+        total = incoming + sum(self._plans[k].held_bytes for k in mine)
         for k in mine:                                   # oldest first
-            if len(mine) <= _MAX_PLANS and total <= _MAX_WORKSPACE_BYTES:
+            over_count = len(mine) > _MAX_PLANS
+            if not over_count and total <= _MAX_WORKSPACE_BYTES:
                 break
-            if k == keep:
-                continue
-            total -= self._plans[k].workspace_bytes
+            if k in keep or (not over_count and self._plans[k].held_bytes == 0):
+                continue                                 # (a plan without a workspace frees nothing)
+            total -= self._plans[k].held_bytes
             del self._plans[k]
             mine = [m for m in mine if m != k]
 
@@ -318,6 +335,14 @@ class ModelEngine:
         for p in params:
             if p.device != mixture.device or p.dtype != torch.float32 or not p.is_contiguous():
                 raise _lib.SrfError("all parameters must be contiguous float32 on %s" % mixture.device)
+        # same shape contract as run(): srf_separate reads batch * T floats, so a [B, 2, T] tensor handed to a 1-channel
+        # model would silently be processed as its first B * T samples
+        channels = int(getattr(module, "in_audio_channels", 1) or 1)
+        if mixture.dim() != 3:
+            raise RuntimeError("expected a mixture of shape [batch, %d, time], got %s" % (channels, tuple(mixture.shape)))
+        if mixture.shape[1] != channels or channels != 1:
+            raise _lib.SrfError("separate() takes single-channel mixtures [batch, 1, time] (the README recipe); got %s for a "
+                                "model with %d input channel(s)" % (tuple(mixture.shape), channels))
         x = mixture.detach().to(torch.float32).contiguous()
         batch, _, T = x.shape
         if batch == 0 or T == 0:
@@ -409,12 +434,14 @@ class ModelEngine:
         streams = self._side_streams.setdefault(dev.index, [])
         while len(streams) < len(parts):
             streams.append(torch.cuda.Stream(dev))
-        lo = 0
+        lo, held = 0, []
         for lane, n in enumerate(parts):
             st = streams[lane]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                self.plan_for(n, x.shape[-1], dev, lane=lane + 1).forward(table, x[lo:lo + n], out[lo:lo + n])
+                plan = self.plan_for(n, x.shape[-1], dev, lane=lane + 1, keep=held)
+                held.append(plan.cache_key)
+                plan.forward(table, x[lo:lo + n], out[lo:lo + n])
             x.record_stream(st)
             out.record_stream(st)
             lo += n

@@ -369,3 +369,31 @@ def set_kernel_mode(mode):
     """0 = fast paths, split-bf16x3 MFMA GEMMs (default); 1 = generic kernels only; 2 = fast paths with
     exact-fp32 MFMA GEMMs."""
     _lib.load().srf_set_kernel_mode(int(mode))
+
+
+class kernel_trace:
+    """Context manager over the in-library profiler (srf_profile_begin / _end / _get): ``with ops.kernel_trace(dev) as tr``
+    records one (kernel family name, milliseconds) pair per launch this library makes on torch's current stream of `dev`
+    inside the block; afterwards ``tr.launches`` holds them in launch order and ``tr.names`` the set of family names.
+    Used by bench.py's per-kernel pass and by the tests that must prove WHICH kernel a shape was dispatched to."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.launches, self.names = [], set()
+
+    def __enter__(self):
+        self._stream = _lib.current_stream(self.device)
+        _lib.check(_lib.load().srf_profile_begin(self._stream), "srf_profile_begin")
+        return self
+
+    def __exit__(self, *exc):
+        lib = _lib.load()
+        cnt = C.c_int(0)
+        _lib.check(lib.srf_profile_end(self._stream, C.byref(cnt)), "srf_profile_end")
+        name, ms = C.c_char_p(), C.c_float()
+        for i in range(cnt.value):
+            lib.srf_profile_get(i, C.byref(name), C.byref(ms))
+            if not name.value.startswith(b"("):          # "(gap)": host-side idle before a forward, not a kernel
+                self.launches.append((name.value.decode(), ms.value))
+        self.names = {n for n, _ in self.launches}
+        return False

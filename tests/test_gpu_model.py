@@ -103,26 +103,67 @@ def test_unfused_pyramid_agrees(manifest, name):
     assert np.abs(out - gold["out"]).max() <= TOL
 
 
-@pytest.mark.parametrize("case", ["cfg2_improved_u16", "cfg3_groupcomm_u8"])
-def test_batch32_examples_are_independent_at_full_size(manifest, case):
-    """BASELINE cfgs 2 and 3 at their full size (batch 32): every example must reproduce the golden output of
-    the same waveform run on its own -- nothing on the path mixes examples -- on the single-stream
-    forward and on the auto-tuned batch split (different kernels get dispatched at different batch sizes)."""
+# (case, bench batch, kernel families the single-stream forward MUST have been dispatched to)
+_X3V = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_conv_x3v<3>"}
+_BENCH_BATCH = [("cfg2_improved_u16", 32, _X3V), ("cfg3_groupcomm_u8", 32, {"pw_conv_x3v<1>", "pw_conv_x3v<3>", "pw_conv_small"}),
+                ("cfg4_improved_u36_n2048", 32, _X3V), ("cfg5_improved_u36_n4096", 16, _X3V)]
+
+
+@pytest.mark.parametrize("case,batch,families", _BENCH_BATCH, ids=[c for c, _, _ in _BENCH_BATCH])
+def test_bench_batch_examples_match_reference_golden(manifest, case, batch, families):
+    """Every BASELINE configuration AT THE BATCH bench.py TIMES IT (cfg 2 / 3 / 4: 32, cfg 5: 16), through the kernels the
+    bench times: every example must reproduce the reference's golden output of the same waveform run on its own -- nothing
+    on the path mixes examples -- within the north-star tolerance, on the single-stream forward and on
+    every batch split the auto-tuner may pick.  The batch-1/2 goldens alone fall below the `tiles >= #CUs` gate of
+    srf_pw_conv_packed and never reach the 256 x 128 GEMM, so the test also proves -- through the
+    in-library profiler -- that the single-stream forward really ran those kernel families (a future dispatch change
+    cannot silently re-route it)."""
+    from sudo_rm_rf_amd import ops
     cfg, sd, wav, gold = load_case(manifest, case)
     model = build(cfg, sd)
     nb = wav.shape[0]
-    reps = np.concatenate([wav] * (32 // nb), axis=0)    # 32 examples: golden inputs interleaved
-    assert reps.shape[0] == 32
+    reps = np.concatenate([wav] * (batch // nb), axis=0)    # golden inputs interleaved
+    assert reps.shape[0] == batch
     x = torch.from_numpy(reps).to(DEV)
     eng = model._engine()
-    # the single-stream forward AND, where the engine uses it (Improved models), whatever batch split the auto-tuner
-    # picks; GroupComm models stay on one stream by default (engine.ModelEngine.multi_stream)
-    for multi in ((False, True) if eng.multi_stream else (False,)):
-        eng.multi_stream = multi
-        with torch.no_grad():
-            out = model(x).cpu().numpy()
-        for i in range(32):
-            assert np.abs(out[i] - gold["out"][i % nb]).max() <= TOL, (multi, i)
+    assert eng.multi_stream
+
+    def check(out, what):
+        out = out.cpu().numpy()
+        worst = max(float(np.abs(out[i] - gold["out"][i % nb]).max()) for i in range(batch))
+        print(f"{case} batch {batch} ({what}): max abs err vs reference golden = {worst:.3e}")
+        assert worst <= TOL, (what, worst)
+
+    try:
+        eng.multi_stream = False
+        with torch.no_grad(), ops.kernel_trace(DEV) as tr:
+            out = model(x)
+        check(out, "single stream")
+        missing = families - tr.names
+        assert not missing, "single-stream forward did not run %s (ran %s)" % (sorted(missing), sorted(tr.names))
+        count = {n: sum(1 for k, _ in tr.launches if k == n) for n in tr.names}
+        U = cfg.num_blocks
+        if cfg.variant == "improved":     # bottleneck, U x proj_1x1, U x res_conv, mask -- ALL on the 256 x 128 kernel
+            assert (count["pw_conv_x3v<1>"], count["pw_conv_x3v<0>"], count["pw_conv_x3v<2>"], count["pw_conv_x3v<3>"]) == \
+                (1, U, U, 1), count
+        else:                             # GroupComm: bottleneck + mask on it, the per-group convs on the thin-shape kernel
+            assert (count["pw_conv_x3v<1>"], count["pw_conv_x3v<3>"], count["pw_conv_small"]) == (1, 1, 2 * U), count
+        # (the only GEMM left on the 128 x 128 kernels is the decoder's 42-row frame GEMM)
+        assert sum(v for k, v in count.items() if k.startswith("pw_conv_bf16x3") or k == "pw_conv_mfma") == 1, count
+        eng.multi_stream = True
+        for parts in eng._split_candidates(batch)[1:]:        # the explicit splits: halves and 5 : 3
+            out = torch.empty_like(out)
+            with torch.no_grad():
+                params = [p.detach() for p in model.state_dict(keep_vars=True).values()]
+                with torch.cuda.device(x.device), eng._run_lock(x.device):
+                    eng._forward_split(parts, x, out, eng._param_table(params, x.device))
+            check(out, "split %s" % (parts,))
+        with torch.no_grad():                                  # and the public path with whatever the auto-tuner picks
+            for _ in range(4):
+                out = model(x)
+        check(out, "auto-tuned %s" % (eng._split_choice.get((x.device.index, batch, x.shape[-1])),))
+    finally:
+        eng.multi_stream = True
 
 
 def test_run_to_run_determinism(manifest):
@@ -228,6 +269,9 @@ def test_separate_pipeline_matches_reference_recipe(variant, K):
         unfused = ops.wav_denormalize(model(nrm), stats, nrm if variant == "groupcomm" else None)
     assert (got - unfused).abs().max().item() <= 2e-5
     assert torch.equal(pipeline.separate(model, mix.to(DEV).unsqueeze(1)), got)          # [batch, 1, time] form
+    for bad in (torch.zeros(2, 2, 100, device=DEV), torch.zeros(2, 100, device=DEV)):    # the engine entry checks the shape itself
+        with pytest.raises(RuntimeError):
+            model._engine().separate(model, bad, False)
 
 
 @pytest.mark.gpu
