@@ -221,6 +221,31 @@ def cpu_baseline_subprocess(args):
         return {"value": None, "kind": "port", "error": "cpu baseline exceeded %.0f s" % args.cpu_timeout}
 
 
+def train_loop(step, flat_grad, steps, warmup, rank, world, dev):
+    """The timed region of a training bench, model-agnostic (tests/test_distributed_cpu.py drives it over gloo with a stub
+    step): one set-up step, `warmup` untimed steps, barrier, EXACTLY `steps` timed steps, device sync, max over ranks; then
+    the gradient all-reduce timed on its own (bytes, ms, bus GB/s).  step() -> loss tensor; flat_grad() -> the flat gradient
+    buffer of the last step (what the all-reduce moves).  Returns a dict on every rank."""
+    import torch
+    from sudo_rm_rf_amd import distributed as D
+    l = step()                # set-up, not a step: plan, saved-activation and scratch buffers, optimizer state
+    for _ in range(warmup):
+        l = step()
+    D.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        l = step()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    mine = time.perf_counter() - t0
+    dt = D.max_over_ranks(mine, dev)
+    per_rank = D.gather_over_ranks(1e3 * mine / steps, dev)
+    flat = flat_grad()
+    ar = D.time_allreduce(flat, repeats=10, device=dev) if flat is not None else None
+    return {"seconds": dt, "ms_per_step": 1e3 * dt / steps, "per_rank_ms_per_step": per_rank, "loss": float(l.detach()),
+            "allreduce": ar}
+
+
 def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
     """SURVEY.md §8 cfg 4 style measurement: the reference runner's loop body on `batch` examples per GPU, gradients
     all-reduced over RCCL when world > 1 (replaces DataParallel), weak scaling.  One JSON line on rank 0."""
@@ -239,6 +264,7 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
     clean = torch.randn(batch, kw["num_sources"], T, generator=g).to(dev)
     mix = clean.sum(1, keepdim=True)
     mix = (mix - mix.mean(-1, keepdim=True)) / (mix.std(-1, keepdim=True) + 1e-9)
+    in_place = []
 
     def step():
         opt.zero_grad()
@@ -247,36 +273,32 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
             rec = mixture_consistency.apply(rec, mix)
         l = torch.clamp(loss_fn(rec, clean), min=-30., max=+30.)
         l.backward()
-        D.allreduce_gradients(model.parameters())
+        flat = D.allreduce_gradients(model.parameters())      # in place on the backward's flat buffer: one collective
+        in_place.append(flat is not None and flat.data_ptr() == model._engine().last_flat_grad.data_ptr())
         if not fused:
             torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
         opt.step()
         return l
 
-    l = step()                # set-up, not a step: plan, saved-activation and scratch buffers, optimizer state
-    for _ in range(args.warmup):
-        l = step()
-    D.barrier(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        l = step()
-    torch.cuda.synchronize(dev)
-    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    r = train_loop(step, lambda: model._engine().last_flat_grad, args.steps, args.warmup, rank, world, dev)
     if rank == 0:
         plan = model._engine().last_plan
         saved, scratch = plan.train_sizes()
         print(json.dumps({
             "metric": "trained-seconds/sec (training step: forward, PIT-SI-SDR, backward, all-reduce, clip, Adam), "
                       + args.workload,
-            "value": world * batch * (T / fs) * args.steps / dt, "unit": "trained-seconds/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "value": world * batch * (T / fs) * args.steps / r["seconds"], "unit": "trained-seconds/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (forward GEMMs exact fp32 MFMA; backward GEMMs split-bf16 x3, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%s training step, batch %d per GPU, T=%d" % (args.workload, batch, T),
                        "global_batch": batch * world, "parallelism": "data-parallel x%d, one gradient all-reduce" % world},
             "optimizer": "fused HIP clip_grad_norm + Adam" if fused else "torch clip_grad_norm_ + torch.optim.Adam",
-            "loss": float(l.detach()), "saved_activations_GB": saved / 2 ** 30, "scratch_GB": scratch / 2 ** 30,
+            "per_rank_ms_per_step": r["per_rank_ms_per_step"],
+            # the step's one collective, timed on its own after the timed region (bus_GBps = 2 (N-1)/N bytes / time)
+            "gradient_allreduce": dict(r["allreduce"], in_place_on_backward_buffer=bool(in_place) and all(in_place)),
+            "loss": r["loss"], "saved_activations_GB": saved / 2 ** 30, "scratch_GB": scratch / 2 ** 30,
             "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}))
     if world > 1:
         dist.barrier()

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 10
+#define SRF_ABI_VERSION 11
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -93,17 +93,6 @@ const char* srf_last_error(void);
  *   2 = fast paths, but 1x1 convs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32). */
 void srf_set_kernel_mode(int mode);
 int srf_get_kernel_mode(void);
-/* Diagnostics / A-B switches between kernel variants that compute the same result (default 0 = the shipped paths):
- *   8        pre-packed weights for the split-bf16 GEMM            16        per-level depthwise + merge kernels instead
- *   32 / 64  LDS pyramid kernels instead of the register ones                of the fused pyramid (inference and training)
- *   128      non-persistent pyramid pass 1                         256       no half-tile tail in the persistent GEMM
- *   1024     TAC forward with one time step per lane               2048      one-tile-per-block GEMM everywhere
- *   bits 12-13, 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating)
- *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
- *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)
- *   1<<29 / 1<<30  chunked depthwise-backward / scalar GlobLN-backward kernels and no backward fusion */
-void srf_set_debug_flags(int flags);
-
 /* In-library profiler (bench.py): between begin/end every kernel launched through this library is
  * followed by a HIP event on the caller's stream; end() synchronises the stream and get(i) returns
  * the kernel family name and the elapsed ms between the previous event and launch i's event
@@ -111,6 +100,24 @@ void srf_set_debug_flags(int flags);
 int srf_profile_begin(void* stream);
 int srf_profile_end(void* stream, int* count);
 int srf_profile_get(int i, const char** name, float* ms);
+
+/* ---- SRF_DIAGNOSTICS -----------------------------------------------------------------------------------------------------
+ * NOT part of the drop-in surface: process-wide switches between kernel variants for A/B measurements and bisection
+ * (tools/, bench.py --debug-flags, a handful of tests).  They act on every thread's subsequent launches; a caller that does
+ * not define SRF_DIAGNOSTICS before including this header does not see them.  Default 0 = the shipped paths.
+ *   2        swap the GEMM's fragment-read order                   4         without the 256 x 128 GEMM (128 x 128 kernels)
+ *   8        WITHOUT pre-packed weights (srf_forward packs by default)
+ *   16       per-level depthwise + merge kernels instead of the fused pyramid (inference and training)
+ *   32 / 64  LDS pyramid kernels instead of the register ones      128       non-persistent pyramid pass 1
+ *   256      leftover GEMM tiles as whole tiles (no quarter tiles) 512       quarter tiles last
+ *   1024     TAC forward with one time step per lane               2048      one-tile-per-block GEMM everywhere
+ *   bits 12-13, 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating)
+ *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
+ *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)
+ *   1<<29 / 1<<30  chunked depthwise-backward / scalar GlobLN-backward kernels and no backward fusion */
+#ifdef SRF_DIAGNOSTICS
+void srf_set_debug_flags(int flags);
+#endif
 
 /* ---- whole-model path ---------------------------------------------------------------------- */
 int srf_plan_create(const srf_config* cfg, int batch, int T, srf_plan** out);
@@ -203,7 +210,8 @@ int srf_pyramid(const float* y1, float* merged, const srf_norm* in_norm, const f
 
 /* Transposed conv synthesis + crop: out[b,o,t] = sum_{ci,l,k: h*l+k-h=t} v[b,ci,l]*w[ci,o,k], t<T.
  * v: [Bt,Ci,L], w: [Ci,Co,K] (ConvTranspose1d layout), out: [Bt,Co,T].
- * scratch: device buffer of srf_decoder_scratch_floats() floats. */
+ * scratch: device buffer of srf_decoder_scratch_floats() floats, 16-byte aligned (the decoder zero-fills a part of it with
+ * 16-byte stores; an unaligned scratch is rejected with SRF_EINVAL). */
 size_t srf_decoder_scratch_floats(int Bt, int Ci, int Co, int K, int L);
 int srf_decoder(const float* v, const float* w, float* out, int Bt, int Ci, int Co, int K, int L, int T,
                 float* scratch, void* stream);
@@ -370,30 +378,45 @@ int srf_clip_adam_step(const void* tensors, const void* chunks, int n_chunks, do
  * 0, then the sources; one crop start per example, shared by its files (:183-186,:201); float32 values exactly as
  * scipy.io.wavfile.read + torch.tensor(dtype=float32) give them; zero pad to time_samples (:157-166) -- straight into
  * CALLER-OWNED buffers (pinned host memory if the copy to the device is to be asynchronous):
- *   wave [batch][n_streams][time_samples] float32, len [batch] int32 (valid samples), stat [batch][2] float32 = {mean,
- *   unbiased std} of the mixture over the range the reference normalises it on (the crop when it crops, else the whole
- *   file: it truncates after normalising, :183-191).
+ *   wave [batch][n_streams][time_samples] float32, len [batch][n_streams] int32 (valid samples of every stream: a source
+ *   file may be shorter than its mixture), stat [batch][2] float32 = {mean, unbiased std} of the mixture over the range the
+ *   reference normalises it on (the crop when it crops, else the whole file: it truncates after normalising, :183-191;
+ *   only computed when the feeder was created with normalize != 0).
  * paths: n_items * n_streams file names, item-major.  augment: random crop start when a file is longer than time_samples
  * (splitmix64 of seed, epoch and item: reproducible, unlike the reference's time-seeded numpy generator).  shuffle /
  * drop_last: the DataLoader's (get_generator, :219-224).
  * srf_feeder_submit queues the next batch of the epoch (returns 1, queues nothing, when the epoch is exhausted);
  * srf_feeder_wait blocks until the OLDEST submitted batch is complete and hands its buffers back.  Any number of batches may
- * be in flight.  srf_wav_info / srf_wav_read: the reader on its own (RIFF/WAVE mono, PCM 8/16/24/32, IEEE float 32/64). */
+ * be in flight.  srf_wav_info / srf_wav_read: the reader on its own (RIFF/WAVE mono, PCM 8/16/24/32, IEEE float 32/64).
+ * srf_feeder_create_sharded: the rank-aware form for one process per GPU (the reference feeds its DataParallel replicas
+ * from ONE DataLoader and scatters each batch, wham.py:219-226 + run_improved_sudormrf.py:118): every rank builds the same
+ * epoch order from (seed, epoch); a GLOBAL batch is batch * world consecutive items of it and this feeder delivers items
+ * [rank * batch, (rank + 1) * batch) of every global batch -- disjoint across ranks, their concatenation in rank order is the
+ * single-process batch of size batch * world, an epoch covers every item once over all ranks.  world > 1 requires drop_last.
+ * normalize = 0 skips the mixture statistics (and the second read of files longer than time_samples they need).
+ * srf_feeder_create = the same with normalize 1, rank 0, world 1.  srf_feeder_epoch_items: the items this rank delivers in
+ * the current epoch, in order.  srf_feeder_read_example: one example synchronously in the calling thread (Dataset[i]). */
 typedef struct srf_feeder srf_feeder;
 int srf_wav_info(const char* path, int* rate, int* channels, int* bits, long* frames);
 int srf_wav_read(const char* path, long start, long n, float* dst, long* frames);
 int srf_feeder_create(const char* const* paths, int n_items, int n_streams, int time_samples, int batch, int n_threads,
                       int augment, int shuffle, int drop_last, unsigned long long seed, srf_feeder** out);
+int srf_feeder_create_sharded(const char* const* paths, int n_items, int n_streams, int time_samples, int batch,
+                              int n_threads, int augment, int shuffle, int drop_last, unsigned long long seed, int normalize,
+                              int rank, int world, srf_feeder** out);
 void srf_feeder_destroy(srf_feeder* f);
+long srf_feeder_epoch_items(srf_feeder* f, int* items, long capacity);
+int srf_feeder_read_example(const char* const* paths, int n_streams, int time_samples, long start, int augment, int normalize,
+                            float* wave, int* len, float* stat);
 long srf_feeder_batches_per_epoch(const srf_feeder* f);
 long srf_feeder_item_frames(const srf_feeder* f, int item);
 int srf_feeder_start_epoch(srf_feeder* f, int epoch);
 int srf_feeder_submit(srf_feeder* f, float* wave, int* len, float* stat);
 int srf_feeder_wait(srf_feeder* f, float** wave, int** len, float** stat, int* n_valid);
 /* The Dataset's normalisation on a whole batch, on the device (wham.py:189-217): raw [B][n_streams][T] as delivered by the
- * feeder -> mix [B][T], src [B][n_streams-1][T].  normalize = 0: copy; 1: every stream (x - mean)/(std + eps) over its valid
- * samples (the mixture with `stat`), zero pad, then (x - mean_T)/(mix_std + eps) with the population std of the padded
- * mixture. */
+ * feeder (len [B][n_streams]) -> mix [B][T], src [B][n_streams-1][T].  normalize = 0: copy; 1: every stream
+ * (x - mean)/(std + eps) over ITS OWN valid samples (the mixture with `stat`), zero pad, then (x - mean_T)/(mix_std + eps)
+ * with the population std of the padded mixture. */
 int srf_feeder_normalize(const float* raw, const int* len, const float* stat, int B, int n_streams, int T, int normalize,
                          float eps, float* mix, float* src, void* stream);
 

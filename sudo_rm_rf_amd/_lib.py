@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # SRF_LIB: an alternative build of the same library (same-box A/B of kernel variants, tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SRF_LIB") or os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 STAT_BUCKETS = 64
 
 SRF_OK = 0
@@ -108,7 +108,11 @@ _PROTOS = {
     "srf_wav_info": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_l)]),
     "srf_wav_read": (_i, [C.c_char_p, _l, _l, _vp, C.POINTER(_l)]),
     "srf_feeder_create": (_i, [C.POINTER(C.c_char_p), _i, _i, _i, _i, _i, _i, _i, _i, C.c_ulonglong, C.POINTER(_vp)]),
+    "srf_feeder_create_sharded": (_i, [C.POINTER(C.c_char_p), _i, _i, _i, _i, _i, _i, _i, _i, C.c_ulonglong, _i, _i, _i,
+                                       C.POINTER(_vp)]),
     "srf_feeder_destroy": (None, [_vp]),
+    "srf_feeder_epoch_items": (_l, [_vp, _vp, _l]),
+    "srf_feeder_read_example": (_i, [C.POINTER(C.c_char_p), _i, _i, _l, _i, _i, _vp, _vp, _vp]),
     "srf_feeder_batches_per_epoch": (_l, [_vp]),
     "srf_feeder_item_frames": (_l, [_vp, _i]),
     "srf_feeder_start_epoch": (_i, [_vp, _i]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#define SRF_DIAGNOSTICS 1   // the library itself sees (and defines) the diagnostics switches
 #include "../../include/sudormrf_hip.h"
 
 #define SRF_WAVE 64

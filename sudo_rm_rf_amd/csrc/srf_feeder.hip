@@ -172,18 +172,57 @@ static inline uint64_t splitmix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+// One file of one example: the crop [start, start + T) (wham.py:178-186,196), zero padded when the file is shorter (:157-166),
+// its valid length, and -- for the mixture (stream 0) of a normalising Dataset -- {mean, unbiased std} over what the
+// reference normalises: the crop when it crops (augment and a longer file), else the WHOLE file: it truncates to T only
+// after normalising (wham.py:183-191).  Shared by the worker threads and by srf_feeder_read_example.
+static bool read_stream(const char* path, int stream, long start, int T, int augment, int normalize, float* dst, int* len,
+                        float* stat, std::string& err) {
+  long fr = 0;
+  bool ok = wav_read_range(path, start, T, dst, &fr, err);
+  if (!ok) {
+    memset(dst, 0, sizeof(float) * (size_t)T);
+    *len = 0;
+    return false;
+  }
+  long got = fr - start;
+  if (got > T) got = T;
+  if (got < 0) got = 0;
+  if (got < T) memset(dst + got, 0, sizeof(float) * (size_t)(T - got));
+  *len = (int)got;
+  if (stream != 0 || !normalize) return true;     // (no statistics pass, and no second read of a long file, when nothing uses them)
+  const bool whole = !(augment && fr > T) && fr > T;
+  std::vector<float> rest;
+  const float* p = dst;
+  long n = got;
+  if (whole) {
+    rest.resize((size_t)fr);
+    ok = wav_read_range(path, 0, fr, rest.data(), nullptr, err);
+    p = rest.data();
+    n = fr;
+  }
+  double a = 0.0, q = 0.0;
+  for (long i = 0; i < n; ++i) a += p[i];
+  const double mean = n > 0 ? a / n : 0.0;
+  for (long i = 0; i < n; ++i) q += (p[i] - mean) * (p[i] - mean);
+  stat[0] = (float)mean;
+  stat[1] = n > 1 ? (float)sqrt(q / (n - 1)) : NAN;
+  return ok;
+}
+
 struct srf_feeder {
   std::vector<std::string> paths;   // [item][stream]
   std::vector<long> frames;         // [item] length of the mixture file (stream 0)
-  int n_items = 0, n_streams = 0, T = 0, batch = 0, augment = 0, shuffle = 0, drop_last = 1;
+  int n_items = 0, n_streams = 0, T = 0, batch = 0, augment = 0, shuffle = 0, drop_last = 1, normalize = 1;
+  int rank = 0, world = 1;          // this feeder hands out shard `rank` of every GLOBAL batch of batch * world items
   uint64_t seed = 0;
   int epoch = 0;
-  std::vector<int> order;           // item order of the current epoch
-  long cursor = 0;                  // next item of `order` to hand out
+  std::vector<int> order;           // item order of the current epoch (identical on every rank: seed and epoch only)
+  long cursor = 0;                  // first item of `order` of the next GLOBAL batch
 
   struct Slot {
     float* wave;
-    int* len;
+    int* len;      // [batch][n_streams]: valid samples of every stream (a source file may be shorter than its mixture)
     float* stat;   // [batch][2]: {mean, unbiased std} of the mixture over the range the reference normalises it on
     int n_valid;
     std::atomic<int> pending{0};
@@ -211,41 +250,10 @@ struct srf_feeder {
         j = jobs.front();
         jobs.pop_front();
       }
-      float* dst = j.slot->wave + ((size_t)j.b * n_streams + j.stream) * T;
       std::string err;
-      long fr = 0;
-      // wham.py:178-186,196: the crop [start, start + T) of every file of the example; shorter files are zero padded (:157-166)
-      bool ok = wav_read_range(paths[(size_t)j.item * n_streams + j.stream].c_str(), j.start, T, dst, &fr, err);
-      long got = 0;
-      if (ok) {
-        got = fr - j.start;
-        if (got > T) got = T;
-        if (got < 0) got = 0;
-        if (got < T) memset(dst + got, 0, sizeof(float) * (size_t)(T - got));
-        if (j.stream == 0) {
-          j.slot->len[j.b] = (int)got;
-          // Mixture statistics over what the reference normalises: the crop when it crops (augment and a longer file), else
-          // the WHOLE file -- it truncates to T only after normalising (wham.py:183-191).
-          const bool whole = !(augment && fr > T) && fr > T;
-          std::vector<float> rest;
-          const float* p = dst;
-          long n = got;
-          if (whole) {
-            rest.resize((size_t)fr);
-            ok = wav_read_range(paths[(size_t)j.item * n_streams].c_str(), 0, fr, rest.data(), nullptr, err);
-            p = rest.data();
-            n = fr;
-          }
-          double a = 0.0, q = 0.0;
-          for (long i = 0; i < n; ++i) a += p[i];
-          const double mean = n > 0 ? a / n : 0.0;
-          for (long i = 0; i < n; ++i) q += (p[i] - mean) * (p[i] - mean);
-          j.slot->stat[2 * j.b] = (float)mean;
-          j.slot->stat[2 * j.b + 1] = n > 1 ? (float)sqrt(q / (n - 1)) : NAN;
-        }
-      } else {
-        memset(dst, 0, sizeof(float) * (size_t)T);
-      }
+      const bool ok = read_stream(paths[(size_t)j.item * n_streams + j.stream].c_str(), j.stream, j.start, T, augment, normalize,
+                                  j.slot->wave + ((size_t)j.b * n_streams + j.stream) * T,
+                                  j.slot->len + (size_t)j.b * n_streams + j.stream, j.slot->stat + 2 * (size_t)j.b, err);
       {
         std::lock_guard<std::mutex> lk(mu);
         if (!ok && j.slot->err.empty()) j.slot->err = err;
@@ -258,10 +266,28 @@ struct srf_feeder {
 extern "C" int srf_feeder_create(const char* const* paths, int n_items, int n_streams, int time_samples, int batch,
                                  int n_threads, int augment, int shuffle, int drop_last, unsigned long long seed,
                                  srf_feeder** out) {
+  return srf_feeder_create_sharded(paths, n_items, n_streams, time_samples, batch, n_threads, augment, shuffle, drop_last, seed,
+                                   /*normalize=*/1, /*rank=*/0, /*world=*/1, out);
+}
+
+// Rank-aware form (one process per GPU; the reference feeds all its DataParallel replicas from ONE DataLoader,
+// wham.py:219-226, which then scatters every batch): all ranks build the same epoch order from (seed, epoch), a GLOBAL batch
+// is `batch * world` consecutive items of it, and this feeder delivers items [rank * batch, (rank + 1) * batch) of every
+// global batch -- so the ranks' batches of a step are disjoint, their concatenation in rank order IS the single-process
+// batch of size batch * world, and an epoch covers every item exactly once over all ranks.  world > 1 needs drop_last
+// (every rank must see the same number of steps, or the gradient all-reduce deadlocks).
+extern "C" int srf_feeder_create_sharded(const char* const* paths, int n_items, int n_streams, int time_samples, int batch,
+                                         int n_threads, int augment, int shuffle, int drop_last, unsigned long long seed,
+                                         int normalize, int rank, int world, srf_feeder** out) {
   SRF_CHECK_ARG(paths && out && n_items > 0 && n_streams > 0 && time_samples > 0 && batch > 0 && n_threads > 0,
                 "srf_feeder_create: bad arguments");
+  SRF_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "srf_feeder_create: rank %d outside world %d", rank, world);
+  SRF_CHECK_ARG(world == 1 || drop_last, "srf_feeder_create: a sharded feeder (world %d) needs drop_last", world);
   *out = nullptr;
   srf_feeder* f = new srf_feeder();
+  f->normalize = normalize;
+  f->rank = rank;
+  f->world = world;
   f->n_items = n_items;
   f->n_streams = n_streams;
   f->T = time_samples;
@@ -310,7 +336,28 @@ extern "C" void srf_feeder_destroy(srf_feeder* f) {
 
 extern "C" long srf_feeder_batches_per_epoch(const srf_feeder* f) {
   if (!f) return 0;
-  return f->drop_last ? f->n_items / f->batch : (f->n_items + f->batch - 1) / f->batch;
+  const long g = (long)f->batch * f->world;
+  return f->drop_last ? f->n_items / g : (f->n_items + g - 1) / g;
+}
+
+// The items this rank delivers in the CURRENT epoch, in delivery order (after srf_feeder_start_epoch): fills at most
+// `capacity` entries, returns the count.  For bookkeeping and for the tests of the sharding.
+extern "C" long srf_feeder_epoch_items(srf_feeder* f, int* items, long capacity) {
+  if (!f) return 0;
+  std::lock_guard<std::mutex> lk(f->mu);
+  const long g = (long)f->batch * f->world;
+  long n = 0;
+  for (long base = 0; base < f->n_items; base += g) {
+    const long left = f->n_items - base;
+    if (f->drop_last && left < g) break;
+    for (long b = 0; b < f->batch; ++b) {
+      const long pos = base + (long)f->rank * f->batch + b;
+      if (pos >= f->n_items) break;
+      if (items && n < capacity) items[n] = f->order[pos];
+      ++n;
+    }
+  }
+  return n;
 }
 
 extern "C" long srf_feeder_item_frames(const srf_feeder* f, int item) {
@@ -337,14 +384,17 @@ extern "C" int srf_feeder_start_epoch(srf_feeder* f, int epoch) {
   return SRF_OK;
 }
 
-// Queue the next batch of the epoch into caller-owned buffers (wave: batch * streams * time floats, len: batch ints; pinned
+// Queue the next batch of the epoch into caller-owned buffers (wave: batch * streams * time floats, len: batch * streams ints; pinned
 // host memory if the caller wants an asynchronous copy).  Returns 1 when the epoch has no batch left (nothing queued).
 extern "C" int srf_feeder_submit(srf_feeder* f, float* wave, int* len, float* stat) {
   SRF_CHECK_ARG(f && wave && len && stat, "srf_feeder_submit: null pointer");
   std::lock_guard<std::mutex> lk(f->mu);
-  const long left = f->n_items - f->cursor;
-  if (left <= 0 || (f->drop_last && left < f->batch)) return 1;
-  const int nb = left < f->batch ? (int)left : f->batch;
+  const long gbatch = (long)f->batch * f->world;
+  const long left = f->n_items - f->cursor;                       // items of the epoch not yet dealt to a global batch
+  if (left <= 0 || (f->drop_last && left < gbatch)) return 1;
+  const long mine0 = f->cursor + (long)f->rank * f->batch;        // this rank's slice of the global batch
+  const long avail = f->n_items - mine0;
+  const int nb = avail < f->batch ? (int)(avail > 0 ? avail : 0) : f->batch;   // (< batch only without drop_last, world 1)
   auto* s = new srf_feeder::Slot();
   s->wave = wave;
   s->len = len;
@@ -352,13 +402,13 @@ extern "C" int srf_feeder_submit(srf_feeder* f, float* wave, int* len, float* st
   s->n_valid = nb;
   s->pending = nb * f->n_streams;
   for (int b = 0; b < f->batch; ++b) {
-    len[b] = 0;
+    for (int st = 0; st < f->n_streams; ++st) len[(size_t)b * f->n_streams + st] = 0;
     stat[2 * b] = 0.f;
     stat[2 * b + 1] = 1.f;
   }
   if (nb < f->batch) memset(wave + (size_t)nb * f->n_streams * f->T, 0, sizeof(float) * (size_t)(f->batch - nb) * f->n_streams * f->T);
   for (int b = 0; b < nb; ++b) {
-    const int item = f->order[f->cursor + b];
+    const int item = f->order[mine0 + b];
     long start = 0;
     if (f->augment && f->frames[item] > f->T) {   // wham.py:183-186: one start per example, shared by its files
       const uint64_t r = splitmix64(splitmix64(f->seed + 0x632BE59BD9B4E019ULL * (uint64_t)(f->epoch + 1)) ^ (uint64_t)item);
@@ -366,7 +416,7 @@ extern "C" int srf_feeder_submit(srf_feeder* f, float* wave, int* len, float* st
     }
     for (int st = 0; st < f->n_streams; ++st) f->jobs.push_back(srf_feeder::Job{s, b, item, st, start});
   }
-  f->cursor += nb;
+  f->cursor += gbatch;
   f->inflight.push_back(s);
   f->cv_job.notify_all();
   return SRF_OK;
@@ -393,10 +443,29 @@ extern "C" int srf_feeder_wait(srf_feeder* f, float** wave, int** len, float** s
   return SRF_OK;
 }
 
+// One example, synchronously in the calling thread (Dataset.__getitem__'s reads): paths[n_streams] = mixture, sources; the
+// crop [start, start + time_samples) of every file -> wave [n_streams][time_samples], len [n_streams], stat [2] exactly as
+// a worker thread fills them for one batch row.
+extern "C" int srf_feeder_read_example(const char* const* paths, int n_streams, int time_samples, long start, int augment,
+                                       int normalize, float* wave, int* len, float* stat) {
+  SRF_CHECK_ARG(paths && wave && len && stat && n_streams > 0 && time_samples > 0 && start >= 0,
+                "srf_feeder_read_example: bad arguments");
+  stat[0] = 0.f;
+  stat[1] = 1.f;
+  for (int st = 0; st < n_streams; ++st) {
+    SRF_CHECK_ARG(paths[st], "srf_feeder_read_example: null path %d", st);
+    std::string err;
+    const bool ok = read_stream(paths[st], st, start, time_samples, augment, normalize, wave + (size_t)st * time_samples,
+                                len + st, stat, err);
+    SRF_CHECK_ARG(ok, "srf_feeder: %s", err.c_str());
+  }
+  return SRF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // device side: the Dataset's normalisation recipe on a whole batch
 // ---------------------------------------------------------------------------------------------
-// raw [B][S1][T] (stream 0 = mixture, zero padded beyond len[b]) -> mix [B][T], src [B][S1-1][T].
+// raw [B][S1][T] (stream 0 = mixture; every stream zero padded beyond its len[b][s]) -> mix [B][T], src [B][S1-1][T].
 // normalize = 0: plain copy (wham.py:190-191,208-209 skipped).  normalize = 1, wham.py:189-217:
 //   every stream: x <- (x - mean) / (std + eps) over its VALID samples (torch .std(): unbiased), then zero pad.  The
 //   mixture's {mean, std} come from the host (stat[b]): without the random crop the reference normalises the mixture over
@@ -418,9 +487,11 @@ __global__ __launch_bounds__(256) void srf_feeder_normalize_kernel(const float* 
                                                                    float* __restrict__ src) {
   __shared__ double red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int n = min(max(len[b], 0), T);
   double mix_std = 0.0;
   for (int s = 0; s < S1; ++s) {
+    // valid samples of THIS stream: the reference normalises the slice it read (wham.py:201-207), so a source file shorter
+    // than its mixture must not have its zero padding counted in its mean / std
+    const int n = min(max(len[(size_t)b * S1 + s], 0), T);
     const float* x = raw + ((size_t)b * S1 + s) * T;
     float* y = s == 0 ? mix + (size_t)b * T : src + ((size_t)b * (S1 - 1) + (s - 1)) * T;
     if (!normalize) {

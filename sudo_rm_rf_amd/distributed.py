@@ -90,6 +90,26 @@ def separate_sharded(model, mixtures, gather=False):
     return torch.cat(parts, 0)
 
 
+def flat_gradient_view(params):
+    """If the .grad tensors of `params` are consecutive views of ONE buffer -- what the HIP training step hands to autograd
+    (engine._TrainStep.backward: srf_backward writes one flat fp32 gradient; the per-parameter views are adopted by
+    autograd without a copy) -- return that buffer as a 1-D tensor covering exactly those gradients; else None."""
+    grads = [p.grad for p in params]
+    if not grads or any(g is None or not g.is_contiguous() or g.dtype != grads[0].dtype or g.device != grads[0].device
+                        for g in grads):
+        return None
+    base = grads[0].untyped_storage().data_ptr()
+    item = grads[0].element_size()
+    pos = grads[0].data_ptr()
+    for g in grads:
+        if g.untyped_storage().data_ptr() != base or g.data_ptr() != pos:
+            return None
+        pos += g.numel() * item
+    total = (pos - grads[0].data_ptr()) // item
+    return torch.empty(0, dtype=grads[0].dtype, device=grads[0].device).set_(
+        grads[0].untyped_storage(), grads[0].storage_offset(), (total,), (1,))
+
+
 def allreduce_gradients(parameters, average=True):
     """The training step's only collective: ONE all-reduce of the flat fp32 gradient over
     RCCL / xGMI after backward, then 1/world scaling -- what replaces the reference's DataParallel gather of
@@ -97,13 +117,26 @@ def allreduce_gradients(parameters, average=True):
     clip_grad_norm_ + Adam step on identical gradients, so the replicas stay bit-identical without a broadcast.
     With equal shard sizes the averaged gradient equals the gradient of the reference's batch-mean loss
     (losses/sisdr.py:307); the +-30 clamp of the runner acts on each shard's mean here (it only gates the gradient
-    when the loss is saturated).  Returns the flat gradient (a copy; .grad tensors are updated)."""
+    when the loss is saturated).
+
+    IN PLACE when the gradients already are views of one flat buffer (the HIP training step's are): one collective on
+    that buffer, one scaling kernel, no concatenation and no copy back (round 2 did `torch.cat` + ~1 230 `copy_`
+    launches, ~6 ms of a 133 ms cfg-4 step).  Gradients from elsewhere (plain autograd) take the gather / scatter
+    path.  Returns the reduced flat gradient (aliasing the .grad tensors in the in-place case)."""
     params = [p for p in parameters if p.grad is not None]
     if not params:
         return None
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
     _, ws, _ = world()
-    if dist.is_initialized() and ws > 1:
+    active = dist.is_initialized() and ws > 1
+    flat = flat_gradient_view(params)
+    if flat is not None:
+        if active:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if average:
+                flat.mul_(1.0 / ws)
+        return flat
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    if active:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if average:
             flat.mul_(1.0 / ws)
@@ -113,3 +146,26 @@ def allreduce_gradients(parameters, average=True):
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
     return flat
+
+
+def time_allreduce(flat, repeats=10, device=None):
+    """Milliseconds per all-reduce of `flat` (isolated: barrier, `repeats` back-to-back collectives, max over ranks) and the
+    bus bandwidth it corresponds to, 2 (N-1)/N * bytes / time -- the per-link figure of a ring all-reduce (xGMI: ~153 GB/s
+    per link, 7 links per GPU).  {"bytes", "ms", "bus_GBps", "world"}; world 1: zeros."""
+    _, ws, _ = world()
+    nbytes = flat.numel() * flat.element_size()
+    if not (dist.is_initialized() and ws > 1):
+        return {"bytes": nbytes, "ms": 0.0, "bus_GBps": 0.0, "world": 1}
+    import time
+    scratch = flat.clone()
+    dev = device if device is not None else (flat.device if flat.is_cuda else None)
+    dist.all_reduce(scratch)                     # warm-up (communicator set-up)
+    barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        dist.all_reduce(scratch)
+        scratch.mul_(1.0 / ws)                   # (keeps the values bounded; part of what a step does anyway)
+    if flat.is_cuda:
+        torch.cuda.synchronize(flat.device)
+    sec = max_over_ranks(time.perf_counter() - t0, dev) / repeats
+    return {"bytes": nbytes, "ms": 1e3 * sec, "bus_GBps": 2.0 * (ws - 1) / ws * nbytes / sec / 1e9, "world": ws}

@@ -148,7 +148,7 @@ class _TrainStep(torch.autograd.Function):
         dev = x.device
         g = grad_out.detach().to(torch.float32).contiguous()
         sizes = [p.numel() for p in params]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        flat = ctx.engine._flat_grad_buffer(params, sum(sizes), dev)
         grads, off = [], 0
         for p, n in zip(params, sizes):
             grads.append(flat[off:off + n].view_as(p))
@@ -161,6 +161,7 @@ class _TrainStep(torch.autograd.Function):
                                   saved.numel(), _lib.ptr(scratch), scratch.numel(), _lib.current_stream(dev))
             _lib.check(rc, "srf_backward")
         ctx.saved_buf = None
+        ctx.engine.last_flat_grad = flat      # (autograd adopts the views below as the .grad tensors: this IS the gradient)
         return (None, None, None) + tuple(grads)
 
 
@@ -201,6 +202,25 @@ class ModelEngine:
         self._graphs = OrderedDict()
         self._graph_seen = {}
         self._run_locks = {}
+        self._grad_bufs = {}
+        self.last_flat_grad = None
+
+    def _flat_grad_buffer(self, params, total, device):
+        """The flat fp32 buffer srf_backward writes all parameter gradients into (zeroed: the weight-gradient kernels
+        accumulate).  ONE persistent buffer per device, re-zeroed every step, instead of a fresh torch.zeros per step --
+        unless a parameter's live .grad still aliases it (gradient accumulation over micro-batches: autograd will ADD the new
+        views to those tensors, so they must not be the same memory), in which case this step gets a buffer of its own."""
+        key = (device.index, total)
+        buf = self._grad_bufs.get(key)
+        if buf is not None:
+            lo, hi = buf.data_ptr(), buf.data_ptr() + 4 * total
+            if any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in params):
+                return torch.zeros(total, dtype=torch.float32, device=device)
+            buf.zero_()
+            return buf
+        self._grad_bufs.clear()               # (a model has one parameter set: keep one buffer)
+        buf = self._grad_bufs[key] = torch.zeros(total, dtype=torch.float32, device=device)
+        return buf
 
     def _run_lock(self, device):
         """One re-entrant lock per device: a forward is a chain of dependent launches into a workspace, so the launches

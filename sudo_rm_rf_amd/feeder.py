@@ -4,8 +4,10 @@ with the per-example work moved off Python.
 ``Dataset(**kwargs)`` takes the reference's keyword arguments and indexes the same directory tree.  ``get_generator`` returns
 an iterator over ``(mixtures [B, T], sources [B, S, T])`` float32 tensors ON THE MI355X: a pool of native threads
 (csrc/srf_feeder.hip) reads and crops the batch's WAV files into pinned buffers, one asynchronous copy moves the raw batch,
-and one kernel applies the Dataset's normalisation recipe there.  ``Dataset[i]`` (one example, CPU tensors, the reference's
-``__getitem__``) is kept for API compatibility and as the parity reference of the batch path."""
+and one kernel applies the Dataset's normalisation recipe there; with one process per GPU every rank's feeder deals itself a
+disjoint shard of each global batch (``rank`` / ``world_size``).  ``Dataset[i]`` (the reference's ``__getitem__``: one example,
+CPU tensors) is a batch of one through the same native reader and device kernel.  ``normalize_tensor_wav`` / ``safe_pad``
+only mirror the reference's public helpers; nothing on the feeder's path calls them."""
 import ctypes as C
 import glob
 import os
@@ -138,7 +140,14 @@ class Dataset(torch.utils.data.Dataset):
                [os.path.join(self.dataset_dirpath, s, name) for s in self.source_names]
 
     def __getitem__(self, idx):
-        """One example on the CPU, operation for operation wham.py:171-217 (files through the native reader)."""
+        """One example, wham.py:171-217: (mixture [T], sources [S, T]) float32 CPU tensors like the reference returns them.
+        A batch of one through the product path -- the native reader (srf_feeder_read_example) and the device kernel of the
+        batch feeder (srf_feeder_normalize) on the current MI355X -- so it needs the GPU like everything else here; the
+        operation-for-operation CPU restatement of the reference's recipe lives in oracle/feeder_oracle.py (test
+        infrastructure).  The random crop start is drawn like the reference's (time-seeded numpy generator, :173-186)."""
+        if not torch.cuda.is_available():
+            raise _lib.SrfError("Dataset[i] normalises on an MI355X (srf_feeder_normalize); no GPU is visible and there is "
+                                "deliberately no CPU path (use get_generator(...) / this call on a GPU box)")
         if self.augment:
             np.random.seed(int(np.modf(time())[0] * 100000000))
         paths = self.paths_of(idx)
@@ -146,38 +155,58 @@ class Dataset(torch.utils.data.Dataset):
         rand_start = 0
         if self.augment and max_len > self.time_samples:
             rand_start = np.random.randint(0, max_len - self.time_samples)
-            mixture_wav = torch.from_numpy(wav_read(paths[0], rand_start, self.time_samples).copy())
-        else:
-            mixture_wav = torch.from_numpy(wav_read(paths[0]).copy())
-        if self.normalize_audio:
-            mixture_wav = normalize_tensor_wav(mixture_wav)
-        mixture_wav = self.safe_pad(mixture_wav)
-        sources_list = []
-        for p in paths[1:]:
-            source_wav = torch.from_numpy(wav_read(p, rand_start, self.time_samples).copy())
-            if self.normalize_audio:
-                source_wav = normalize_tensor_wav(source_wav)
-            sources_list.append(self.safe_pad(source_wav))
-        if self.normalize_audio:
-            mix_std = mixture_wav.detach().cpu().numpy().std()
-            mixture_wav = normalize_tensor_wav(mixture_wav, std=mix_std)
-            sources_list = [normalize_tensor_wav(s, std=mix_std) for s in sources_list]
-        return mixture_wav, torch.stack(sources_list, dim=0)
+        # what the reference's safe_pad leaves: time_samples with zero_pad, else at most the samples the file has (:157-166)
+        T = self.time_samples if self.zero_pad else max(1, min(self.time_samples, max_len - rand_start))
+        S1 = len(paths)
+        wave = torch.empty((1, S1, T), dtype=torch.float32).pin_memory()
+        ln = torch.empty((1, S1), dtype=torch.int32)
+        st = torch.empty((1, 2), dtype=torch.float32)
+        arr = (C.c_char_p * S1)(*[os.fsencode(p) for p in paths])
+        lib = _lib.load()
+        _lib.check(lib.srf_feeder_read_example(arr, S1, T, int(rand_start), int(self.augment), int(self.normalize_audio),
+                                               wave.data_ptr(), ln.data_ptr(), st.data_ptr()), "srf_feeder_read_example")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        raw, nd, sd = wave.to(dev), ln.to(dev), st.to(dev)
+        mix = torch.empty((1, T), dtype=torch.float32, device=dev)
+        src = torch.empty((1, S1 - 1, T), dtype=torch.float32, device=dev)
+        _lib.check(lib.srf_feeder_normalize(raw.data_ptr(), nd.data_ptr(), sd.data_ptr(), 1, S1, T, int(self.normalize_audio),
+                                            C.c_float(EPS), mix.data_ptr(), src.data_ptr(), _lib.current_stream(dev)),
+                   "srf_feeder_normalize")
+        return mix[0].cpu(), src[0].cpu()
 
-    def get_generator(self, batch_size=4, shuffle=True, num_workers=4, device=None, prefetch=3, seed=0, drop_last=True):
+    def get_generator(self, batch_size=4, shuffle=True, num_workers=4, device=None, prefetch=3, seed=0, drop_last=True,
+                      rank=None, world_size=None):
         """The reference's DataLoader(batch_size, shuffle, num_workers, drop_last=True) (wham.py:219-224) as a native
-        feeder: iterating it yields (mixtures [B, T], sources [B, S, T]) on `device` (default: the current MI355X)."""
-        return BatchFeeder(self, batch_size, shuffle, num_workers, device, prefetch, seed, drop_last)
+        feeder: iterating it yields (mixtures [B, T], sources [B, S, T]) on `device` (default: the current MI355X).
+        rank / world_size (default: torch.distributed's, when initialised; else 0 / 1): one process per GPU -- every rank
+        gets its own disjoint `batch_size` examples of each global batch of batch_size * world_size (BatchFeeder)."""
+        return BatchFeeder(self, batch_size, shuffle, num_workers, device, prefetch, seed, drop_last, rank=rank,
+                           world_size=world_size)
 
 
 class BatchFeeder:
     """Iterable over the batches of one epoch per ``iter()`` (epoch counter advances, so every epoch reshuffles / recrops).
     Pipeline per batch: native threads fill a pinned buffer -> cudaMemcpyAsync on a side stream -> srf_feeder_normalize on
-    that stream -> the consumer's stream waits on the batch's event.  `prefetch` batches are in flight."""
+    that stream -> the consumer's stream waits on the batch's event (no host synchronisation anywhere: a pinned slot goes
+    back to the readers once its copy EVENT has completed, polled at the next batch).  `prefetch` batches are in flight.
 
-    def __init__(self, dataset, batch_size, shuffle, num_workers, device, prefetch, seed, drop_last, host_only=False):
+    Sharding (rank, world_size): all ranks derive the same epoch order from (seed, epoch); this feeder
+    delivers examples [rank * B, (rank + 1) * B) of every global batch of B * world_size -- disjoint across ranks, together
+    exactly the single-process batch -- and every rank runs the same number of steps (drop_last is required)."""
+
+    def __init__(self, dataset, batch_size, shuffle, num_workers, device, prefetch, seed, drop_last, host_only=False,
+                 rank=None, world_size=None):
         if not dataset.zero_pad and any(n < dataset.time_samples for n in dataset.file_frames):
             raise _lib.SrfError("files shorter than time_samples need zero_pad=True to be batched")
+        if rank is None or world_size is None:
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized()
+            rank = (dist.get_rank() if on else 0) if rank is None else rank
+            world_size = (dist.get_world_size() if on else 1) if world_size is None else world_size
+        self.rank, self.world_size = int(rank), int(world_size)
+        if self.world_size > 1 and not drop_last:
+            raise _lib.SrfError("a sharded feeder (world size %d) needs drop_last=True: every rank must run the same number "
+                                "of steps" % self.world_size)
         self.ds, self.B, self.host_only = dataset, int(batch_size), host_only
         self.S1 = 1 + len(dataset.source_names)
         self.T = dataset.time_samples
@@ -186,8 +215,9 @@ class BatchFeeder:
         flat = [os.fsencode(p) for i in range(len(dataset)) for p in dataset.paths_of(i)]
         arr = (C.c_char_p * len(flat))(*flat)
         h = C.c_void_p()
-        _lib.check(lib.srf_feeder_create(arr, len(dataset), self.S1, self.T, self.B, max(1, int(num_workers)),
-                                         int(dataset.augment), int(bool(shuffle)), int(bool(drop_last)), int(seed), C.byref(h)),
+        _lib.check(lib.srf_feeder_create_sharded(arr, len(dataset), self.S1, self.T, self.B, max(1, int(num_workers)),
+                                                 int(dataset.augment), int(bool(shuffle)), int(bool(drop_last)), int(seed),
+                                                 int(dataset.normalize_audio), self.rank, self.world_size, C.byref(h)),
                    "srf_feeder_create")
         self._h, self._lib, self._epoch = h, lib, 0
         if host_only:
@@ -199,8 +229,10 @@ class BatchFeeder:
                 raise _lib.SrfError("BatchFeeder delivers to an MI355X only (got %s)" % self.device)
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
             self._stream = torch.cuda.Stream(self.device)
-        self._slots = [(mk((self.B, self.S1, self.T), torch.float32), mk((self.B,), torch.int32), mk((self.B, 2), torch.float32))
-                       for _ in range(self.prefetch)]
+        # one slot more than the prefetch depth: the slot whose copy is still leaving the host is parked, not re-armed
+        n_slots = self.prefetch + (0 if host_only else 1)
+        self._slots = [(mk((self.B, self.S1, self.T), torch.float32), mk((self.B, self.S1), torch.int32),
+                        mk((self.B, 2), torch.float32)) for _ in range(n_slots)]
 
     def __len__(self):
         return int(self._lib.srf_feeder_batches_per_epoch(self._h))
@@ -209,6 +241,13 @@ class BatchFeeder:
         h, self._h = getattr(self, "_h", None), None
         if h:
             self._lib.srf_feeder_destroy(h)
+
+    def epoch_items(self):
+        """Dataset indices this rank delivers in the CURRENT epoch (the one the last iter() started), in order."""
+        cap = len(self.ds)
+        buf = (C.c_int * cap)()
+        n = self._lib.srf_feeder_epoch_items(self._h, buf, cap)
+        return list(buf[:n])
 
     def _submit(self, slot):
         w, n, st = self._slots[slot]
@@ -222,10 +261,21 @@ class BatchFeeder:
         lib = self._lib
         _lib.check(lib.srf_feeder_start_epoch(self._h, self._epoch), "srf_feeder_start_epoch")
         self._epoch += 1
-        queued = []
-        for s in range(self.prefetch):
-            if self._submit(s):
-                queued.append(s)
+        queued, parked = [], []             # slots being read / slots whose host -> device copy may still be in flight
+        free = list(range(len(self._slots)))
+        more = True
+
+        def arm():                          # hand every free slot back to the readers (until the epoch runs out)
+            nonlocal more
+            while more and free and len(queued) < self.prefetch:
+                slot = free.pop(0)
+                if self._submit(slot):
+                    queued.append(slot)
+                else:
+                    more = False
+                    free.insert(0, slot)
+
+        arm()
         try:
             while queued:
                 slot = queued.pop(0)
@@ -234,30 +284,47 @@ class BatchFeeder:
                 w, n, st = self._slots[slot]
                 if self.host_only:
                     out = (w[:nv.value].clone(), n[:nv.value].clone(), st[:nv.value].clone())
+                    free.append(slot)
                 else:
-                    out = self._to_device(w, n, st, nv.value)
-                if self._submit(slot):      # the slot's buffers are free again (the copy above is complete / ordered)
-                    queued.append(slot)
+                    out, copied = self._to_device(w, n, st, nv.value)
+                    parked.append((slot, copied))
+                # slots whose copy has left the host go back to the readers; only when every slot is parked (the consumer
+                # is far ahead of PCIe) does the host wait -- for the oldest copy alone
+                while parked and (parked[0][1].query() or not (queued or free)):
+                    s0, ev = parked.pop(0)
+                    ev.synchronize()
+                    free.append(s0)
+                arm()
                 yield out
         finally:
             while queued:                   # abandoned iteration: drain what is in flight
                 queued.pop(0)
                 lib.srf_feeder_wait(self._h, None, None, None, None)
+            for _, ev in parked:
+                ev.synchronize()
 
     def _to_device(self, w, n, st, nv):
+        """Pinned slot -> (mix, src) on the device; returns them and the event after which the slot may be overwritten.
+        Stream discipline: everything the side stream writes is ALLOCATED on the side stream, so the caching
+        allocator never hands it a block whose previous owner's consumer-stream kernels (the train step of an earlier
+        batch) may still be queued; the outputs are then handed to the consumer's stream with wait_event + record_stream,
+        so the consumer may drop them at any time without the side stream re-using them too early."""
         dev, lib = self.device, self._lib
-        mix = torch.empty((self.B, self.T), dtype=torch.float32, device=dev)
-        src = torch.empty((self.B, self.S1 - 1, self.T), dtype=torch.float32, device=dev)
+        cur = torch.cuda.current_stream(dev)
         with torch.cuda.device(dev), torch.cuda.stream(self._stream):
+            mix = torch.empty((self.B, self.T), dtype=torch.float32, device=dev)
+            src = torch.empty((self.B, self.S1 - 1, self.T), dtype=torch.float32, device=dev)
             raw = w.to(dev, non_blocking=True)
             nd = n.to(dev, non_blocking=True)
             sd = st.to(dev, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self._stream)      # the pinned slot has left the host once this completes
             _lib.check(lib.srf_feeder_normalize(raw.data_ptr(), nd.data_ptr(), sd.data_ptr(), self.B, self.S1, self.T,
                                                 int(self.ds.normalize_audio), C.c_float(EPS), mix.data_ptr(), src.data_ptr(),
                                                 _lib.current_stream(dev)), "srf_feeder_normalize")
             done = torch.cuda.Event()
             done.record(self._stream)
-        done.synchronize()                  # the pinned slot is resubmitted right after: its copy must have left the host
-        for t in (mix, src, raw, nd, sd):
-            t.record_stream(torch.cuda.current_stream(dev))
-        return mix[:nv], src[:nv]
+        cur.wait_event(done)                 # consumer-stream work queued after this sees the finished batch
+        mix.record_stream(cur)
+        src.record_stream(cur)
+        return (mix[:nv], src[:nv]), copied

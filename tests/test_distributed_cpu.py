@@ -81,6 +81,93 @@ def test_two_rank_gloo_sharding():
         assert e_gather < 1e-6 and e_local < 1e-6
 
 
+def _train_worker(rank, world, port, q, tree):
+    """The 8-GPU training path's glue on 2 CPU ranks: rank-aware feeder, the flat gradient buffer
+    all-reduced IN PLACE, bench.py's train loop (barrier, timed steps, max over ranks, all-reduce timing) with a stub model."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from sudo_rm_rf_amd import distributed as D, feeder
+    torch.set_num_threads(1)
+    r, ws, dev = D.init_from_env(backend="gloo")
+    # ---- feeder: rank / world picked up from the process group; ranks' epochs are disjoint and cover the set
+    ds = feeder.Dataset(root_dirpath=tree, task="sep_clean", split="tr", sample_rate=8000, timelength=0.2,
+                        normalize_audio=True, n_samples=0, zero_pad=True, augment=True, min_or_max="min")
+    bf = feeder.BatchFeeder(ds, 1, True, 2, None, 2, 9, True, host_only=True)
+    assert (bf.rank, bf.world_size) == (rank, world)
+    batches = list(bf)
+    mine = torch.tensor(bf.epoch_items(), dtype=torch.int64)
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    allv = torch.cat(both).tolist()
+    assert len(batches) == len(bf) == len(ds) // world and len(set(allv)) == len(allv) == world * len(bf)
+    # ---- a stub "model" whose gradients are views of ONE flat buffer, like the HIP training step's
+    torch.manual_seed(0)                                                    # same weights on every rank
+    shapes = [(4, 3), (5,), (2, 2, 2)]
+    params = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    flat = torch.zeros(sum(p.numel() for p in params))
+    state = {"calls": 0}
+
+    def step():
+        x = batches[state["calls"] % len(batches)][0].double().mean()       # this rank's data decides its gradient
+        state["calls"] += 1
+        flat.zero_()
+        off = 0
+        for i, p in enumerate(params):
+            n = p.numel()
+            v = flat[off:off + n].view_as(p)
+            v += (i + 1) * float(x) + rank
+            p.grad = v
+            off += n
+        red = D.allreduce_gradients(params)
+        assert red.data_ptr() == flat.data_ptr() and red.numel() == flat.numel()      # in place: no cat, no copy back
+        for p in params:
+            assert p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+        return red.sum()
+
+    assert D.flat_gradient_view(params) is None                             # (no gradients yet)
+    out = bench.train_loop(step, lambda: flat, steps=3, warmup=1, rank=rank, world=world, dev=dev)
+    assert state["calls"] == 1 + 1 + 3
+    assert len(out["per_rank_ms_per_step"]) == world and out["ms_per_step"] >= max(out["per_rank_ms_per_step"]) - 1e-6
+    ar = out["allreduce"]
+    assert ar["world"] == world and ar["bytes"] == 4 * flat.numel() and ar["ms"] > 0 and ar["bus_GBps"] > 0
+    # the averaged gradient is identical on every rank: gather and compare
+    g = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(g, flat)
+    assert all(torch.equal(g[0], t) for t in g)
+    # gradients that are NOT one buffer take the gather / scatter path and give the same answer
+    for p in params:
+        p.grad = p.grad.clone() + rank
+    want = [p.grad.clone() for p in params]
+    red2 = D.allreduce_gradients(params)
+    assert D.flat_gradient_view(params) is None and red2.numel() == flat.numel()
+    for p, w0 in zip(params, want):
+        assert torch.allclose(p.grad, w0 - rank + (world - 1) / 2.0)
+    q.put((rank, allv, float(flat.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_training_glue(tmp_path):
+    from oracle import feeder_oracle
+    feeder_oracle.make_fake_wham(str(tmp_path), task="sep_clean", seed=3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+
+
 def test_shard_slice_rejects_uneven():
     from sudo_rm_rf_amd.distributed import shard_slice
     with pytest.raises(ValueError):
