@@ -205,6 +205,14 @@ __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int
 
 int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st);
 int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
+int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);   // round 3 (srf_pwconv_x3w.hip)
+bool srf_x3w_supported(int Bt, int pro);
+// the 256 x 128 kernel: round 3's unless debug flag 16384 asks for round 2's (same-box A/B) or the launch has more examples
+// than the statistics table of the round-3 kernel holds
+static int srf_pw_256_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
+  if (!(srf_debug_flags() & 16384) && srf_x3w_supported(a.Bt, pro)) return srf_pw_x3w_launch(a, wpack, pro, st);
+  return srf_pw_x3v_launch(a, wpack, pro, st);
+}
 size_t srf_x3v_packed_bytes(int Cout, int Cin);
 bool srf_x3v_supported(int Cin, int Cout, int L);
 int srf_pw_small_launch(const PwArgs& a, hipStream_t st);
@@ -274,7 +282,7 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
   if (mfma_ok && mode == 0 && w_packed && srf_x3v_supported(Cin, Cout, L) && srf_aligned16(w_packed) &&
       (long)Bt * Cin * L * 4 < (1L << 31) && !(srf_debug_flags() & 4) &&
       (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus())
-    return srf_pw_x3v_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
+    return srf_pw_256_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
   // An activation tensor beyond the 2 GB reach of the kernel's 32-bit buffer offsets (cfg 5's bottleneck: 16 x 4096 x 12800
   // floats = 3.4 GB) goes out as several launches over runs of whole examples: examples are independent, every per-example
   // pointer (statistics slots included) just moves along.
@@ -295,7 +303,7 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
         if (a.nrm.sums) c.nrm.sums = a.nrm.sums + (size_t)b0 * SRF_STAT_BUCKETS * 2;
         const bool more = b0 + per < Bt;    // (one profiler interval for the whole operation: only the last launch is marked)
         if (more) srf_prof_hold(+1);
-        const int rc = srf_pw_x3v_launch(c, reinterpret_cast<const char*>(w_packed), pro_sel, st);
+        const int rc = srf_pw_256_launch(c, reinterpret_cast<const char*>(w_packed), pro_sel, st);
         if (more) srf_prof_hold(-1);
         if (rc) return rc;
       }
