@@ -22,6 +22,7 @@
 //      where the epilogue's operands are in flight, read just in time instead).
 // The round-2 kernel stays in the library (debug flag 16384) for same-box A/B runs.
 // Prologue / epilogue semantics are those of srf_pw.h (PwArgs).
+#include <atomic>
 #include <type_traits>
 
 #include "srf_pw.h"
@@ -51,13 +52,16 @@ __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8
 
 // PRO: 0 = identity, 1 = GlobLN, 2 = GlobLN + PReLU, 3 = PReLU only.
 // EPI: 0 = bias (+ statistics), 1 = bias + residual, 2 = ReLU(bias + .) x mul (mask epilogue), 3 = decided at run time (any).
-// ABL (diagnostics, results are wrong when != 0): 1 = no activation loads, 2 = no weight DMA, 4 = no MFMAs, 16 = no epilogue.
+// ABL (diagnostics, results are wrong when != 0): 1 = no activation loads, 2 = no weight DMA, 4 = no MFMAs, 8 = no GlobLN / PReLU /
+// split / ds_write, 16 = no epilogue, 32 = no fragment reads.
 // gamma / beta come again as noalias kernel arguments so that they are fetched with scalar loads.
 // Work distribution, barrier protocol and LDS images: see srf_pwconv_x3v.hip (unchanged).
-template <int PRO, int EPI, int ABL = 0>
+// DYN: tiles come from per-XCD work queues (`ctr`: 8 queue heads + a done counter, zero between launches) instead of the static
+// round-robin deal -- see "Work distribution" below.
+template <int PRO, int EPI, int ABL = 0, bool DYN = false>
 __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt,
                                                             int total, int rounds, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta) {
+                                                            const float* __restrict__ beta, unsigned* __restrict__ ctr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // W_NSTAGE * W_STAGE (+ the statistics table)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -72,6 +76,12 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
   const int x_bytes = a.Bt * Cin * L * 4;
   constexpr bool kHasExt = EPI != 0;         // the epilogue reads a second tensor (residual or mask multiplier)
+  // One-off start-up stagger (diagnostics: epi_mask bits 8..11 = units of ~4K cycles, 4 phases by block id; default none)
+  {
+    const int units = (a.epi_mask >> 8) & 15;
+    const int phase = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < units * phase; ++i) __builtin_amdgcn_s_sleep(64);
+  }
 
   // ---- GlobLN statistics of every example, once per block: {mean, rstd} in LDS behind the stages.  (A vector load per tile
   // -- the round-2 form -- is waited for with vmcnt(0) right behind two k-tiles' worth of activation loads.)  Wavefront w
@@ -98,13 +108,20 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   }
 
   struct TileCur {
-    int i, v, mt, lt, b, q;   // q: -1 = full tile, 0..3 = quarter of its parent tile
+    int i, v, mt, lt, b, q;   // q: -1 = full tile, 0..3 = quarter of its parent tile; v < 0: no tile
   };
   const int vstep = nblk >> 3;
   const int st_b = vstep / (nMt * nLt), st_r = vstep - st_b * (nMt * nLt);
   const int st_l = st_r / nMt, st_m = st_r - st_l * nMt;
   const int qfirst = (a.epi_mask >> 12) & 1 ? nq_mine : 0;     // tiles [0, qfirst) are quarter tiles, then the full ones
   auto is_quarter = [&](int i) { return qfirst ? i < qfirst : i >= rounds; };
+  auto cur_from_v = [&](TileCur& c, int v) {
+    const int t = v / nMt;
+    c.v = v;
+    c.mt = v - t * nMt;
+    c.b = t / nLt;
+    c.lt = t - c.b * nLt;
+  };
   auto cur_set = [&](TileCur& c, int i) {   // by division: a block's first tile and its quarter tiles
     int p = blockIdx.x + (i - qfirst) * nblk;
     c.q = -1;
@@ -113,13 +130,8 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       p = rounds * nblk + (qi >> 2);
       c.q = qi & 3;
     }
-    const int v = srf_xcd_remap(p, total);
-    const int t = v / nMt;
     c.i = i;
-    c.v = v;
-    c.mt = v - t * nMt;
-    c.b = t / nLt;
-    c.lt = t - c.b * nLt;
+    cur_from_v(c, srf_xcd_remap(p, total));
   };
   auto cur_next = [&](TileCur& c) {
     const int i = c.i + 1;
@@ -136,6 +148,53 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     cy = c.lt >= nLt ? 1 : 0;
     c.lt -= cy ? nLt : 0;
     c.b += st_b + cy;
+  };
+  // ---- Work distribution, DYN (round 3).  Why: with the static deal every CU runs the same program at the same time -- all
+  // k-loops together, then all epilogues together -- so the chip's 32 MB of tile outputs (+ 32 MB of residual reads) move in a
+  // burst while the matrix pipes idle, and vmcnt counts loads and stores in order: the first operand loads requested after an
+  // epilogue cannot be consumed before that epilogue's stores have retired (ablation, tools/gemm_ab.py, proj_1x1: k-loop memory
+  // pipeline alone 47 us, epilogue alone 49 us, both 99 us over a 27 us base; a start-up stagger of up to 29 us cost 12 us).
+  // Now the XCD's blocks start OUT OF PHASE without idling: block j (of the XCD's nbx) first runs j % 4 quarter tiles (0 .. 3/4 of
+  // a tile of work, reserved at the end of the XCD's tile range), then draws full tiles from the XCD's queue head (one returning
+  // atomicAdd per tile, two tiles ahead of use), then quarter tiles of the last nbx / 4 tiles: no block ever waits for
+  // another, the phases stay spread because every block keeps its own pace, and the tail is balanced to a quarter tile.
+  // Queue of XCD x (blocks with blockIdx % 8 == x: the dispatcher's placement -- an assumption about SPEED only): the virtual
+  // tile ids srf_xcd_remap gives that XCD, [base, base + W): [0, NF) full tiles | [NF, NF + Tq) as 4 Tq quarter items | the
+  // rest as seed quarters.  An item code >= 0 is an index into the dynamic part, < 0 a seed quarter.
+  const int xq = blockIdx.x & 7, jq = blockIdx.x >> 3, nbx = nblk >> 3;
+  const int d_qn = total >> 3, d_rn = total & 7;
+  const int d_base = xq < d_rn ? xq * (d_qn + 1) : d_rn * (d_qn + 1) + (xq - d_rn) * d_qn;
+  const int d_W = d_qn + (xq < d_rn ? 1 : 0);
+  const bool seed_on = (nbx & 7) == 0 && d_W >= 3 * nbx;
+  const int d_seedT = seed_on ? (nbx >> 2) * 6 / 4 : 0;                 // 6 seed quarters per 4 blocks
+  const int d_Tq = seed_on ? nbx >> 2 : d_W % nbx;                      // tail tiles dealt as quarters
+  const int d_NF = d_W - d_seedT - d_Tq;
+  const int d_items = d_NF + 4 * d_Tq;
+  const int d_nseed = seed_on ? (jq & 3) : 0;
+  const int d_seed0 = (jq >> 2) * 6 + ((jq & 3) * ((jq & 3) - 1)) / 2;
+  int* code_box = reinterpret_cast<int*>(smem + W_NSTAGE * W_STAGE + ((PRO == 1 || PRO == 2) ? a.Bt * 8 : 0));   // 4 ints
+  auto decode = [&](TileCur& c, int i, int code) {
+    c.i = i;
+    c.q = -1;
+    int v = -1;
+    if (code < 0) {
+      const int qi = -1 - code;
+      v = d_base + d_NF + d_Tq + (qi >> 2);
+      c.q = qi & 3;
+    } else if (code < d_NF) {
+      v = d_base + code;
+    } else if (code < d_items) {
+      const int qi = code - d_NF;
+      v = d_base + d_NF + (qi >> 2);
+      c.q = qi & 3;
+    }
+    if (v >= 0) cur_from_v(c, v);
+    c.v = v;
+  };
+  // item n of this block: a seed quarter while n < d_nseed, else the next dynamic item (one lane draws; >= d_items: no more work)
+  auto draw = [&](int n) -> int {
+    if (n < d_nseed) return -1 - (d_seed0 + n);
+    return (int)atomicAdd(&ctr[xq], 1u);
   };
 
   // ---- B staging geometry: thread -> time step n = tid & 127, k-group kg = tid >> 7 (wave-uniform), 8 k rows
@@ -195,6 +254,11 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   };
   // GlobLN / PReLU / split of k-tile kt (tile t) -> B images of `stage`
   auto lds_store = [&](const Regs& r, const TileP& t, int kt, int stage) __attribute__((always_inline)) {
+    if (ABL & 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(r.b[j]));
+      return;
+    }
     char* base = smem + stage * W_STAGE + b_lds;
     float vb[8];
     // Opaque at the point of use: volatile asm statements keep their order, so the conversion below -- and with it the
@@ -245,6 +309,11 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   };
   auto read_frags = [&](Frags& f, int stage, int ks, auto full_tag) __attribute__((always_inline)) {
     constexpr int NT = decltype(full_tag)::value ? 2 : 1;
+    if (ABL & 32) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(f.ah[t]), "+v"(f.al[t]), "+v"(f.bh[t]), "+v"(f.bl[t]));
+      return;
+    }
     const char* base = smem + stage * W_STAGE;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -323,11 +392,29 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   };
 
   TileCur cur, nxc;
-  cur_set(cur, 0);
+  if constexpr (DYN) {
+    if (tid == 0) {
+      code_box[0] = draw(0);
+      code_box[1] = draw(1);
+    }
+    __syncthreads();
+    decode(cur, 0, code_box[0]);
+    decode(nxc, 1, code_box[1]);
+    __syncthreads();                      // (the boxes are rewritten during the first tile)
+    if (cur.v < 0) {                      // nothing left for this block (more blocks than work items): only the bookkeeping
+      if (tid == 0 && atomicAdd(&ctr[8], 1u) == (unsigned)nblk - 1) {
+        for (int i = 0; i < 9; ++i) ctr[i] = 0;
+      }
+      return;
+    }
+  } else {
+    cur_set(cur, 0);
+    nxc = cur;
+    if (ntile > 1) cur_next(nxc);
+    else nxc.v = -1;
+  }
   tc = make_tile(cur);
-  nxc = cur;
-  if (ntile > 1) cur_next(nxc);
-  tn = ntile > 1 ? make_tile(nxc) : tc;   // past the last tile the pipeline re-reads that tile (harmless)
+  tn = nxc.v >= 0 ? make_tile(nxc) : tc;   // past the last tile the pipeline re-reads that tile (harmless)
   Regs r0, r1;
   if (ABL & 1) {
 #pragma unroll
@@ -344,8 +431,12 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
 
   using T = std::true_type;
   using F = std::false_type;
-  for (int i = 0; i < ntile; ++i) {
+  for (int i = 0; cur.v >= 0; ++i) {
     const bool quarter = cur.q >= 0;
+    int drawn = 0;                        // DYN: the code of item i + 2, drawn now, published before the tile's last barrier
+    if constexpr (DYN) {
+      if (tid == 0) drawn = draw(i + 2);
+    }
     set_off(quarter);
     const int m0 = cur.mt * W_BM, v = cur.v;
     const int l0 = cur.lt * W_BN + (quarter ? cur.q * 32 : 0);
@@ -425,6 +516,9 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       step(r0, nk - 3, full_tag, T{}, F{});      // last prefetching step: nothing requested for k-tile nk-2
       epi_issue(std::integral_constant<int, 0>{});
       step(r1, nk - 2, full_tag, F{}, F{});
+      if constexpr (DYN) {
+        if (tid == 0) code_box[2 + (i & 1)] = drawn;     // read by everyone behind the next barrier (the draw is ~nk steps old)
+      }
       step(r0, nk - 1, full_tag, F{}, F{});
       if constexpr (kHasExt) epi_issue(std::integral_constant<int, 1>{});
     };
@@ -434,8 +528,13 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       k_loop(T{});
     // parameters of the tile after next (LDS table + integer arithmetic: no memory wait)
     TileCur nnc = nxc;
-    const bool has_nn = i + 2 < ntile;
-    if (has_nn) cur_next(nnc);
+    if constexpr (DYN) {
+      if (nxc.v >= 0) decode(nnc, i + 2, code_box[2 + (i & 1)]);
+    } else {
+      if (i + 2 < ntile) cur_next(nnc);
+      else nnc.v = -1;
+    }
+    const bool has_nn = nnc.v >= 0 && nxc.v >= 0;
     const TileP tnn = has_nn ? make_tile(nnc) : tn;
     // epilogue through wave-private strips in the stage the tile's last k-tile has just freed
     const int free_stage = s0 == 0 ? W_NSTAGE - 1 : s0 - 1;
@@ -509,7 +608,19 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     __builtin_amdgcn_s_barrier();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus DMA of the pipeline tail must not outlive the block's LDS
+  if constexpr (DYN) {
+    // the last block out re-zeroes the queue heads (every block's draws are behind it): the slot is clean for its next launch
+    if (tid == 0 && atomicAdd(&ctr[8], 1u) == (unsigned)nblk - 1) {
+      for (int i = 0; i < 9; ++i) ctr[i] = 0;
+    }
+  }
 }
+
+// Work-queue heads of the DYN kernels: one 64-byte slot per launch in flight (8 queue heads + a done counter, all zero between
+// launches: the last block out of a launch re-zeroes its slot).  Launches take slots round-robin; a slot is reused 1024
+// launches later.  Device memory is per GPU, the sequence number per process.
+constexpr int W_CTR_SLOTS = 1024;
+__device__ unsigned g_x3w_ctr[W_CTR_SLOTS][16];
 
 bool srf_x3w_supported(int Bt, int pro) { return !(pro == 1 || pro == 2) || Bt <= W_MAX_STAT_EXAMPLES; }
 
@@ -519,17 +630,28 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
   SRF_CHECK_ARG((long)a.Bt * a.Cin * a.L * 4 < (1L << 31), "srf_pw_conv: activation tensor too large for buffer loads");
   SRF_CHECK_ARG(srf_x3w_supported(a.Bt, pro), "srf_pw_conv: too many examples for the statistics table");
-  const size_t lds = (size_t)W_NSTAGE * W_STAGE + ((pro == 1 || pro == 2) ? (size_t)a.Bt * sizeof(float2) : 0);
+  const size_t lds = (size_t)W_NSTAGE * W_STAGE + ((pro == 1 || pro == 2) ? (size_t)a.Bt * sizeof(float2) : 0) + 16;
   // dynamic LDS beyond 64 KB needs the attribute once per device (per-device cache, srf_common.h)
   const long ok = srf_device_cached(3, [](void*) -> long {
-    const int bytes = W_NSTAGE * W_STAGE + W_MAX_STAT_EXAMPLES * (int)sizeof(float2);
+    const int bytes = W_NSTAGE * W_STAGE + W_MAX_STAT_EXAMPLES * (int)sizeof(float2) + 16;
     bool good = true;
-    const void* fns[] = {(const void*)&srf_pw_x3w_kernel<0, 0>, (const void*)&srf_pw_x3w_kernel<1, 0>,
+    const void* fns[] = {(const void*)&srf_pw_x3w_kernel<0, 0, 0, true>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, true>,
+                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, true>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, true>,
+                         (const void*)&srf_pw_x3w_kernel<0, 3, 0, true>, (const void*)&srf_pw_x3w_kernel<1, 3, 0, true>,
+                         (const void*)&srf_pw_x3w_kernel<2, 3, 0, true>, (const void*)&srf_pw_x3w_kernel<3, 3, 0, true>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0>, (const void*)&srf_pw_x3w_kernel<1, 0>,
                          (const void*)&srf_pw_x3w_kernel<2, 1>, (const void*)&srf_pw_x3w_kernel<3, 2>,
                          (const void*)&srf_pw_x3w_kernel<0, 3>, (const void*)&srf_pw_x3w_kernel<1, 3>,
                          (const void*)&srf_pw_x3w_kernel<2, 3>, (const void*)&srf_pw_x3w_kernel<3, 3>,
                          (const void*)&srf_pw_x3w_kernel<2, 1, 3>, (const void*)&srf_pw_x3w_kernel<2, 1, 4>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 16>, (const void*)&srf_pw_x3w_kernel<2, 1, 19>};
+                         (const void*)&srf_pw_x3w_kernel<2, 1, 16>, (const void*)&srf_pw_x3w_kernel<2, 1, 19>,
+                         (const void*)&srf_pw_x3w_kernel<2, 1, 20>, (const void*)&srf_pw_x3w_kernel<2, 1, 23>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 3>, (const void*)&srf_pw_x3w_kernel<0, 0, 4>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 7>, (const void*)&srf_pw_x3w_kernel<0, 0, 12>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 16>, (const void*)&srf_pw_x3w_kernel<0, 0, 19>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 20>, (const void*)&srf_pw_x3w_kernel<0, 0, 23>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 31>, (const void*)&srf_pw_x3w_kernel<0, 0, 55>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 63>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
@@ -543,15 +665,55 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   dim3 grid((unsigned)nb), block(512);
   PwArgs ap = a;
   if (!(srf_debug_flags() & 512)) ap.epi_mask |= 1 << 12;   // quarter tiles first (flag 512: last)
+  ap.epi_mask |= ((srf_debug_flags() >> 22) & 3) << 8;      // diagnostics: start-up stagger units (flag bits 22-23)
   const bool res = a.residual != nullptr, mask = !res && (a.epi_mask & 1);
-#define W_GO(P, E, A) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta)
-  const int abl = (srf_debug_flags() >> 16) & 31;     // diagnostics: ablated pipelines (res_conv form only)
+  // tiles dealt statically (default) or drawn from per-XCD work queues with phase seeds (debug flag 32768).  Measured round 3
+  // (tools/gemm_ab.py, same box): the queues are bit-identical and SLOWER -- proj_1x1 125 vs 115 us, res_conv 145 vs 128,
+  // bottleneck 128 vs 107: a quarter tile costs ~0.6 of a full tile's time (it streams the whole weight image and pays every
+  // per-step cost for a quarter of the MFMA work), so 2.5 quarter tiles per block of phase seeds + tail cost more than the
+  // de-synchronised epilogues win.  Kept as a switch: the mechanism is sound, its seed is not.
+  const bool dyn = (srf_debug_flags() & 32768) != 0;
+  unsigned* ctr = nullptr;
+  if (dyn) {
+    const long base = srf_device_cached(4, [](void*) -> long {
+      void* p = nullptr;
+      return hipGetSymbolAddress(&p, HIP_SYMBOL(g_x3w_ctr)) == hipSuccess ? (long)p : 0;
+    }, nullptr);
+    SRF_CHECK_ARG(base != 0, "srf_pw_conv: cannot locate the work-queue counters");
+    static std::atomic<unsigned> seq{0};
+    ctr = reinterpret_cast<unsigned*>(base) + 16 * (seq.fetch_add(1, std::memory_order_relaxed) % W_CTR_SLOTS);
+  }
+#define W_GO(P, E, A) do { if (dyn && (A) == 0) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, true>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, ctr); \
+    else hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, false>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, (unsigned*)nullptr); } while (0)
+  // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated below)
+  const int abl = (srf_debug_flags() >> 16) & 63;
   if (abl && pro == 2 && res) {
     switch (abl) {
       case 3: W_GO(2, 1, 3); break;
       case 4: W_GO(2, 1, 4); break;
       case 16: W_GO(2, 1, 16); break;
-      default: W_GO(2, 1, 19); break;
+      case 19: W_GO(2, 1, 19); break;
+      case 20: W_GO(2, 1, 20); break;
+      case 23: W_GO(2, 1, 23); break;
+      default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for res_conv", abl);
+    }
+    SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
+    return SRF_OK;
+  }
+  if (abl && pro == 0 && !res && !mask) {
+    switch (abl) {
+      case 3: W_GO(0, 0, 3); break;
+      case 4: W_GO(0, 0, 4); break;
+      case 7: W_GO(0, 0, 7); break;
+      case 12: W_GO(0, 0, 12); break;
+      case 16: W_GO(0, 0, 16); break;
+      case 19: W_GO(0, 0, 19); break;
+      case 20: W_GO(0, 0, 20); break;
+      case 23: W_GO(0, 0, 23); break;
+      case 31: W_GO(0, 0, 31); break;
+      case 55: W_GO(0, 0, 55); break;
+      case 63: W_GO(0, 0, 63); break;
+      default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for proj_1x1", abl);
     }
     SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
     return SRF_OK;

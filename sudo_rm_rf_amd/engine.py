@@ -202,25 +202,16 @@ class ModelEngine:
         self._graphs = OrderedDict()
         self._graph_seen = {}
         self._run_locks = {}
-        self._grad_bufs = {}
         self.last_flat_grad = None
 
     def _flat_grad_buffer(self, params, total, device):
         """The flat fp32 buffer srf_backward writes all parameter gradients into (zeroed: the weight-gradient kernels
-        accumulate).  ONE persistent buffer per device, re-zeroed every step, instead of a fresh torch.zeros per step --
-        unless a parameter's live .grad still aliases it (gradient accumulation over micro-batches: autograd will ADD the new
-        views to those tensors, so they must not be the same memory), in which case this step gets a buffer of its own."""
-        key = (device.index, total)
-        buf = self._grad_bufs.get(key)
-        if buf is not None:
-            lo, hi = buf.data_ptr(), buf.data_ptr() + 4 * total
-            if any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in params):
-                return torch.zeros(total, dtype=torch.float32, device=device)
-            buf.zero_()
-            return buf
-        self._grad_bufs.clear()               # (a model has one parameter set: keep one buffer)
-        buf = self._grad_bufs[key] = torch.zeros(total, dtype=torch.float32, device=device)
-        return buf
+        accumulate).  A fresh block from torch's caching allocator per step (allocation = a free-list pop, the fill = one
+        memset kernel): autograd ADOPTS the per-parameter views as .grad tensors or keeps them alive inside the graph (a
+        DataParallel replica's gradients sit in its Broadcast node until all replicas are done; gradient accumulation adds
+        later steps INTO the first step's views), so the lifetime of a step's buffer is not the engine's to decide -- a
+        persistent buffer re-zeroed per step corrupted exactly those two cases (tests/test_gpu_train.py)."""
+        return torch.zeros(total, dtype=torch.float32, device=device)
 
     def _run_lock(self, device):
         """One re-entrant lock per device: a forward is a chain of dependent launches into a workspace, so the launches
