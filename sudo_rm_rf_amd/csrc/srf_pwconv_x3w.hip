@@ -58,10 +58,14 @@ __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8
 // Work distribution, barrier protocol and LDS images: see srf_pwconv_x3v.hip (unchanged).
 // DYN: tiles come from per-XCD work queues (`ctr`: 8 queue heads + a done counter, zero between launches) instead of the static
 // round-robin deal -- see "Work distribution" below.
-template <int PRO, int EPI, int ABL = 0, bool DYN = false>
+// DS: 0 = the tile's outputs leave in a burst after its k-loop (strips, float4 stores); 8 / 16 = DRIP epilogue: the finished
+// accumulators are parked in 64 registers and leave 64 / DS registers per step during the first DS steps of the NEXT tile's
+// k-loop, as dword buffer stores straight from the MFMA layout (see the drip block in the kernel).
+template <int PRO, int EPI, int ABL = 0, bool DYN = false, int DS = 0, int CP = 0>
 __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt,
                                                             int total, int rounds, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, unsigned* __restrict__ ctr) {
+                                                            const float* __restrict__ beta, unsigned* __restrict__ ctr,
+                                                            const float* __restrict__ bias_r) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // W_NSTAGE * W_STAGE (+ the statistics table)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * W_BK + j) * L * 4, 0));
+      r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * W_BK + j) * L * 4, (CP & 4) ? 2 : 0));
   };
   // GlobLN / PReLU / split of k-tile kt (tile t) -> B images of `stage`
   auto lds_store = [&](const Regs& r, const TileP& t, int kt, int stage) __attribute__((always_inline)) {
@@ -431,6 +435,126 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
 
   using T = std::true_type;
   using F = std::false_type;
+  if constexpr (DS > 0) {
+    // ================= DRIP epilogue (EPI 0: bias + statistics) =================
+    // Why: vmcnt counts loads and stores in order, so operand loads requested after an epilogue's stores cannot be consumed
+    // before those stores have retired, and a tile's 128 KB per CU retire at the chip's write rate (~4.3 TB/s: 49 us for
+    // proj_1x1's 210 MB on their own, tools/gemm_ab.py).  Burst epilogues therefore serialise with the k-loops (ablation:
+    // loads alone 47 us, epilogue alone 49 us, both 99 us).  Here a finished tile's accumulators are PARKED (64 registers) and
+    // written during the next tile's first DS k-steps, 64 / DS registers per step, as dword buffer stores straight from the
+    // MFMA C layout (a register = 2 rows x 32 columns = two full 128-byte lines), at the START of each step: the stores of
+    // step g are older than the DMA of step g, so the step's counted wait (vmcnt(20)) never covers them and they have two
+    // full steps to retire -- 16 KB per CU and step, i.e. the chip's write rate spread evenly over the launch.
+    // The k-loop's first DS steps are unrolled so that every parked register has a compile-time index.
+    f32x16 park[2][2];
+    bool pk_valid = false;
+    int pk_nt = 0, pk_mrow = 0, pk_lcol = 0, pk_v = 0, pk_q = 0;
+    long pk_b = 0;
+    int pk_vo = 0;                         // per-lane byte offset of (row pk_mrow + 4 * (lane >> 5), column pk_lcol + (lane & 31))
+    float pk_s = 0.f, pk_sq = 0.f;
+    const int lhalf = lane >> 5;
+    auto drain = [&](int piece) __attribute__((always_inline)) {     // piece: compile-time after unrolling
+      constexpr int PER = 64 / DS;
+      if (!pk_valid) return;
+      __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)pk_b * a.Cout * L, 0, a.Cout * L * 4, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int f = piece * PER + u;
+        const int mi = f >> 5, ni = (f >> 4) & 1, r = f & 15;
+        const int row8 = pk_mrow + mi * 32 + 8 * (r >> 2);             // first of the 8 rows this register group covers
+        if (mi < pk_nt && ni < pk_nt && row8 < a.Cout && pk_lcol + ni * 32 < L) {   // wave-uniform (Cout % 8 == 0, L % 32 == 0)
+          const float b_lo = bias_r[row8 + (r & 3)], b_hi = bias_r[row8 + (r & 3) + 4];   // scalar loads (uniform address)
+          const float o = park[mi][ni][r] + (lhalf ? b_hi : b_lo);
+          const int soff = ((mi * 32 + 8 * (r >> 2) + (r & 3)) * L + ni * 32) * 4;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), yrs, pk_vo, soff, 0);
+          pk_s += o;
+          pk_sq = fmaf(o, o, pk_sq);
+        }
+      }
+      if (piece == DS - 1) {
+        if (a.out_sums) {
+          const double ds = srf_dpp_wave_sum((double)pk_s), dq = srf_dpp_wave_sum((double)pk_sq);
+          if (lane == 63) {
+            double* dst = srf_stat_slot(a.out_sums, pk_b, (long)pk_v * 32 + wave + (pk_q >= 0 ? 8 * (pk_q + 1) : 0));
+            atomicAdd(dst, ds);
+            atomicAdd(dst + 1, dq);
+          }
+        }
+        pk_valid = false;
+      }
+    };
+    auto dstep = [&](Regs& nx, int kt, auto full_tag, bool pref) __attribute__((always_inline)) {
+      const int s1 = s0 == W_NSTAGE - 1 ? 0 : s0 + 1, s2 = s1 == W_NSTAGE - 1 ? 0 : s1 + 1;
+      int k1, k2, k3;
+      const TileP t1 = pick(kt + 1, k1), t2 = pick(kt + 2, k2), t3 = pick(kt + 3, k3);
+      // (fragments read just in time, one set of 32 registers: the parked tile occupies the second set's room)
+      read_frags(f0, s0, 0, full_tag);
+      lds_store(nx, t1, k1, s1);
+      gload_a(t2, k2, s2);
+      gload_b(nx, t3, k3);
+      mma(f0, full_tag);
+      read_frags(f0, s0, 1, full_tag);
+      mma(f0, full_tag);
+      asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      s0 = s1;
+    };
+    for (int i = 0; cur.v >= 0; ++i) {
+      const bool quarter = cur.q >= 0;
+      set_off(quarter);
+      auto k_loop = [&](auto full_tag) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < DS; s += 2) {            // the first DS steps: one parked piece leaves ahead of each
+          drain(s);
+          dstep(r1, s, full_tag, true);
+          drain(s + 1);
+          dstep(r0, s + 1, full_tag, s + 2 < nk);
+        }
+        for (int kt = DS; kt < nk; kt += 2) {
+          dstep(r1, kt, full_tag, true);
+          dstep(r0, kt + 1, full_tag, kt + 2 < nk);
+        }
+      };
+      if (quarter)
+        k_loop(F{});
+      else
+        k_loop(T{});
+      TileCur nnc = nxc;
+      if (i + 2 < ntile) cur_next(nnc);
+      else nnc.v = -1;
+      const bool has_nn = nnc.v >= 0 && nxc.v >= 0;
+      const TileP tnn = has_nn ? make_tile(nnc) : tn;
+      // park the finished tile: it leaves during the next tile's k-loop (or below, after the last tile)
+      const int m0 = cur.mt * W_BM;
+      const int l0 = cur.lt * W_BN + (quarter ? cur.q * 32 : 0);
+      pk_nt = quarter ? 1 : 2;
+      pk_mrow = quarter ? m0 + wave * 32 : m0 + wm * 64;
+      pk_lcol = quarter ? l0 : l0 + wn * 64;
+      pk_b = cur.b;
+      pk_v = cur.v;
+      pk_q = cur.q;
+      pk_vo = ((pk_mrow + 4 * lhalf) * L + pk_lcol + (lane & 31)) * 4;
+      pk_s = 0.f;
+      pk_sq = 0.f;
+      pk_valid = true;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          park[mi][ni] = acc[mi][ni];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+      cur = nxc;
+      nxc = nnc;
+      tc = tn;
+      tn = tnn;
+    }
+#pragma unroll
+    for (int s = 0; s < DS; ++s) drain(s);           // the last tile of the block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   for (int i = 0; cur.v >= 0; ++i) {
     const bool quarter = cur.q >= 0;
     int drawn = 0;                        // DYN: the code of item i + 2, drawn now, published before the tile's last barrier
@@ -497,7 +621,12 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
               epi_col(ni, lc);
               if (ext && mi < NT && ni < NT) {
                 const int me = is_res ? mc : mc % extC;
-                rext[mi][ni][ii] = *reinterpret_cast<const float4*>(extb + me * L + lc);
+                if constexpr (CP & 8) {
+                  typedef float f32x4v __attribute__((ext_vector_type(4)));
+                  const f32x4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(extb + me * L + lc));
+                  rext[mi][ni][ii] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                } else
+                  rext[mi][ni][ii] = *reinterpret_cast<const float4*>(extb + me * L + lc);
               } else {
                 rext[mi][ni][ii] = make_float4(0.f, 0.f, 0.f, 0.f);
               }
@@ -574,7 +703,16 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
               int mc, lc;
               const bool okr = epi_row(mi, ii, mc), okc = epi_col(ni, lc);
               if (okr && okc) {
-                *reinterpret_cast<float4*>(yb + mc * L + lc) = o;
+                if constexpr ((CP & 3) == 0) {
+                  *reinterpret_cast<float4*>(yb + mc * L + lc) = o;
+                } else {
+                  // cache-policy experiment: the output tensor is written once and read by a LATER kernel -- keep it from
+                  // displacing the L2-resident weight image that every CU re-reads for every tile
+                  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                  const u32x4 ov = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                  __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, a.Cout * L * 4, 0x00020000);
+                  __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, (mc * L + lc) * 4, 0, (CP & 3) == 1 ? 2 : (CP & 3) == 2 ? 16 : 18);
+                }
                 s += (o.x + o.y) + (o.z + o.w);
                 q = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, fmaf(o.w, o.w, q))));
               }
@@ -635,7 +773,27 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   const long ok = srf_device_cached(3, [](void*) -> long {
     const int bytes = W_NSTAGE * W_STAGE + W_MAX_STAT_EXAMPLES * (int)sizeof(float2) + 16;
     bool good = true;
-    const void* fns[] = {(const void*)&srf_pw_x3w_kernel<0, 0, 0, true>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, true>,
+    const void* fns[] = {(const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 0, 1>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 0, 4>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 0, 5>,
+                         (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 0, 1>,
+                         (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 0, 4>,
+                         (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 0, 5>,
+                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 1>,
+                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 4>,
+                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 5>,
+                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 8>,
+                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 12>,
+                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 13>,
+                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 1>,
+                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 4>,
+                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 5>,
+                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 8>,
+                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 12>,
+                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 13>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 8>, (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 16>,
+                         (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 8>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 16>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 0, true>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, true>,
                          (const void*)&srf_pw_x3w_kernel<2, 1, 0, true>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, true>,
                          (const void*)&srf_pw_x3w_kernel<0, 3, 0, true>, (const void*)&srf_pw_x3w_kernel<1, 3, 0, true>,
                          (const void*)&srf_pw_x3w_kernel<2, 3, 0, true>, (const void*)&srf_pw_x3w_kernel<3, 3, 0, true>,
@@ -683,8 +841,8 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
     static std::atomic<unsigned> seq{0};
     ctr = reinterpret_cast<unsigned*>(base) + 16 * (seq.fetch_add(1, std::memory_order_relaxed) % W_CTR_SLOTS);
   }
-#define W_GO(P, E, A) do { if (dyn && (A) == 0) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, true>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, ctr); \
-    else hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, false>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, (unsigned*)nullptr); } while (0)
+#define W_GO(P, E, A) do { if (dyn && (A) == 0) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, true>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, ctr, a.bias); \
+    else hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, false>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, (unsigned*)nullptr, a.bias); } while (0)
   // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated below)
   const int abl = (srf_debug_flags() >> 16) & 63;
   if (abl && pro == 2 && res) {
@@ -718,6 +876,45 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
     SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
     return SRF_OK;
   }
+  // Cache policy (CP) of the four model forms: bit 0 = non-temporal output stores, bit 2 = non-temporal activation loads,
+  // bit 3 = non-temporal residual / mask-multiplier loads.  Every CU re-reads the whole packed weight image from L2 for every
+  // tile, while activations, residuals and outputs stream through once: marked non-temporal they stop displacing the weights.
+  // Defaults = the fastest of each form in the same-box A/B of tools/gemm_ab.py (round 3); debug flag bits 26..29 = CP + 1 override.
+  const int cp_flag = (srf_debug_flags() >> 26) & 15;
+  const bool model_form = !dyn && !(srf_debug_flags() & (1 << 24)) && ((pro == 0 && !res && !mask) || (pro == 1 && !res && !mask) || (pro == 2 && res) || (pro == 3 && mask));
+  if (model_form) {
+    static const int kDefaultCp[4] = {0, 5, 5, 5};
+    const int cp = cp_flag ? cp_flag - 1 : kDefaultCp[pro];
+#define W_CP(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, false, 0, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, (unsigned*)nullptr, a.bias)
+#define W_CP4(P, E) switch (cp & 7) { case 1: W_CP(P, E, 1); break; case 4: W_CP(P, E, 4); break; case 5: W_CP(P, E, 5); break; default: W_CP(P, E, 0); break; }
+#define W_CP7(P, E) switch (cp) { case 1: W_CP(P, E, 1); break; case 4: W_CP(P, E, 4); break; case 5: W_CP(P, E, 5); break; \
+      case 8: W_CP(P, E, 8); break; case 12: W_CP(P, E, 12); break; case 13: W_CP(P, E, 13); break; default: W_CP(P, E, 0); break; }
+    if (cp != 0 || true) {
+      if (pro == 0) { W_CP4(0, 0) }
+      else if (pro == 1) { W_CP4(1, 0) }
+      else if (pro == 2) { W_CP7(2, 1) }
+      else { W_CP7(3, 2) }
+      static const char* const kCp[4] = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_conv_x3v<3>"};
+      SRF_CHECK_LAUNCH(kCp[pro], st);
+      return SRF_OK;
+    }
+#undef W_CP7
+#undef W_CP4
+#undef W_CP
+  }
+  // DRIP epilogue (bias + statistics launches: proj_1x1, bottleneck): debug flag 1 << 24
+  const int nk = a.Cin / W_BK;
+  const bool drip_ok = !dyn && !res && !mask && (a.Cout % 8 == 0) && (a.L % 32 == 0) && nk >= 8 && (nk % 2 == 0) &&
+                       (long)a.Cout * a.L * 4 < (1L << 31) && (srf_debug_flags() & (1 << 24));
+#define W_DRIP(P, D) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, 0, 0, false, D>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, (unsigned*)nullptr, a.bias)
+  if (drip_ok && (pro == 0 || pro == 1)) {
+    if (pro == 0) { if (nk >= 16) W_DRIP(0, 16); else W_DRIP(0, 8); }
+    else { if (nk >= 16) W_DRIP(1, 16); else W_DRIP(1, 8); }
+    static const char* const kDrip[2] = {"pw_conv_x3v<0>", "pw_conv_x3v<1>"};
+    SRF_CHECK_LAUNCH(kDrip[pro], st);
+    return SRF_OK;
+  }
+#undef W_DRIP
   // the forms the models use are specialised on their epilogue; anything else runs the run-time-switched one
   if (pro == 0 && !res && !mask) W_GO(0, 0, 0);
   else if (pro == 1 && !res && !mask) W_GO(1, 0, 0);
