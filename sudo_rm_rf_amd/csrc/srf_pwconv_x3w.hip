@@ -373,6 +373,14 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     t.rstd = nx ? tn.rstd : tc.rstd;
     return t;
   };
+  // ---- in-kernel timeline (ABL & 64, diagnostics; results stay correct).  Three registers used as 64-entry arrays (entry =
+  // lane): tl_wait[kt] / tl_bar[kt] = shader cycles every wavefront spent in the step's counted wait / in its barrier, summed
+  // over the block's tiles, by k-step of the tile (kt < 32); tl_abs[3 t .. 3 t + 2] = s_memrealtime (100 MHz, one clock for the
+  // whole chip) at the start / k-loop end / epilogue end of the block's tile t (t < 20).  Written to `a.mul` at the end.
+  unsigned tl_wait = 0, tl_bar = 0, tl_abs = 0;
+  auto tl_put = [&](unsigned& arr, int idx, unsigned val, bool add) __attribute__((always_inline)) {
+    arr = (lane == idx) ? (add ? arr + val : val) : arr;
+  };
   auto step = [&](Regs& nx, int kt, auto full_tag, auto have0_tag, auto pref_tag) __attribute__((always_inline)) {
     constexpr bool HAVE0 = decltype(have0_tag)::value, PREF = decltype(pref_tag)::value;
     const int s1 = s0 == W_NSTAGE - 1 ? 0 : s0 + 1, s2 = s1 == W_NSTAGE - 1 ? 0 : s1 + 1;
@@ -380,7 +388,15 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     const TileP t1 = pick(kt + 1, k1), t2 = pick(kt + 2, k2), t3 = pick(kt + 3, k3);
     if constexpr (!HAVE0) read_frags(f0, s0, 0, full_tag);
     if constexpr (HAVE0) read_frags(f1, s0, 1, full_tag);
-    lds_store(nx, t1, k1, s1);
+    if constexpr (ABL & 64) {      // how long the step sits in the activation conversion (its wait for the loads of two steps ago)
+      const unsigned ta = (unsigned)__builtin_amdgcn_s_memtime();
+      lds_store(nx, t1, k1, s1);
+      const unsigned tb = (unsigned)__builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tl_put(tl_bar, 32 + (kt & 31), tb - ta, true);
+    } else {
+      lds_store(nx, t1, k1, s1);
+    }
     gload_a(t2, k2, s2);
     gload_b(nx, t3, k3);
     mma(f0, full_tag);
@@ -388,8 +404,19 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       read_frags(f1, s0, 1, full_tag);
       mma(f1, full_tag);
     }
-    asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (ABL & 64) {
+      const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+      const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      const unsigned t2 = (unsigned)__builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tl_put(tl_wait, kt & 31, t1 - t0, true);
+      tl_put(tl_bar, kt & 31, t2 - t1, true);
+    } else {
+      asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     if constexpr (PREF) read_frags(f0, s1, 0, full_tag);     // next k-tile's first half, under this one's second
     if constexpr (HAVE0) mma(f1, full_tag);
     s0 = s1;
@@ -635,6 +662,11 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
         }
       }
     };
+    unsigned tl_c0 = 0;
+    if constexpr (ABL & 64) {
+      if (i < 20) tl_put(tl_abs, 3 * i, (unsigned)__builtin_amdgcn_s_memrealtime(), false);
+      tl_c0 = (unsigned)__builtin_amdgcn_s_memtime();
+    }
     auto k_loop = [&](auto full_tag) __attribute__((always_inline)) {
       read_frags(f0, s0, 0, full_tag);     // this tile's k-tile 0 (complete since the barrier that ended the previous tile)
       for (int kt = 0; kt + 4 < nk; kt += 2) {
@@ -655,6 +687,10 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       k_loop(F{});
     else
       k_loop(T{});
+    if constexpr (ABL & 64) {
+      if (i < 20) tl_put(tl_abs, 3 * i + 1, (unsigned)__builtin_amdgcn_s_memrealtime(), false);
+      if (i < 20) tl_put(tl_wait, 32 + i, (unsigned)__builtin_amdgcn_s_memtime() - tl_c0, false);   // k-loop shader cycles of tile i
+    }
     // parameters of the tile after next (LDS table + integer arithmetic: no memory wait)
     TileCur nnc = nxc;
     if constexpr (DYN) {
@@ -703,7 +739,9 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
               int mc, lc;
               const bool okr = epi_row(mi, ii, mc), okc = epi_col(ni, lc);
               if (okr && okc) {
-                if constexpr ((CP & 3) == 0) {
+                if constexpr (ABL & 128) {
+                  asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));   // diagnostics: epilogue without its stores
+                } else if constexpr ((CP & 3) == 0) {
                   *reinterpret_cast<float4*>(yb + mc * L + lc) = o;
                 } else {
                   // cache-policy experiment: the output tensor is written once and read by a LATER kernel -- keep it from
@@ -744,8 +782,17 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     // strip reads done before the next step's DMA overwrites that stage
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (ABL & 64) {
+      if (i < 20) tl_put(tl_abs, 3 * i + 2, (unsigned)__builtin_amdgcn_s_memrealtime(), false);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus DMA of the pipeline tail must not outlive the block's LDS
+  if constexpr (ABL & 64) {
+    unsigned* out = reinterpret_cast<unsigned*>(const_cast<float*>(a.mul)) + ((size_t)blockIdx.x * 8 + wave) * 192;
+    out[lane] = tl_wait;
+    out[64 + lane] = tl_bar;
+    out[128 + lane] = tl_abs;
+  }
   if constexpr (DYN) {
     // the last block out re-zeroes the queue heads (every block's draws are behind it): the slot is clean for its next launch
     if (tid == 0 && atomicAdd(&ctr[8], 1u) == (unsigned)nblk - 1) {
@@ -791,6 +838,8 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
                          (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 8>,
                          (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 12>,
                          (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 13>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 64>, (const void*)&srf_pw_x3w_kernel<2, 1, 64>,
+                         (const void*)&srf_pw_x3w_kernel<0, 0, 192>,
                          (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 8>, (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 16>,
                          (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 8>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 16>,
                          (const void*)&srf_pw_x3w_kernel<0, 0, 0, true>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, true>,
@@ -844,7 +893,8 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
 #define W_GO(P, E, A) do { if (dyn && (A) == 0) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, true>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, ctr, a.bias); \
     else hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, false>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, (unsigned*)nullptr, a.bias); } while (0)
   // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated below)
-  const int abl = (srf_debug_flags() >> 16) & 63;
+  const int abl = ((srf_debug_flags() >> 16) & 63) | ((srf_debug_flags() & (1 << 25)) ? 64 : 0) |
+                  ((srf_debug_flags() & (1 << 30)) ? 128 : 0);   // (flag 1 << 25: timeline, 1 << 30: epilogue without stores)
   if (abl && pro == 2 && res) {
     switch (abl) {
       case 3: W_GO(2, 1, 3); break;
@@ -853,6 +903,7 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
       case 19: W_GO(2, 1, 19); break;
       case 20: W_GO(2, 1, 20); break;
       case 23: W_GO(2, 1, 23); break;
+      case 64: W_GO(2, 1, 64); break;
       default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for res_conv", abl);
     }
     SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
@@ -871,6 +922,8 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
       case 31: W_GO(0, 0, 31); break;
       case 55: W_GO(0, 0, 55); break;
       case 63: W_GO(0, 0, 63); break;
+      case 64: W_GO(0, 0, 64); break;
+      case 192: W_GO(0, 0, 192); break;
       default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for proj_1x1", abl);
     }
     SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
