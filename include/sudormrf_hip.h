@@ -112,7 +112,6 @@ int srf_profile_get(int i, const char** name, float* ms);
  *   256      leftover GEMM tiles as whole tiles (no quarter tiles) 512       quarter tiles last
  *   1024     TAC forward with one time step per lane               2048      one-tile-per-block GEMM everywhere
  *   16384    round 2's 256 x 128 GEMM (srf_pwconv_x3v.hip) instead of round 3's (srf_pwconv_x3w.hip)
- *   32768    round 3's GEMM with per-XCD work queues + phase seeds instead of the static tile deal (slower: srf_pwconv_x3w.hip)
  *   bits 12-13, 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating)
  *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
  *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)

@@ -20,9 +20,15 @@
 //      the matrix pipe idle.  The fragments of a k-tile's first half are now requested BEHIND the barrier that completes the
 //      tile, under the MFMAs of the previous tile's second half (two fragment sets of 32 registers; the last two steps of a tile,
 //      where the epilogue's operands are in flight, read just in time instead).
+// Measured and removed again, round 3 (all bit-identical to this kernel; code: git tag r3-gemm-experiments, numbers:
+// profiles/r03_NOTES.md): a DRIP epilogue (a finished tile's accumulators parked in 64 registers and stored during the next
+// tile's first 8 / 16 k-steps as dword buffer stores straight from the MFMA layout: proj_1x1 138 vs 119 us), per-XCD WORK
+// QUEUES with phase seeds (blocks start out of phase on 0-3 quarter tiles, then draw tiles with one atomicAdd each: 125 vs
+// 115 us -- a quarter tile costs ~0.6 of a full tile's time), start-up stagger (114-121 vs 108 us).  Why none of the
+// re-orderings pays: these launches run at the package power cap (1.35 kW of 1.4 kW, shader clock 1.3 GHz), so their
+// time follows the work, not its schedule.
 // The round-2 kernel stays in the library (debug flag 16384) for same-box A/B runs.
 // Prologue / epilogue semantics are those of srf_pw.h (PwArgs).
-#include <atomic>
 #include <type_traits>
 
 #include "srf_pw.h"
@@ -56,16 +62,11 @@ __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8
 // split / ds_write, 16 = no epilogue, 32 = no fragment reads.
 // gamma / beta come again as noalias kernel arguments so that they are fetched with scalar loads.
 // Work distribution, barrier protocol and LDS images: see srf_pwconv_x3v.hip (unchanged).
-// DYN: tiles come from per-XCD work queues (`ctr`: 8 queue heads + a done counter, zero between launches) instead of the static
-// round-robin deal -- see "Work distribution" below.
-// DS: 0 = the tile's outputs leave in a burst after its k-loop (strips, float4 stores); 8 / 16 = DRIP epilogue: the finished
-// accumulators are parked in 64 registers and leave 64 / DS registers per step during the first DS steps of the NEXT tile's
-// k-loop, as dword buffer stores straight from the MFMA layout (see the drip block in the kernel).
-template <int PRO, int EPI, int ABL = 0, bool DYN = false, int DS = 0, int CP = 0>
+// CP: cache policy of the streamed tensors (see the launch function).
+template <int PRO, int EPI, int ABL = 0, int CP = 0>
 __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt,
                                                             int total, int rounds, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, unsigned* __restrict__ ctr,
-                                                            const float* __restrict__ bias_r) {
+                                                            const float* __restrict__ beta) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // W_NSTAGE * W_STAGE (+ the statistics table)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -153,54 +154,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     c.lt -= cy ? nLt : 0;
     c.b += st_b + cy;
   };
-  // ---- Work distribution, DYN (round 3).  Why: with the static deal every CU runs the same program at the same time -- all
-  // k-loops together, then all epilogues together -- so the chip's 32 MB of tile outputs (+ 32 MB of residual reads) move in a
-  // burst while the matrix pipes idle, and vmcnt counts loads and stores in order: the first operand loads requested after an
-  // epilogue cannot be consumed before that epilogue's stores have retired (ablation, tools/gemm_ab.py, proj_1x1: k-loop memory
-  // pipeline alone 47 us, epilogue alone 49 us, both 99 us over a 27 us base; a start-up stagger of up to 29 us cost 12 us).
-  // Now the XCD's blocks start OUT OF PHASE without idling: block j (of the XCD's nbx) first runs j % 4 quarter tiles (0 .. 3/4 of
-  // a tile of work, reserved at the end of the XCD's tile range), then draws full tiles from the XCD's queue head (one returning
-  // atomicAdd per tile, two tiles ahead of use), then quarter tiles of the last nbx / 4 tiles: no block ever waits for
-  // another, the phases stay spread because every block keeps its own pace, and the tail is balanced to a quarter tile.
-  // Queue of XCD x (blocks with blockIdx % 8 == x: the dispatcher's placement -- an assumption about SPEED only): the virtual
-  // tile ids srf_xcd_remap gives that XCD, [base, base + W): [0, NF) full tiles | [NF, NF + Tq) as 4 Tq quarter items | the
-  // rest as seed quarters.  An item code >= 0 is an index into the dynamic part, < 0 a seed quarter.
-  const int xq = blockIdx.x & 7, jq = blockIdx.x >> 3, nbx = nblk >> 3;
-  const int d_qn = total >> 3, d_rn = total & 7;
-  const int d_base = xq < d_rn ? xq * (d_qn + 1) : d_rn * (d_qn + 1) + (xq - d_rn) * d_qn;
-  const int d_W = d_qn + (xq < d_rn ? 1 : 0);
-  const bool seed_on = (nbx & 7) == 0 && d_W >= 3 * nbx;
-  const int d_seedT = seed_on ? (nbx >> 2) * 6 / 4 : 0;                 // 6 seed quarters per 4 blocks
-  const int d_Tq = seed_on ? nbx >> 2 : d_W % nbx;                      // tail tiles dealt as quarters
-  const int d_NF = d_W - d_seedT - d_Tq;
-  const int d_items = d_NF + 4 * d_Tq;
-  const int d_nseed = seed_on ? (jq & 3) : 0;
-  const int d_seed0 = (jq >> 2) * 6 + ((jq & 3) * ((jq & 3) - 1)) / 2;
-  int* code_box = reinterpret_cast<int*>(smem + W_NSTAGE * W_STAGE + ((PRO == 1 || PRO == 2) ? a.Bt * 8 : 0));   // 4 ints
-  auto decode = [&](TileCur& c, int i, int code) {
-    c.i = i;
-    c.q = -1;
-    int v = -1;
-    if (code < 0) {
-      const int qi = -1 - code;
-      v = d_base + d_NF + d_Tq + (qi >> 2);
-      c.q = qi & 3;
-    } else if (code < d_NF) {
-      v = d_base + code;
-    } else if (code < d_items) {
-      const int qi = code - d_NF;
-      v = d_base + d_NF + (qi >> 2);
-      c.q = qi & 3;
-    }
-    if (v >= 0) cur_from_v(c, v);
-    c.v = v;
-  };
-  // item n of this block: a seed quarter while n < d_nseed, else the next dynamic item (one lane draws; >= d_items: no more work)
-  auto draw = [&](int n) -> int {
-    if (n < d_nseed) return -1 - (d_seed0 + n);
-    return (int)atomicAdd(&ctr[xq], 1u);
-  };
-
   // ---- B staging geometry: thread -> time step n = tid & 127, k-group kg = tid >> 7 (wave-uniform), 8 k rows
   const int b_n = tid & 127, b_c = wave >> 1, b_kg = b_c * 8;
   const int b_lds = 2 * W_A_IMG + w_swz(b_n, b_c);
@@ -423,22 +376,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   };
 
   TileCur cur, nxc;
-  if constexpr (DYN) {
-    if (tid == 0) {
-      code_box[0] = draw(0);
-      code_box[1] = draw(1);
-    }
-    __syncthreads();
-    decode(cur, 0, code_box[0]);
-    decode(nxc, 1, code_box[1]);
-    __syncthreads();                      // (the boxes are rewritten during the first tile)
-    if (cur.v < 0) {                      // nothing left for this block (more blocks than work items): only the bookkeeping
-      if (tid == 0 && atomicAdd(&ctr[8], 1u) == (unsigned)nblk - 1) {
-        for (int i = 0; i < 9; ++i) ctr[i] = 0;
-      }
-      return;
-    }
-  } else {
+  {
     cur_set(cur, 0);
     nxc = cur;
     if (ntile > 1) cur_next(nxc);
@@ -462,132 +400,8 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
 
   using T = std::true_type;
   using F = std::false_type;
-  if constexpr (DS > 0) {
-    // ================= DRIP epilogue (EPI 0: bias + statistics) =================
-    // Why: vmcnt counts loads and stores in order, so operand loads requested after an epilogue's stores cannot be consumed
-    // before those stores have retired, and a tile's 128 KB per CU retire at the chip's write rate (~4.3 TB/s: 49 us for
-    // proj_1x1's 210 MB on their own, tools/gemm_ab.py).  Burst epilogues therefore serialise with the k-loops (ablation:
-    // loads alone 47 us, epilogue alone 49 us, both 99 us).  Here a finished tile's accumulators are PARKED (64 registers) and
-    // written during the next tile's first DS k-steps, 64 / DS registers per step, as dword buffer stores straight from the
-    // MFMA C layout (a register = 2 rows x 32 columns = two full 128-byte lines), at the START of each step: the stores of
-    // step g are older than the DMA of step g, so the step's counted wait (vmcnt(20)) never covers them and they have two
-    // full steps to retire -- 16 KB per CU and step, i.e. the chip's write rate spread evenly over the launch.
-    // The k-loop's first DS steps are unrolled so that every parked register has a compile-time index.
-    f32x16 park[2][2];
-    bool pk_valid = false;
-    int pk_nt = 0, pk_mrow = 0, pk_lcol = 0, pk_v = 0, pk_q = 0;
-    long pk_b = 0;
-    int pk_vo = 0;                         // per-lane byte offset of (row pk_mrow + 4 * (lane >> 5), column pk_lcol + (lane & 31))
-    float pk_s = 0.f, pk_sq = 0.f;
-    const int lhalf = lane >> 5;
-    auto drain = [&](int piece) __attribute__((always_inline)) {     // piece: compile-time after unrolling
-      constexpr int PER = 64 / DS;
-      if (!pk_valid) return;
-      __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)pk_b * a.Cout * L, 0, a.Cout * L * 4, 0x00020000);
-#pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int f = piece * PER + u;
-        const int mi = f >> 5, ni = (f >> 4) & 1, r = f & 15;
-        const int row8 = pk_mrow + mi * 32 + 8 * (r >> 2);             // first of the 8 rows this register group covers
-        if (mi < pk_nt && ni < pk_nt && row8 < a.Cout && pk_lcol + ni * 32 < L) {   // wave-uniform (Cout % 8 == 0, L % 32 == 0)
-          const float b_lo = bias_r[row8 + (r & 3)], b_hi = bias_r[row8 + (r & 3) + 4];   // scalar loads (uniform address)
-          const float o = park[mi][ni][r] + (lhalf ? b_hi : b_lo);
-          const int soff = ((mi * 32 + 8 * (r >> 2) + (r & 3)) * L + ni * 32) * 4;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), yrs, pk_vo, soff, 0);
-          pk_s += o;
-          pk_sq = fmaf(o, o, pk_sq);
-        }
-      }
-      if (piece == DS - 1) {
-        if (a.out_sums) {
-          const double ds = srf_dpp_wave_sum((double)pk_s), dq = srf_dpp_wave_sum((double)pk_sq);
-          if (lane == 63) {
-            double* dst = srf_stat_slot(a.out_sums, pk_b, (long)pk_v * 32 + wave + (pk_q >= 0 ? 8 * (pk_q + 1) : 0));
-            atomicAdd(dst, ds);
-            atomicAdd(dst + 1, dq);
-          }
-        }
-        pk_valid = false;
-      }
-    };
-    auto dstep = [&](Regs& nx, int kt, auto full_tag, bool pref) __attribute__((always_inline)) {
-      const int s1 = s0 == W_NSTAGE - 1 ? 0 : s0 + 1, s2 = s1 == W_NSTAGE - 1 ? 0 : s1 + 1;
-      int k1, k2, k3;
-      const TileP t1 = pick(kt + 1, k1), t2 = pick(kt + 2, k2), t3 = pick(kt + 3, k3);
-      // (fragments read just in time, one set of 32 registers: the parked tile occupies the second set's room)
-      read_frags(f0, s0, 0, full_tag);
-      lds_store(nx, t1, k1, s1);
-      gload_a(t2, k2, s2);
-      gload_b(nx, t3, k3);
-      mma(f0, full_tag);
-      read_frags(f0, s0, 1, full_tag);
-      mma(f0, full_tag);
-      asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      s0 = s1;
-    };
-    for (int i = 0; cur.v >= 0; ++i) {
-      const bool quarter = cur.q >= 0;
-      set_off(quarter);
-      auto k_loop = [&](auto full_tag) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < DS; s += 2) {            // the first DS steps: one parked piece leaves ahead of each
-          drain(s);
-          dstep(r1, s, full_tag, true);
-          drain(s + 1);
-          dstep(r0, s + 1, full_tag, s + 2 < nk);
-        }
-        for (int kt = DS; kt < nk; kt += 2) {
-          dstep(r1, kt, full_tag, true);
-          dstep(r0, kt + 1, full_tag, kt + 2 < nk);
-        }
-      };
-      if (quarter)
-        k_loop(F{});
-      else
-        k_loop(T{});
-      TileCur nnc = nxc;
-      if (i + 2 < ntile) cur_next(nnc);
-      else nnc.v = -1;
-      const bool has_nn = nnc.v >= 0 && nxc.v >= 0;
-      const TileP tnn = has_nn ? make_tile(nnc) : tn;
-      // park the finished tile: it leaves during the next tile's k-loop (or below, after the last tile)
-      const int m0 = cur.mt * W_BM;
-      const int l0 = cur.lt * W_BN + (quarter ? cur.q * 32 : 0);
-      pk_nt = quarter ? 1 : 2;
-      pk_mrow = quarter ? m0 + wave * 32 : m0 + wm * 64;
-      pk_lcol = quarter ? l0 : l0 + wn * 64;
-      pk_b = cur.b;
-      pk_v = cur.v;
-      pk_q = cur.q;
-      pk_vo = ((pk_mrow + 4 * lhalf) * L + pk_lcol + (lane & 31)) * 4;
-      pk_s = 0.f;
-      pk_sq = 0.f;
-      pk_valid = true;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          park[mi][ni] = acc[mi][ni];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        }
-      cur = nxc;
-      nxc = nnc;
-      tc = tn;
-      tn = tnn;
-    }
-#pragma unroll
-    for (int s = 0; s < DS; ++s) drain(s);           // the last tile of the block
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-  }
   for (int i = 0; cur.v >= 0; ++i) {
     const bool quarter = cur.q >= 0;
-    int drawn = 0;                        // DYN: the code of item i + 2, drawn now, published before the tile's last barrier
-    if constexpr (DYN) {
-      if (tid == 0) drawn = draw(i + 2);
-    }
     set_off(quarter);
     const int m0 = cur.mt * W_BM, v = cur.v;
     const int l0 = cur.lt * W_BN + (quarter ? cur.q * 32 : 0);
@@ -677,9 +491,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       step(r0, nk - 3, full_tag, T{}, F{});      // last prefetching step: nothing requested for k-tile nk-2
       epi_issue(std::integral_constant<int, 0>{});
       step(r1, nk - 2, full_tag, F{}, F{});
-      if constexpr (DYN) {
-        if (tid == 0) code_box[2 + (i & 1)] = drawn;     // read by everyone behind the next barrier (the draw is ~nk steps old)
-      }
       step(r0, nk - 1, full_tag, F{}, F{});
       if constexpr (kHasExt) epi_issue(std::integral_constant<int, 1>{});
     };
@@ -693,12 +504,8 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     }
     // parameters of the tile after next (LDS table + integer arithmetic: no memory wait)
     TileCur nnc = nxc;
-    if constexpr (DYN) {
-      if (nxc.v >= 0) decode(nnc, i + 2, code_box[2 + (i & 1)]);
-    } else {
-      if (i + 2 < ntile) cur_next(nnc);
-      else nnc.v = -1;
-    }
+    if (i + 2 < ntile) cur_next(nnc);
+    else nnc.v = -1;
     const bool has_nn = nnc.v >= 0 && nxc.v >= 0;
     const TileP tnn = has_nn ? make_tile(nnc) : tn;
     // epilogue through wave-private strips in the stage the tile's last k-tile has just freed
@@ -793,19 +600,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     out[64 + lane] = tl_bar;
     out[128 + lane] = tl_abs;
   }
-  if constexpr (DYN) {
-    // the last block out re-zeroes the queue heads (every block's draws are behind it): the slot is clean for its next launch
-    if (tid == 0 && atomicAdd(&ctr[8], 1u) == (unsigned)nblk - 1) {
-      for (int i = 0; i < 9; ++i) ctr[i] = 0;
-    }
-  }
 }
-
-// Work-queue heads of the DYN kernels: one 64-byte slot per launch in flight (8 queue heads + a done counter, all zero between
-// launches: the last block out of a launch re-zeroes its slot).  Launches take slots round-robin; a slot is reused 1024
-// launches later.  Device memory is per GPU, the sequence number per process.
-constexpr int W_CTR_SLOTS = 1024;
-__device__ unsigned g_x3w_ctr[W_CTR_SLOTS][16];
 
 bool srf_x3w_supported(int Bt, int pro) { return !(pro == 1 || pro == 2) || Bt <= W_MAX_STAT_EXAMPLES; }
 
@@ -815,50 +610,38 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
   SRF_CHECK_ARG((long)a.Bt * a.Cin * a.L * 4 < (1L << 31), "srf_pw_conv: activation tensor too large for buffer loads");
   SRF_CHECK_ARG(srf_x3w_supported(a.Bt, pro), "srf_pw_conv: too many examples for the statistics table");
-  const size_t lds = (size_t)W_NSTAGE * W_STAGE + ((pro == 1 || pro == 2) ? (size_t)a.Bt * sizeof(float2) : 0) + 16;
+  const size_t lds = (size_t)W_NSTAGE * W_STAGE + ((pro == 1 || pro == 2) ? (size_t)a.Bt * sizeof(float2) : 0);
   // dynamic LDS beyond 64 KB needs the attribute once per device (per-device cache, srf_common.h)
   const long ok = srf_device_cached(3, [](void*) -> long {
-    const int bytes = W_NSTAGE * W_STAGE + W_MAX_STAT_EXAMPLES * (int)sizeof(float2) + 16;
+    const int bytes = W_NSTAGE * W_STAGE + W_MAX_STAT_EXAMPLES * (int)sizeof(float2);
     bool good = true;
-    const void* fns[] = {(const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 0, 1>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 0, 4>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 0, 5>,
-                         (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 0, 1>,
-                         (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 0, 4>,
-                         (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 0, 5>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 1>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 4>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 5>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 8>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 12>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, false, 0, 13>,
-                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 1>,
-                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 4>,
-                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 5>,
-                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 8>,
-                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 12>,
-                         (const void*)&srf_pw_x3w_kernel<3, 2, 0, false, 0, 13>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 64>, (const void*)&srf_pw_x3w_kernel<2, 1, 64>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 192>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 8>, (const void*)&srf_pw_x3w_kernel<0, 0, 0, false, 16>,
-                         (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 8>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, false, 16>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 0, true>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, true>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 0, true>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, true>,
-                         (const void*)&srf_pw_x3w_kernel<0, 3, 0, true>, (const void*)&srf_pw_x3w_kernel<1, 3, 0, true>,
-                         (const void*)&srf_pw_x3w_kernel<2, 3, 0, true>, (const void*)&srf_pw_x3w_kernel<3, 3, 0, true>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0>, (const void*)&srf_pw_x3w_kernel<1, 0>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1>, (const void*)&srf_pw_x3w_kernel<3, 2>,
-                         (const void*)&srf_pw_x3w_kernel<0, 3>, (const void*)&srf_pw_x3w_kernel<1, 3>,
-                         (const void*)&srf_pw_x3w_kernel<2, 3>, (const void*)&srf_pw_x3w_kernel<3, 3>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 3>, (const void*)&srf_pw_x3w_kernel<2, 1, 4>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 16>, (const void*)&srf_pw_x3w_kernel<2, 1, 19>,
-                         (const void*)&srf_pw_x3w_kernel<2, 1, 20>, (const void*)&srf_pw_x3w_kernel<2, 1, 23>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 3>, (const void*)&srf_pw_x3w_kernel<0, 0, 4>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 7>, (const void*)&srf_pw_x3w_kernel<0, 0, 12>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 16>, (const void*)&srf_pw_x3w_kernel<0, 0, 19>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 20>, (const void*)&srf_pw_x3w_kernel<0, 0, 23>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 31>, (const void*)&srf_pw_x3w_kernel<0, 0, 55>,
-                         (const void*)&srf_pw_x3w_kernel<0, 0, 63>};
+    const void* fns[] = {
+        // the four forms the models launch, by cache policy
+        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 0>, (const void*)&srf_pw_x3w_kernel<0, 0, 0, 1>,
+        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 4>, (const void*)&srf_pw_x3w_kernel<0, 0, 0, 5>,
+        (const void*)&srf_pw_x3w_kernel<1, 0, 0, 0>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 1>,
+        (const void*)&srf_pw_x3w_kernel<1, 0, 0, 4>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 5>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 0>, (const void*)&srf_pw_x3w_kernel<2, 1, 0, 1>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 4>, (const void*)&srf_pw_x3w_kernel<2, 1, 0, 5>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 13>,
+        (const void*)&srf_pw_x3w_kernel<3, 2, 0, 0>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, 1>,
+        (const void*)&srf_pw_x3w_kernel<3, 2, 0, 4>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, 5>,
+        (const void*)&srf_pw_x3w_kernel<3, 2, 0, 13>,
+        // any other prologue / epilogue combination (unit tests, stand-alone srf_pw_conv callers)
+        (const void*)&srf_pw_x3w_kernel<0, 3>, (const void*)&srf_pw_x3w_kernel<1, 3>,
+        (const void*)&srf_pw_x3w_kernel<2, 3>, (const void*)&srf_pw_x3w_kernel<3, 3>,
+        // diagnostics: ablated pipelines and the in-kernel timeline (proj_1x1 and res_conv forms)
+        (const void*)&srf_pw_x3w_kernel<0, 0, 3>, (const void*)&srf_pw_x3w_kernel<0, 0, 4>,
+        (const void*)&srf_pw_x3w_kernel<0, 0, 7>, (const void*)&srf_pw_x3w_kernel<0, 0, 12>,
+        (const void*)&srf_pw_x3w_kernel<0, 0, 16>, (const void*)&srf_pw_x3w_kernel<0, 0, 19>,
+        (const void*)&srf_pw_x3w_kernel<0, 0, 20>, (const void*)&srf_pw_x3w_kernel<0, 0, 23>,
+        (const void*)&srf_pw_x3w_kernel<0, 0, 31>, (const void*)&srf_pw_x3w_kernel<0, 0, 55>,
+        (const void*)&srf_pw_x3w_kernel<0, 0, 63>, (const void*)&srf_pw_x3w_kernel<0, 0, 64>,
+        (const void*)&srf_pw_x3w_kernel<0, 0, 192>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 3>, (const void*)&srf_pw_x3w_kernel<2, 1, 4>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 16>, (const void*)&srf_pw_x3w_kernel<2, 1, 19>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 20>, (const void*)&srf_pw_x3w_kernel<2, 1, 23>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 64>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
@@ -874,36 +657,20 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   if (!(srf_debug_flags() & 512)) ap.epi_mask |= 1 << 12;   // quarter tiles first (flag 512: last)
   ap.epi_mask |= ((srf_debug_flags() >> 22) & 3) << 8;      // diagnostics: start-up stagger units (flag bits 22-23)
   const bool res = a.residual != nullptr, mask = !res && (a.epi_mask & 1);
-  // tiles dealt statically (default) or drawn from per-XCD work queues with phase seeds (debug flag 32768).  Measured round 3
-  // (tools/gemm_ab.py, same box): the queues are bit-identical and SLOWER -- proj_1x1 125 vs 115 us, res_conv 145 vs 128,
-  // bottleneck 128 vs 107: a quarter tile costs ~0.6 of a full tile's time (it streams the whole weight image and pays every
-  // per-step cost for a quarter of the MFMA work), so 2.5 quarter tiles per block of phase seeds + tail cost more than the
-  // de-synchronised epilogues win.  Kept as a switch: the mechanism is sound, its seed is not.
-  const bool dyn = (srf_debug_flags() & 32768) != 0;
-  unsigned* ctr = nullptr;
-  if (dyn) {
-    const long base = srf_device_cached(4, [](void*) -> long {
-      void* p = nullptr;
-      return hipGetSymbolAddress(&p, HIP_SYMBOL(g_x3w_ctr)) == hipSuccess ? (long)p : 0;
-    }, nullptr);
-    SRF_CHECK_ARG(base != 0, "srf_pw_conv: cannot locate the work-queue counters");
-    static std::atomic<unsigned> seq{0};
-    ctr = reinterpret_cast<unsigned*>(base) + 16 * (seq.fetch_add(1, std::memory_order_relaxed) % W_CTR_SLOTS);
-  }
-#define W_GO(P, E, A) do { if (dyn && (A) == 0) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, true>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, ctr, a.bias); \
-    else hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, false>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, (unsigned*)nullptr, a.bias); } while (0)
-  // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated below)
+#define W_GO(P, E, A, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta)
+  // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated above),
+  // 1 << 25 = in-kernel timeline (tools/gemm_timeline.py), 1 << 30 = epilogue without its stores
   const int abl = ((srf_debug_flags() >> 16) & 63) | ((srf_debug_flags() & (1 << 25)) ? 64 : 0) |
-                  ((srf_debug_flags() & (1 << 30)) ? 128 : 0);   // (flag 1 << 25: timeline, 1 << 30: epilogue without stores)
+                  ((srf_debug_flags() & (1 << 30)) ? 128 : 0);
   if (abl && pro == 2 && res) {
     switch (abl) {
-      case 3: W_GO(2, 1, 3); break;
-      case 4: W_GO(2, 1, 4); break;
-      case 16: W_GO(2, 1, 16); break;
-      case 19: W_GO(2, 1, 19); break;
-      case 20: W_GO(2, 1, 20); break;
-      case 23: W_GO(2, 1, 23); break;
-      case 64: W_GO(2, 1, 64); break;
+      case 3: W_GO(2, 1, 3, 0); break;
+      case 4: W_GO(2, 1, 4, 0); break;
+      case 16: W_GO(2, 1, 16, 0); break;
+      case 19: W_GO(2, 1, 19, 0); break;
+      case 20: W_GO(2, 1, 20, 0); break;
+      case 23: W_GO(2, 1, 23, 0); break;
+      case 64: W_GO(2, 1, 64, 0); break;
       default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for res_conv", abl);
     }
     SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
@@ -911,19 +678,19 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   }
   if (abl && pro == 0 && !res && !mask) {
     switch (abl) {
-      case 3: W_GO(0, 0, 3); break;
-      case 4: W_GO(0, 0, 4); break;
-      case 7: W_GO(0, 0, 7); break;
-      case 12: W_GO(0, 0, 12); break;
-      case 16: W_GO(0, 0, 16); break;
-      case 19: W_GO(0, 0, 19); break;
-      case 20: W_GO(0, 0, 20); break;
-      case 23: W_GO(0, 0, 23); break;
-      case 31: W_GO(0, 0, 31); break;
-      case 55: W_GO(0, 0, 55); break;
-      case 63: W_GO(0, 0, 63); break;
-      case 64: W_GO(0, 0, 64); break;
-      case 192: W_GO(0, 0, 192); break;
+      case 3: W_GO(0, 0, 3, 0); break;
+      case 4: W_GO(0, 0, 4, 0); break;
+      case 7: W_GO(0, 0, 7, 0); break;
+      case 12: W_GO(0, 0, 12, 0); break;
+      case 16: W_GO(0, 0, 16, 0); break;
+      case 19: W_GO(0, 0, 19, 0); break;
+      case 20: W_GO(0, 0, 20, 0); break;
+      case 23: W_GO(0, 0, 23, 0); break;
+      case 31: W_GO(0, 0, 31, 0); break;
+      case 55: W_GO(0, 0, 55, 0); break;
+      case 63: W_GO(0, 0, 63, 0); break;
+      case 64: W_GO(0, 0, 64, 0); break;
+      case 192: W_GO(0, 0, 192, 0); break;
       default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for proj_1x1", abl);
     }
     SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
@@ -932,51 +699,26 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   // Cache policy (CP) of the four model forms: bit 0 = non-temporal output stores, bit 2 = non-temporal activation loads,
   // bit 3 = non-temporal residual / mask-multiplier loads.  Every CU re-reads the whole packed weight image from L2 for every
   // tile, while activations, residuals and outputs stream through once: marked non-temporal they stop displacing the weights.
-  // Defaults = the fastest of each form in the same-box A/B of tools/gemm_ab.py (round 3); debug flag bits 26..29 = CP + 1 override.
+  // Defaults = what measured fastest INSIDE the forward (profiles/r03_NOTES.md: isolated launches mislead -- non-temporal
+  // stores looked 10 % faster on proj_1x1 alone and cost 5 % in the model, where the next kernel reads that tensor): proj_1x1
+  // plain; bottleneck, res_conv, mask non-temporal activation loads + stores.  Debug flag bits 26..29 = CP + 1 override.
   const int cp_flag = (srf_debug_flags() >> 26) & 15;
-  const bool model_form = !dyn && !(srf_debug_flags() & (1 << 24)) && ((pro == 0 && !res && !mask) || (pro == 1 && !res && !mask) || (pro == 2 && res) || (pro == 3 && mask));
-  if (model_form) {
-    static const int kDefaultCp[4] = {0, 5, 5, 5};
-    const int cp = cp_flag ? cp_flag - 1 : kDefaultCp[pro];
-#define W_CP(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, false, 0, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, (unsigned*)nullptr, a.bias)
-#define W_CP4(P, E) switch (cp & 7) { case 1: W_CP(P, E, 1); break; case 4: W_CP(P, E, 4); break; case 5: W_CP(P, E, 5); break; default: W_CP(P, E, 0); break; }
-#define W_CP7(P, E) switch (cp) { case 1: W_CP(P, E, 1); break; case 4: W_CP(P, E, 4); break; case 5: W_CP(P, E, 5); break; \
-      case 8: W_CP(P, E, 8); break; case 12: W_CP(P, E, 12); break; case 13: W_CP(P, E, 13); break; default: W_CP(P, E, 0); break; }
-    if (cp != 0 || true) {
-      if (pro == 0) { W_CP4(0, 0) }
-      else if (pro == 1) { W_CP4(1, 0) }
-      else if (pro == 2) { W_CP7(2, 1) }
-      else { W_CP7(3, 2) }
-      static const char* const kCp[4] = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_conv_x3v<3>"};
-      SRF_CHECK_LAUNCH(kCp[pro], st);
-      return SRF_OK;
-    }
-#undef W_CP7
-#undef W_CP4
-#undef W_CP
-  }
-  // DRIP epilogue (bias + statistics launches: proj_1x1, bottleneck): debug flag 1 << 24
-  const int nk = a.Cin / W_BK;
-  const bool drip_ok = !dyn && !res && !mask && (a.Cout % 8 == 0) && (a.L % 32 == 0) && nk >= 8 && (nk % 2 == 0) &&
-                       (long)a.Cout * a.L * 4 < (1L << 31) && (srf_debug_flags() & (1 << 24));
-#define W_DRIP(P, D) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, 0, 0, false, D>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, (unsigned*)nullptr, a.bias)
-  if (drip_ok && (pro == 0 || pro == 1)) {
-    if (pro == 0) { if (nk >= 16) W_DRIP(0, 16); else W_DRIP(0, 8); }
-    else { if (nk >= 16) W_DRIP(1, 16); else W_DRIP(1, 8); }
-    static const char* const kDrip[2] = {"pw_conv_x3v<0>", "pw_conv_x3v<1>"};
-    SRF_CHECK_LAUNCH(kDrip[pro], st);
-    return SRF_OK;
-  }
-#undef W_DRIP
+  static const int kDefaultCp[4] = {0, 5, 5, 5};
+  const int cp = cp_flag ? cp_flag - 1 : kDefaultCp[pro < 0 || pro > 3 ? 0 : pro];
+#define W_CP4(P, E) switch (cp & 7) { case 1: W_GO(P, E, 0, 1); break; case 4: W_GO(P, E, 0, 4); break; case 5: W_GO(P, E, 0, 5); break; default: W_GO(P, E, 0, 0); break; }
+#define W_CP5(P, E) switch (cp) { case 1: W_GO(P, E, 0, 1); break; case 4: W_GO(P, E, 0, 4); break; case 5: W_GO(P, E, 0, 5); break; \
+    case 13: W_GO(P, E, 0, 13); break; default: W_GO(P, E, 0, 0); break; }
   // the forms the models use are specialised on their epilogue; anything else runs the run-time-switched one
-  if (pro == 0 && !res && !mask) W_GO(0, 0, 0);
-  else if (pro == 1 && !res && !mask) W_GO(1, 0, 0);
-  else if (pro == 2 && res) W_GO(2, 1, 0);
-  else if (pro == 3 && mask) W_GO(3, 2, 0);
-  else if (pro == 0) W_GO(0, 3, 0);
-  else if (pro == 1) W_GO(1, 3, 0);
-  else if (pro == 2) W_GO(2, 3, 0);
-  else W_GO(3, 3, 0);
+  if (pro == 0 && !res && !mask) { W_CP4(0, 0) }
+  else if (pro == 1 && !res && !mask) { W_CP4(1, 0) }
+  else if (pro == 2 && res) { W_CP5(2, 1) }
+  else if (pro == 3 && mask) { W_CP5(3, 2) }
+  else if (pro == 0) W_GO(0, 3, 0, 0);
+  else if (pro == 1) W_GO(1, 3, 0, 0);
+  else if (pro == 2) W_GO(2, 3, 0, 0);
+  else W_GO(3, 3, 0, 0);
+#undef W_CP5
+#undef W_CP4
 #undef W_GO
   // (profiler family names stay those of round 2: the tests and bench.py's launch model key on them)
   static const char* const kLabel[4] = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_conv_x3v<3>"};
