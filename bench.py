@@ -184,19 +184,77 @@ def cpu_baseline(variant, kw, T, fs, batch, repeats, budget_s=45.0):
                       % (sorted(tried), batch, repeats)}
 
 
+def power_pass(run, seconds=2.0):
+    """Package power and clocks while `run()` is launched back to back for `seconds` (untimed pass, rank 0): a thread samples
+    `rocm-smi --showpower --showclocks --showmaxpower`.  Why this is in the bench line: the split-bf16 GEMMs that dominate the
+    forward run AT the package power cap (profiles/r03_NOTES.md), so the roofline that binds them is neither HBM nor the
+    matrix pipe at its nominal clock -- the fraction of the cap in use says how much of the chip's budget the run spends."""
+    import re
+    import subprocess
+    import threading
+    import torch
+    samples, stop = [], threading.Event()
+
+    def num(v):
+        m = re.search(r"(\d+(\.\d+)?)", str(v))
+        return float(m.group(1)) if m else None
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower", "--json"], capture_output=True,
+                                   text=True, timeout=5)
+                card = next(iter(json.loads(r.stdout).values()))
+                rec = {}
+                for k, v in card.items():
+                    kl = k.lower()
+                    if "max graphics package power" in kl:
+                        rec["cap_w"] = num(v)
+                    elif "power" in kl and "(w)" in kl:
+                        rec["power_w"] = num(v)
+                    elif kl.startswith("sclk clock speed"):
+                        rec["sclk_mhz"] = num(v)
+                if "power_w" in rec:
+                    samples.append(rec)
+            except Exception:  # noqa: BLE001  (no rocm-smi / unexpected output: the pass reports nothing)
+                return
+            time.sleep(0.05)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=10)
+    samples = samples[2:] if len(samples) > 6 else samples          # (the first samples still see the ramp-up)
+    if not samples:
+        return None
+    med = lambda k: sorted(x[k] for x in samples if x.get(k) is not None)[len(samples) // 2] if any(k in x for x in samples) else None
+    cap, pw = med("cap_w"), med("power_w")
+    return {"package_w_median": pw, "package_cap_w": cap, "frac_of_cap": (pw / cap) if pw and cap else None,
+            "sclk_mhz_median": med("sclk_mhz"), "samples": len(samples), "source": "rocm-smi, %.0f s of back-to-back forwards" % seconds}
+
+
 def pmc_traffic(kernel_family, workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE are collected in their own runs of this same command -- tools/gpu_round.sh -- and stored
-    under profiles/; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
-    path = os.path.join(ROOT, "profiles", "r02_cfg2_bs32_pmc_hbm_traffic.csv")
-    if workload != "cfg2_improved_u16" or not os.path.exists(path):
+    WRITE_SIZE are collected in their own runs of this same command -- tools/gpu_profiles.sh, summarised by
+    tools/collect_profiles3.py -- and stored under profiles/; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
+    for gfx950)."""
+    short = {"cfg2_improved_u16": "cfg2_bs32", "cfg4_improved_u36_n2048": "cfg4_u36_n2048_bs32",
+             "cfg5_improved_u36_n4096": "cfg5_u36_n4096_8s16k_bs16"}.get(workload)
+    rel = "profiles/r03_%s_pmc_hbm_traffic.csv" % short
+    path = os.path.join(ROOT, rel)
+    if short is None or not os.path.exists(path):
         return {"traffic": None}
     key = {"pw_conv_bf16x3_w8": "srf_pw_bf16x3_w8_kernel", "pw_conv_bf16x3_p8": "srf_pw_bf16x3_p8_kernel",
            "pw_conv_mfma": "srf_pw_mfma_kernel",
            "pyramid_moments": "srf_pyramid_reg_kernel<true", "pyramid_merge": "srf_pyramid_reg_kernel<false"
            }.get(kernel_family, kernel_family)
-    if kernel_family.startswith("pw_conv_x3v<"):             # "pw_conv_x3v<2>" -> "srf_pw_x3v_kernel<2"
-        key = "srf_pw_x3v_kernel<%s" % kernel_family[len("pw_conv_x3v<"):-1]
+    if kernel_family.startswith("pw_conv_x3v<"):             # "pw_conv_x3v<2>" -> the round-3 kernel "srf_pw_x3w_kernel<2, ..."
+        key = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3v<"):-1]
     if kernel_family.startswith("pw_conv_bf16x3_p8<"):       # one label per prologue variant = one rocprof kernel name
         key = "srf_pw_bf16x3_p8_kernel<%s," % kernel_family[len("pw_conv_bf16x3_p8<"):-1]
     fetch, write = {}, {}
@@ -211,7 +269,7 @@ def pmc_traffic(kernel_family, workload):
     f = sum(l * m for l, m in fetch.values()) / sum(l for l, _ in fetch.values())
     w = sum(l * m for l, m in write.values()) / sum(l for l, _ in write.values())
     return {"traffic": (f + w) * 1024 * 1024, "traffic_unit": "bytes/launch (HBM read + write, PMC)",
-            "traffic_source": "profiles/r02_cfg2_bs32_pmc_hbm_traffic.csv"}
+            "traffic_source": rel}
 
 
 def cpu_baseline_subprocess(args):
@@ -519,6 +577,10 @@ def main():
 
     if self_check.get("retimed_single_stream"):
         result["config"]["stream_split"] = [batch]
+
+    if rank == 0 and not args.no_kernel_profile:
+        with torch.no_grad():
+            result["power"] = power_pass(lambda: model(wav))
 
     # ---- per-kernel durations with HIP events on the launch stream (separate instrumented pass) ----
     if rank == 0 and not args.no_kernel_profile:
