@@ -600,7 +600,8 @@ def main():
             _lib.check(lib.srf_profile_end(stream, C.byref(cnt)), "srf_profile_end")
             model._engine().multi_stream = was_multi_p
             engine_mod._GRAPH_MODE = was_graph
-        launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, packed=not (args.debug_flags & 8), **dims)
+        launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, packed=not (args.debug_flags & 8),
+                                         fuse_tail=not (args.debug_flags & (4 | 16384 | 32768)), **dims)
         per = {}
         name, ms = C.c_char_p(), C.c_float()
         marks = []

@@ -112,6 +112,7 @@ int srf_profile_get(int i, const char** name, float* ms);
  *   256      leftover GEMM tiles as whole tiles (no quarter tiles) 512       quarter tiles last
  *   1024     TAC forward with one time step per lane               2048      one-tile-per-block GEMM everywhere
  *   16384    round 2's 256 x 128 GEMM (srf_pwconv_x3v.hip) instead of round 3's (srf_pwconv_x3w.hip)
+ *   32768    WITHOUT the fused tail: mask GEMM -> masked tensor -> decoder frame GEMM -> overlap-add as separate launches
  *   bits 12-13, 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating)
  *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
  *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)
@@ -143,7 +144,9 @@ int srf_separate(const srf_plan* plan, const float* const* params, int num_param
                  float* stats, int mixture_consistency, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Copy an intermediate of the LAST srf_forward on this workspace into dst (for parity tests).
- * what: 0 = encoder output [Bt,N,L], 1 = separation-module output [Bt,B,L], 2 = masked [Bt,S*A*N,L]. */
+ * what: 0 = encoder output [Bt,N,L], 1 = separation-module output [Bt,B,L], 2 = masked [Bt,S*A*N,L].
+ * 2 fails (SRF_EINVAL) at shapes whose forward runs the mask GEMM fused with the decoder (launches with at least as many
+ * 256 x 128 tiles as the GPU has CUs): the masked tensor then never exists in memory. */
 int srf_debug_fetch(const srf_plan* plan, const void* workspace, int what, float* dst, size_t dst_floats,
                     void* stream);
 

@@ -149,8 +149,14 @@ static int srf_zero_launch(void* p, size_t bytes, hipStream_t st) {
 }
 
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
-int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T, const float* stats,
+int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T, int nparts, const float* stats,
                            const float* wav, int mc, hipStream_t st);
+bool srf_mask_decode_supported(int Bt, int Cin, int Cout, int L, int M);
+size_t srf_mask_decode_pack_bytes(int Cout);
+int srf_mask_decode_pack(const float* wd, void* dst, int Ci, int M, hipStream_t st);
+int srf_mask_decode(const float* x, const float* w, const void* w_packed, const float* bias, const float* prelu,
+                    const float* mul, int mul_channels, const void* wd_packed, float* zpart, int Bt, int Cin, int Cout, int L,
+                    int M, hipStream_t st);
 int srf_encoder_impl(const float* wav, const float* w, float* out, double* sums, int Bt, int A, int T, int N, int K, int L,
                      const float* in_stats, void* stream);
 extern "C" int srf_wav_stats(const float* wav, float* stats, int rows, int T, void* stream);
@@ -191,7 +197,7 @@ static int srf_decoder_impl(const float* v, const float* w, float* out, int Bt, 
   if (rc) return rc;
   rc = srf_pw_conv(v, wt, zb, z, Bt, Ci, M, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
   if (rc) return rc;
-  return srf_overlap_add_launch(z, out, Bt, Co, K, L, T, post_stats, post_wav, post_mc, st);
+  return srf_overlap_add_launch(z, out, Bt, Co, K, L, T, 1, post_stats, post_wav, post_mc, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -312,6 +318,8 @@ extern "C" int srf_plan_create(const srf_config* c, int batch, int T, srf_plan**
     add_pack(pu + 5 + 4 * D + 3, p->nB, p->nC);
   }
   add_pack(p->p_tail + 1, p->SA * c->enc_num_basis, c->out_channels);
+  // decoder weights as MFMA fragments for the fused tail (K5); whether it runs is decided per forward
+  p->off_wdpack = (p->SA * K <= 64 && p->pk_of_param[p->p_tail + 1]) ? take(srf_mask_decode_pack_bytes(p->SA * c->enc_num_basis)) : 0;
   p->total_bytes = off;
   p->n_launches = 1 /*memset*/ + 2 + U * (D + 3 + (gc ? 2 : 0)) + 1 + 4;
   *out = p;
@@ -496,6 +504,19 @@ static int srf_forward_impl(const srf_plan* p, const float* const* P, int num_pa
   // ---- mask estimation + decoder                            :295-301
   const float* const* Pt = P + p->p_tail;
   float* masked = fptr(p->off_masked);
+  // K5: mask GEMM and decoder contraction in ONE launch -- the [Bt, S N, L] masked tensor (the largest of the forward) never
+  // reaches HBM; the GEMM leaves per-256-channel partial decoder frames (in the masked tensor's workspace region, <= 1/4 of
+  // it) and the overlap-add sums them.  Only where the 256 x 128 GEMM would have run the mask conv anyway.
+  if (p->off_wdpack && use_pack && packed(p->p_tail + 1) && N % 8 == 0 &&
+      srf_mask_decode_supported(Bt, c.out_channels, p->SA * N, L, p->SA * K)) {
+    const int M = p->SA * K, nparts = (p->SA * N + 255) / 256;
+    rc = srf_mask_decode_pack(Pt[3], ws + p->off_wdpack, p->SA * N, M, st);
+    if (rc) return rc;
+    rc = srf_mask_decode(cur, Pt[1], packed(p->p_tail + 1), Pt[2], Pt[0], enc, N, ws + p->off_wdpack, masked, Bt,
+                         c.out_channels, p->SA * N, L, M, st);
+    if (rc) return rc;
+    return srf_overlap_add_launch(masked, out, Bt, p->SA, K, L, p->T, nparts, wav_stats, wav, mixture_consistency, st);
+  }
   {
     srf_norm pre{nullptr, nullptr, nullptr, Pt[0]};
     rc = srf_pw_conv_packed(cur, Pt[1], packed(p->p_tail + 1), Pt[2], masked, Bt, c.out_channels, p->SA * N, L,
@@ -520,6 +541,13 @@ extern "C" int srf_debug_fetch(const srf_plan* p, const void* workspace, int wha
     off = (c.num_blocks % 2 == 0) ? p->off_xa : p->off_xb;
     n = (size_t)p->Bt * c.out_channels * p->L;
   } else if (what == 2) {
+    // the fused tail (K5) never materialises the masked tensor: its workspace region holds partial decoder frames
+    if (p->off_wdpack && srf_kernel_mode() == 0 && !(srf_debug_flags() & 8) && c.enc_num_basis % 8 == 0 &&
+        srf_mask_decode_supported(p->Bt, c.out_channels, p->SA * c.enc_num_basis, p->L, p->SA * c.enc_kernel_size)) {
+      srf_set_error("srf_debug_fetch: the masked tensor is not materialised at this shape (mask GEMM and decoder run fused); "
+                    "set debug flag 32768 to run the tail unfused");
+      return SRF_EINVAL;
+    }
     off = p->off_masked;
     n = (size_t)p->Bt * p->SA * c.enc_num_basis * p->L;
   } else {

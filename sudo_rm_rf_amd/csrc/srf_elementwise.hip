@@ -200,68 +200,113 @@ int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t s
 }
 
 // out[b,o,t] = sum over the <=3 (frame l, tap k) pairs with h*l + k - h = t of z[b, o*K + k, l]
-// q = t / h, r = t % h:  (l=q+1,k=r), (l=q,k=r+h), and (l=q-1,k=2h) when r == 0.
-__global__ __launch_bounds__(256) void srf_overlap_add_kernel(const float* __restrict__ z,
-                                                              float* __restrict__ out, int Co, int K,
-                                                              int L, int T) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
-  const int o = blockIdx.y;
-  const long b = blockIdx.z;
-  const int h = K / 2;
-  const int q = t / h, r = t - q * h;
-  const float* zb = z + ((size_t)b * Co * K + (size_t)o * K) * L;
-  float acc = 0.f;
-  if (r == 0 && q >= 1 && q - 1 < L) acc += zb[(size_t)(2 * h) * L + (q - 1)];
-  if (q < L) acc += zb[(size_t)(r + h) * L + q];
-  if (q + 1 < L) acc += zb[(size_t)r * L + (q + 1)];
-  out[((size_t)b * Co + o) * T + t] = acc;
-}
-
-// The same with the callers' post-processing folded in (README.md:106-114): out = est * std + mean and, with `mc`,
-// mixture_consistency.apply(out, normalised mixture) -- the mixture re-normalised on the fly from the raw waveform.  One
-// thread owns all Co sources of a time step (two sweeps over its <= 3 * Co inputs instead of a [Co] array).
-__global__ __launch_bounds__(256) void srf_overlap_add_post_kernel(const float* __restrict__ z, float* __restrict__ out,
-                                                                   int Co, int K, int L, int T,
-                                                                   const float* __restrict__ stats,
-                                                                   const float* __restrict__ wav, int mc) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
+// q = t / h, r = t % h:  (l=q-1,k=2h) when r == 0, (l=q,k=r+h), (l=q+1,k=r) -- added in that order.
+// z: [Bt][nparts][Co * K][L]; nparts > 1 = the fused tail's per-256-channel partial frames (srf_pwconv_x3w.hip, EPI 4), summed
+// here in part order (fixed order: run-to-run identical).
+// A block owns OA_Q frames of one example: the [Co K] x [OA_Q + 2] frame values it needs are read ROW-WISE (coalesced; a thread
+// per output sample reads 2-3 different rows at a stride of L floats -- fine for one part, not for the 4-32 of the fused tail)
+// into LDS, summed over the parts on the way; then one thread per output sample (and, POST, all Co sources of it: the callers'
+// post-processing of README.md:106-114 folded in -- out = est * std + mean and, with `mc`, mixture_consistency.apply against
+// the mixture re-normalised on the fly from the raw waveform).
+constexpr int OA_Q = 64;      // frames per block (fewer when Co * K rows of them would not fit 64 KB of LDS)
+template <bool POST>
+__global__ __launch_bounds__(256) void srf_overlap_add_kernel(const float* __restrict__ z, float* __restrict__ out, int Co, int K,
+                                                              int L, int T, int nparts, int qw, const float* __restrict__ stats,
+                                                              const float* __restrict__ wav, int mc) {
+  extern __shared__ float oa_s[];                 // [Co * K][qw + 2]: frames q0 - 1 .. q0 + qw
+  const int W = qw + 2;
+  const int q0 = blockIdx.x * qw;
   const long b = blockIdx.y;
-  const int h = K / 2;
-  const int q = t / h, r = t - q * h;
-  const float mean = stats[2 * b], sd = stats[2 * b + 1];
-  const bool t0 = r == 0 && q >= 1 && q - 1 < L, t1 = q < L, t2 = q + 1 < L;
-  auto est = [&](int o) {
-    const float* zb = z + ((size_t)b * Co * K + (size_t)o * K) * L;
-    float acc = 0.f;
-    if (t0) acc += zb[(size_t)(2 * h) * L + (q - 1)];
-    if (t1) acc += zb[(size_t)(r + h) * L + q];
-    if (t2) acc += zb[(size_t)r * L + (q + 1)];
-    return acc * sd + mean;
-  };
-  float corr = 0.f;
-  if (mc) {
-    float tot = 0.f;
-    for (int o = 0; o < Co; ++o) tot += est(o);
-    corr = ((wav[b * (long)T + t] - mean) / (sd + 1e-9f) - tot) * (1.f / (float)Co);
+  const int M = Co * K, h = K / 2;
+  const size_t pstride = (size_t)M * L;
+  const float* zb = z + (size_t)b * nparts * pstride;
+  // (four frames per load, four parts in flight: 64 B per thread keep enough bytes in flight to cover the HBM latency -- one
+  // dword at a time measured 2.7 TB/s on cfg 5's 1.1 GB of partial frames)
+  const int W4 = W >> 2;                          // W % 4 == 0 (host)
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  for (int idx = threadIdx.x; idx < M * W4; idx += 256) {
+    const int m = idx / W4, j = (idx - m * W4) * 4;
+    const int l = q0 - 1 + j;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (l >= 0 && l + 3 < L) {
+      const float* src = zb + (size_t)m * L + l;
+      int p = 0;
+      for (; p + 4 <= nparts; p += 4, src += 4 * pstride) {
+        const f32x4u t0 = *reinterpret_cast<const f32x4u*>(src), t1 = *reinterpret_cast<const f32x4u*>(src + pstride),
+                     t2 = *reinterpret_cast<const f32x4u*>(src + 2 * pstride),
+                     t3 = *reinterpret_cast<const f32x4u*>(src + 3 * pstride);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (t0[e] + t1[e]) + (t2[e] + t3[e]);
+      }
+      for (; p < nparts; ++p, src += pstride) {
+        const f32x4u t0 = *reinterpret_cast<const f32x4u*>(src);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += t0[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (l + e >= 0 && l + e < L) {
+          const float* src = zb + (size_t)m * L + l + e;
+          int p = 0;
+          for (; p + 4 <= nparts; p += 4, src += 4 * pstride) v[e] += (src[0] + src[pstride]) + (src[2 * pstride] + src[3 * pstride]);
+          for (; p < nparts; ++p, src += pstride) v[e] += *src;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oa_s[m * W + j + e] = v[e];
   }
-  for (int o = 0; o < Co; ++o) {
-    const float v = est(o);
-    out[((size_t)b * Co + o) * T + t] = mc ? v + corr : v;
+  __syncthreads();
+  float mean = 0.f, sd = 1.f;
+  if constexpr (POST) {
+    mean = stats[2 * b];
+    sd = stats[2 * b + 1];
+  }
+  for (int tt = threadIdx.x; tt < qw * h; tt += 256) {
+    const int t = q0 * h + tt;
+    if (t >= T) break;
+    const int qi = tt / h, r = tt - qi * h;       // frame q0 + qi is column qi + 1
+    auto est = [&](int o) {
+      const float* row = oa_s + (size_t)o * K * W;
+      float acc = 0.f;
+      if (r == 0) acc += row[(2 * h) * W + qi];
+      acc += row[(r + h) * W + qi + 1];
+      acc += row[r * W + qi + 2];
+      return POST ? acc * sd + mean : acc;
+    };
+    float corr = 0.f;
+    if (POST && mc) {
+      float tot = 0.f;
+      for (int o = 0; o < Co; ++o) tot += est(o);
+      corr = ((wav[b * (long)T + t] - mean) / (sd + 1e-9f) - tot) * (1.f / (float)Co);
+    }
+    for (int o = 0; o < Co; ++o) {
+      const float v = est(o);
+      out[((size_t)b * Co + o) * T + t] = (POST && mc) ? v + corr : v;
+    }
   }
 }
 
 // stats: null = plain overlap-add; else [Bt][2] {mean, std} of the raw mixture `wav` [Bt][T] (mc: also mixture consistency)
-int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T, const float* stats,
+int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T, int nparts, const float* stats,
                            const float* wav, int mc, hipStream_t st) {
-  if (stats) {
-    dim3 grid((T + 255) / 256, Bt);
-    hipLaunchKernelGGL(srf_overlap_add_post_kernel, grid, dim3(256), 0, st, z, out, Co, K, L, T, stats, wav, mc);
-  } else {
-    dim3 grid((T + 255) / 256, Co, Bt);
-    hipLaunchKernelGGL(srf_overlap_add_kernel, grid, dim3(256), 0, st, z, out, Co, K, L, T);
-  }
+  // frames per block: rows of 128 floats (fewer partly used cache lines at the unaligned row ends) when there are partial
+  // frames to sum and the launch still has >= 4 blocks per CU, else rows of 64 (the single-part case is latency-bound:
+  // more, smaller blocks); fewer when Co * K rows would not fit 64 KB of LDS.  qw + 2 must be a multiple of 4.
+  const int cap = ((int)(64 * 1024 / sizeof(float) / ((size_t)Co * K)) & ~3) - 2;
+  const int nfr = (T + K / 2 - 1) / (K / 2);
+  int qw = OA_Q - 2;
+  if (nparts >= 4 && (long)((nfr + 2 * OA_Q - 3) / (2 * OA_Q - 2)) * Bt >= 1024) qw = 2 * OA_Q - 2;
+  qw = qw > cap ? cap : qw;
+  SRF_CHECK_ARG(qw >= 2, "srf_decoder: %d x %d frame rows exceed the overlap-add's LDS tile", Co, K);
+  const size_t lds = sizeof(float) * (size_t)Co * K * (qw + 2);
+  const int h = K / 2;
+  dim3 grid(((T + h - 1) / h + qw - 1) / qw, Bt);
+  if (stats)
+    hipLaunchKernelGGL(srf_overlap_add_kernel<true>, grid, dim3(256), lds, st, z, out, Co, K, L, T, nparts, qw, stats, wav, mc);
+  else
+    hipLaunchKernelGGL(srf_overlap_add_kernel<false>, grid, dim3(256), lds, st, z, out, Co, K, L, T, nparts, qw, stats, wav, mc);
   SRF_CHECK_LAUNCH("overlap_add", st);
   return SRF_OK;
 }

@@ -12,7 +12,7 @@ struct srf_plan {
   int p_block0, p_block_stride, p_ublock_off, p_tail;
   // workspace offsets (bytes)
   size_t off_stats, stats_bytes, off_enc, off_xa, off_xb, off_xq, off_xu, off_y1, off_lv[SRF_MAX_DEPTH],
-      off_masked, off_dec, off_pyr, total_bytes;
+      off_masked, off_dec, off_pyr, off_wdpack, total_bytes;
   int fused_pyramid;
   int slots_per_block, n_slots;
   // pre-packed (split-bf16) weights of the 1x1 convolutions: param index -> workspace offset (0 = none)

@@ -220,6 +220,53 @@ bool srf_pw_small_supported(int Cin, int Cout, int L);
 int srf_x3v_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n,
                         hipStream_t st);
 
+// ---- K5 (library-internal; srf_forward's tail): mask GEMM + decoder contraction in one launch (srf_pwconv_x3w.hip, EPI 4)
+int srf_pw_x3w_fused_tail_launch(const PwArgs& a, const char* wpack, const char* wdpack, float* zpart, int M, hipStream_t st);
+size_t srf_x3w_dec_pack_bytes(int Ci);
+int srf_x3w_pack_dec_launch(const float* w, void* dst, int Ci, int M, hipStream_t st);
+
+// Whether srf_forward may run its tail fused: the shapes the round-3 256 x 128 kernel is dispatched for (same test as in
+// srf_pw_conv_packed) and a decoder of at most 64 frame rows (sources x taps: 42 for the reference's 2 x 21).
+// Debug flag 32768 = without (the masked tensor is then materialised: srf_debug_fetch(2), A/B).
+bool srf_mask_decode_supported(int Bt, int Cin, int Cout, int L, int M) {
+  if (srf_kernel_mode() != 0 || (srf_debug_flags() & (4 | 8 | 16384 | 32768))) return false;
+  if (M <= 0 || M > 64 || Cout % 8 || Cin % PW_BK || L % 4 || !srf_x3v_supported(Cin, Cout, L) || !srf_x3w_supported(Bt, 3)) return false;
+  if ((long)Bt * Cin * L * 4 >= (1L << 31)) return false;
+  return (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus();
+}
+size_t srf_mask_decode_pack_bytes(int Cout) { return srf_x3w_dec_pack_bytes(Cout); }
+int srf_mask_decode_pack(const float* wd, void* dst, int Ci, int M, hipStream_t st) {
+  return srf_x3w_pack_dec_launch(wd, dst, Ci, M, st);
+}
+// zpart[Bt][ceil(Cout / 256)][M][L] = per-256-channel partial sums of Wd^T (relu(W prelu(x) + bias) * mul)
+int srf_mask_decode(const float* x, const float* w, const void* w_packed, const float* bias, const float* prelu,
+                    const float* mul, int mul_channels, const void* wd_packed, float* zpart, int Bt, int Cin, int Cout, int L,
+                    int M, hipStream_t st) {
+  SRF_CHECK_ARG(x && w && w_packed && bias && prelu && mul && wd_packed && zpart, "srf_mask_decode: null pointer");
+  SRF_CHECK_ARG(srf_mask_decode_supported(Bt, Cin, Cout, L, M) && mul_channels > 0 && mul_channels % 8 == 0,
+                "srf_mask_decode: unsupported shape");
+  SRF_CHECK_ARG(srf_aligned16(x) && srf_aligned16(w_packed) && srf_aligned16(wd_packed), "srf_mask_decode: unaligned operand");
+  PwArgs a;
+  a.x = x;
+  a.w = w;
+  a.bias = bias;
+  a.y = zpart;          // (never written by this form)
+  a.residual = nullptr;
+  a.out_sums = nullptr;
+  a.mul = mul;
+  srf_norm nm{nullptr, nullptr, nullptr, prelu};
+  a.nrm = srf_norm_dev(&nm);
+  a.inv_count = 1.0 / ((double)Cin * (double)L);
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.L = L;
+  a.Bt = Bt;
+  a.mul_channels = mul_channels;
+  a.epi_mask = 1;
+  return srf_pw_x3w_fused_tail_launch(a, reinterpret_cast<const char*>(w_packed), reinterpret_cast<const char*>(wd_packed), zpart,
+                                      M, st);
+}
+
 extern "C" size_t srf_packed_pw_weight_bytes(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0 || !srf_x3v_supported(Cin, Cout, 4)) return 0;
   return srf_x3v_packed_bytes(Cout, Cin);

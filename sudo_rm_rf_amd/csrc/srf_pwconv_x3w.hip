@@ -57,7 +57,10 @@ __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8
 #define W_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
 // PRO: 0 = identity, 1 = GlobLN, 2 = GlobLN + PReLU, 3 = PReLU only.
-// EPI: 0 = bias (+ statistics), 1 = bias + residual, 2 = ReLU(bias + .) x mul (mask epilogue), 3 = decided at run time (any).
+// EPI: 0 = bias (+ statistics), 1 = bias + residual, 2 = ReLU(bias + .) x mul (mask epilogue), 3 = decided at run time (any),
+//      4 = the mask epilogue FUSED with the decoder's contraction (K5): the masked values never leave the chip -- see the EPI 4
+//          block in the tile loop; bias_r = the bias again as a noalias argument (scalar loads), wdpack = the decoder weights as
+//          MFMA A fragments (srf_x3w_pack_dec_kernel), zpart = [Bt][nMt][zM][L] partial decoder frames, zM = sources x taps.
 // ABL (diagnostics, results are wrong when != 0): 1 = no activation loads, 2 = no weight DMA, 4 = no MFMAs, 8 = no GlobLN / PReLU /
 // split / ds_write, 16 = no epilogue, 32 = no fragment reads.
 // gamma / beta come again as noalias kernel arguments so that they are fetched with scalar loads.
@@ -66,7 +69,8 @@ __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8
 template <int PRO, int EPI, int ABL = 0, int CP = 0>
 __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt,
                                                             int total, int rounds, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta) {
+                                                            const float* __restrict__ beta, const float* __restrict__ bias_r,
+                                                            const char* __restrict__ wdpack, float* __restrict__ zpart, int zM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // W_NSTAGE * W_STAGE (+ the statistics table)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   const int ntile = rounds + nq_mine;
   const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
   const int x_bytes = a.Bt * Cin * L * 4;
-  constexpr bool kHasExt = EPI != 0;         // the epilogue reads a second tensor (residual or mask multiplier)
+  constexpr bool kHasExt = EPI != 0 && EPI != 4;   // the strip epilogue reads a second tensor (residual or mask multiplier)
   // One-off start-up stagger (diagnostics: epi_mask bits 8..11 = units of ~4K cycles, 4 phases by block id; default none)
   {
     const int units = (a.epi_mask >> 8) & 15;
@@ -481,6 +485,52 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       if (i < 20) tl_put(tl_abs, 3 * i, (unsigned)__builtin_amdgcn_s_memrealtime(), false);
       tl_c0 = (unsigned)__builtin_amdgcn_s_memtime();
     }
+    // EPI 4: the encoder multiplier in the MFMA C layout (register r of accumulator tile (mi, ni) = row (r & 3) + 8 (r >> 2) +
+    // 4 (lane >> 5), column lane & 31), one dword per register; upper half (mi = 0) two steps ahead, lower half after the last step
+    float rxc[EPI == 4 ? 2 : 1][EPI == 4 ? 2 : 1][EPI == 4 ? 16 : 1];
+    // (buffer loads: ONE per-lane offset -- 4 rows down for the upper lane half, the column -- and the row as the scalar
+    // offset; mul_channels % 8 == 0 and Cout % 8 == 0 (host) keep an 8-row group on one side of the wrap / the bound)
+    auto epi4_issue = [&](auto half_tag) __attribute__((always_inline)) {
+      if constexpr (EPI == 4) {
+        constexpr int mi = decltype(half_tag)::value;
+        __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.mul) + (size_t)b * a.mul_channels * L, 0, a.mul_channels * L * 4, 0x00020000);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int col = lcol + ni * 32 + (lane & 31);
+          const int vo = (4 * (lane >> 5) * L + (col < L ? col : 0)) * 4;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row8 = mrow + mi * 32 + 8 * g;
+            const int so = ((row8 < a.Cout ? row8 : 0) % a.mul_channels) * L * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              rxc[mi][ni][4 * g + j] = (mi < NT && ni < NT)
+                                           ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrs, vo, so + j * L * 4, 0))
+                                           : 0.f;
+          }
+        }
+      }
+    };
+    // EPI 4: this wavefront's Wd^T fragments of 32-channel chunk c of the tile: [block][mb][ks][hi | lo], 1 KB each, lane l at
+    // 16 l (L2-resident; chunk 0 is requested before the tile's last step, chunk c + 1 under chunk c's MFMAs)
+    struct WdFrag {
+      bf16x8 f[EPI == 4 ? 2 : 1][EPI == 4 ? 2 : 1];
+    };
+    WdFrag wd0, wd1;
+    auto wd_load = [&](WdFrag& w, int c) __attribute__((always_inline)) {
+      if constexpr (EPI == 4) {
+        // (buffer loads: the lane offset is the only vector address; block / mb / fragment go into the scalar offset)
+        __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wdpack), 0, nMt * 8 * 8192, 0x00020000);
+        const int so = (((m0 >> 5) + c) * 2 + (wave >> 2)) * 4096;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+            w.f[ks][part] = __builtin_bit_cast(bf16x8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, so + (ks * 2 + part) * 1024, 0));
+      }
+    };
     auto k_loop = [&](auto full_tag) __attribute__((always_inline)) {
       read_frags(f0, s0, 0, full_tag);     // this tile's k-tile 0 (complete since the barrier that ended the previous tile)
       for (int kt = 0; kt + 4 < nk; kt += 2) {
@@ -489,8 +539,13 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       }
       step(r1, nk - 4, full_tag, T{}, T{});
       step(r0, nk - 3, full_tag, T{}, F{});      // last prefetching step: nothing requested for k-tile nk-2
-      epi_issue(std::integral_constant<int, 0>{});
+      if constexpr (EPI == 4) epi4_issue(std::integral_constant<int, 0>{});
+      else epi_issue(std::integral_constant<int, 0>{});
       step(r1, nk - 2, full_tag, F{}, F{});
+      if constexpr (EPI == 4) {      // (just-in-time fragments in these steps leave room for the second half one step ahead)
+        epi4_issue(std::integral_constant<int, 1>{});
+        wd_load(wd0, 0);
+      }
       step(r0, nk - 1, full_tag, F{}, F{});
       if constexpr (kHasExt) epi_issue(std::integral_constant<int, 1>{});
     };
@@ -510,6 +565,133 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     const TileP tnn = has_nn ? make_tile(nnc) : tn;
     // epilogue through wave-private strips in the stage the tile's last k-tile has just freed
     const int free_stage = s0 == 0 ? W_NSTAGE - 1 : s0 - 1;
+    if constexpr (EPI == 4) {
+      // ================= K5 fused: out frames Z[(o, k), l] = sum_ci Wd[ci, (o, k)] * relu(y + bias)[ci, l] * enc[ci % N, l] =================
+      // (improved_sudormrf.py:295-300 + the ConvTranspose1d of :272-279 as a frame GEMM.)  The tile's 256 x 128 masked values
+      // exist only in the accumulators: 32-channel chunks of them go through a 16-KB LDS image (the exact layout of a B-operand
+      // stage: [128 columns][32 k] bf16, hi | lo, swizzled) -- two buffers in the stage the last k-tile freed -- and ALL eight
+      // wavefronts contract a chunk against the matching pre-packed Wd^T fragments (global, L2-resident) into ONE 32 x 32
+      // accumulator each: wavefront w owns frame rows (w >> 2) * 32 .. and columns (w & 3) * 32 ...  Summing over the chunk
+      // index IS the reduction over the tile's 256 channels: fixed order, no atomics.  The tile's [zM x 128] partial frames go to
+      // zpart[b][mt]; the overlap-add kernel adds the nMt partials.  Instead of 128 KB of masked values a tile writes 21 KB.
+      // (the lane id through an opaque copy: otherwise every LDS / store offset below is hoisted out of the tile loop as a
+      // loop invariant and, with all 256 registers taken by the k-loop, spilled -- one scratch round trip per use)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int lhalf = lane_o >> 5, lcol32 = lane_o & 31;
+      char* stage_base = smem + free_stage * W_STAGE;
+      const int zmb = wave >> 2, znb = wave & 3;
+      auto fused_tail = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int NTc = FULL ? 2 : 1;
+        // (1) v = relu(acc + bias) * enc in place (bias: scalar loads, the row is wave-uniform up to the lane half)
+#pragma unroll
+        for (int mi = 0; mi < NTc; ++mi) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row8 = mrow + mi * 32 + 8 * g;
+            const float* bp = bias_r + (row8 < a.Cout ? row8 : 0);        // 8 consecutive scalars (Cout % 8 == 0)
+            float bl[4], bh[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              bl[j] = bp[j];
+              bh[j] = bp[4 + j];
+            }
+#pragma unroll
+            for (int ni = 0; ni < NTc; ++ni)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                const float v = acc[mi][ni][r] + (lhalf ? bh[j] : bl[j]);
+                acc[mi][ni][r] = fmaxf(v, 0.f) * rxc[mi][ni][r];
+              }
+          }
+        }
+        // (2) chunk loop: 8 x 32 channels = the tile's 256 rows
+        f32x16 zacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zacc[r] = 0.f;
+        const bool z_active = FULL ? true : znb == 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          char* buf = stage_base + ((c & 1) ? 0 : 2 * W_A_IMG);      // even chunks: the stage's B region, odd: its A region
+          // the owners write their 32 channels x (64 | 32) columns of chunk c (full tiles: the two wavefronts of row group
+          // c >> 1, accumulator row half c & 1; quarter tiles: wavefront c)
+          const bool owner = FULL ? wm == (c >> 1) : wave == c;
+          if (owner) {
+#pragma unroll
+            for (int ni = 0; ni < NTc; ++ni) {
+              const f32x16& t = FULL ? acc[c & 1][ni] : acc[0][0];
+              const int row = FULL ? wn * 64 + ni * 32 + lcol32 : lcol32;         // image row = tile column
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 hi4, lo4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float v = t[4 * g + j];
+                  const __bf16 h = (__bf16)v;
+                  hi4[j] = h;
+                  lo4[j] = (__bf16)(v - (float)h);
+                }
+                char* dst = buf + w_swz(row, g) + 8 * lhalf;
+                *reinterpret_cast<bf16x4*>(dst) = hi4;
+                *reinterpret_cast<bf16x4*>(dst + W_B_IMG) = lo4;
+              }
+            }
+          }
+          WdFrag& wc = (c & 1) ? wd1 : wd0;
+          WdFrag& wn_ = (c & 1) ? wd0 : wd1;
+          if (c + 1 < 8) wd_load(wn_, c + 1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (z_active) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const int off = w_swz(znb * 32 + lcol32, 2 * ks + lhalf);
+              const bf16x8 vh = *reinterpret_cast<const bf16x8*>(buf + off);
+              const bf16x8 vl = *reinterpret_cast<const bf16x8*>(buf + W_B_IMG + off);
+              zacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc.f[ks][1], vh, zacc, 0, 0, 0);
+              zacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc.f[ks][0], vl, zacc, 0, 0, 0);
+              zacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc.f[ks][0], vh, zacc, 0, 0, 0);
+            }
+          }
+        }
+        // (3) the tile's partial frames
+        // (buffer stores: row in the scalar offset; lanes beyond L / zM get an offset past the descriptor's range = dropped)
+        if (z_active) {
+          float* zb = zpart + ((size_t)b * nMt + cur.mt) * (size_t)zM * L;
+          __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(zb, 0, zM * L * 4, 0x00020000);
+          const int col = l0 + znb * 32 + lcol32;
+          const int vo = (4 * lhalf * L + col) * 4;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int mu = zmb * 32 + (r & 3) + 8 * (r >> 2);           // wave-uniform; + 4 for the upper lane half
+            if (mu < zM) {
+              const bool ok = col < L && mu + 4 * lhalf < zM;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(zacc[r]), zrs, ok ? vo : 0x7ffffff0, mu * L * 4, 0);
+            }
+          }
+        }
+      };
+      if (quarter)
+        fused_tail(F{});
+      else
+        fused_tail(T{});
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+      cur = nxc;
+      nxc = nnc;
+      tc = tn;
+      tn = tnn;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
     float* strip = reinterpret_cast<float*>(smem + free_stage * W_STAGE) + wave * (32 * SRF_EPI_PITCH_H);
     float s = 0.f, q = 0.f;
     if (ABL & 16) {
@@ -604,7 +786,57 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
 
 bool srf_x3w_supported(int Bt, int pro) { return !(pro == 1 || pro == 2) || Bt <= W_MAX_STAT_EXAMPLES; }
 
+// fuse_wd != null: the mask epilogue fused with the decoder's contraction (EPI 4; pro 3, mask epilogue, fuse_M <= 64)
+static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, const char* fuse_wd, float* fuse_z, int fuse_M,
+                                 hipStream_t st);
 int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
+  return srf_pw_x3w_launch_any(a, wpack, pro, nullptr, nullptr, 0, st);
+}
+
+// ---- K5: decoder weights as MFMA A fragments.  w: the ConvTranspose1d weight [Ci][M] (M = sources x taps <= 64), split into
+// bf16 hi | lo.  Image: [ceil(Ci / 256) * 8 blocks of 32 channels][mb 0..1][ks 0..1][hi | lo][lane 0..63][8 bf16]: lane l of
+// fragment (block, mb, ks) holds Wd[block * 32 + 16 ks + 8 (l >> 5) + 0..7][mb * 32 + (l & 31)]; zero beyond Ci / M.
+__global__ __launch_bounds__(256) void srf_x3w_pack_dec_kernel(const float* __restrict__ w, char* __restrict__ dst, int Ci, int M,
+                                                               int nblocks) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // one thread per (block, mb, ks, lane): 8 values, both parts
+  if (idx >= nblocks * 4 * 64) return;
+  const int lane = idx & 63, ks = (idx >> 6) & 1, mb = (idx >> 7) & 1, blk = idx >> 8;
+  const int m = mb * 32 + (lane & 31);
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = blk * 32 + 16 * ks + 8 * (lane >> 5) + e;
+    const float v = (ci < Ci && m < M) ? w[(size_t)ci * M + m] : 0.f;
+    const __bf16 h = (__bf16)v;
+    hi[e] = h;
+    lo[e] = (__bf16)(v - (float)h);
+  }
+  char* o = dst + ((size_t)(blk * 2 + mb) * 4 + ks * 2) * 1024 + lane * 16;
+  *reinterpret_cast<bf16x8*>(o) = hi;
+  *reinterpret_cast<bf16x8*>(o + 1024) = lo;
+}
+
+size_t srf_x3w_dec_pack_bytes(int Ci) { return (size_t)((Ci + W_BM - 1) / W_BM) * 8 * 8192; }
+
+int srf_x3w_pack_dec_launch(const float* w, void* dst, int Ci, int M, hipStream_t st) {
+  SRF_CHECK_ARG(w && dst && Ci > 0 && M > 0 && M <= 64, "srf_pack_decoder: bad arguments");
+  const int nblocks = (Ci + W_BM - 1) / W_BM * 8;
+  const int threads = nblocks * 4 * 64;
+  hipLaunchKernelGGL(srf_x3w_pack_dec_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, w, (char*)dst, Ci, M, nblocks);
+  SRF_CHECK_LAUNCH("pack_decoder", st);
+  return SRF_OK;
+}
+
+// The model's tail in one GEMM launch: partial decoder frames zpart[Bt][ceil(Cout / 256)][M][L] instead of the masked tensor
+int srf_pw_x3w_fused_tail_launch(const PwArgs& a, const char* wpack, const char* wdpack, float* zpart, int M, hipStream_t st) {
+  SRF_CHECK_ARG(wdpack && zpart && M > 0 && M <= 64, "srf_mask_decode: bad arguments");
+  SRF_CHECK_ARG(a.nrm.prelu && !a.nrm.sums && (a.epi_mask & 1) && !a.residual && !a.out_sums && a.mul,
+                "srf_mask_decode: needs the PReLU prologue and the mask epilogue");
+  return srf_pw_x3w_launch_any(a, wpack, 3, wdpack, zpart, M, st);
+}
+
+static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, const char* fuse_wd, float* fuse_z, int fuse_M,
+                                 hipStream_t st) {
   const int nMt = (a.Cout + W_BM - 1) / W_BM, nLt = (a.L + W_BN - 1) / W_BN;
   const long total = (long)a.Bt * nMt * nLt;
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
@@ -627,6 +859,7 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
         (const void*)&srf_pw_x3w_kernel<3, 2, 0, 0>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, 1>,
         (const void*)&srf_pw_x3w_kernel<3, 2, 0, 4>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, 5>,
         (const void*)&srf_pw_x3w_kernel<3, 2, 0, 13>,
+        (const void*)&srf_pw_x3w_kernel<3, 4, 0, 0>, (const void*)&srf_pw_x3w_kernel<3, 4, 0, 4>,
         // any other prologue / epilogue combination (unit tests, stand-alone srf_pw_conv callers)
         (const void*)&srf_pw_x3w_kernel<0, 3>, (const void*)&srf_pw_x3w_kernel<1, 3>,
         (const void*)&srf_pw_x3w_kernel<2, 3>, (const void*)&srf_pw_x3w_kernel<3, 3>,
@@ -657,7 +890,7 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   if (!(srf_debug_flags() & 512)) ap.epi_mask |= 1 << 12;   // quarter tiles first (flag 512: last)
   ap.epi_mask |= ((srf_debug_flags() >> 22) & 3) << 8;      // diagnostics: start-up stagger units (flag bits 22-23)
   const bool res = a.residual != nullptr, mask = !res && (a.epi_mask & 1);
-#define W_GO(P, E, A, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta)
+#define W_GO(P, E, A, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M)
   // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated above),
   // 1 << 25 = in-kernel timeline (tools/gemm_timeline.py), 1 << 30 = epilogue without its stores
   const int abl = ((srf_debug_flags() >> 16) & 63) | ((srf_debug_flags() & (1 << 25)) ? 64 : 0) |
@@ -705,6 +938,12 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   const int cp_flag = (srf_debug_flags() >> 26) & 15;
   static const int kDefaultCp[4] = {0, 5, 5, 5};
   const int cp = cp_flag ? cp_flag - 1 : kDefaultCp[pro < 0 || pro > 3 ? 0 : pro];
+  if (fuse_wd) {
+    if (cp & 4) W_GO(3, 4, 0, 4);
+    else W_GO(3, 4, 0, 0);
+    SRF_CHECK_LAUNCH("pw_mask_decode", st);
+    return SRF_OK;
+  }
 #define W_CP4(P, E) switch (cp & 7) { case 1: W_GO(P, E, 0, 1); break; case 4: W_GO(P, E, 0, 4); break; case 5: W_GO(P, E, 0, 5); break; default: W_GO(P, E, 0, 0); break; }
 #define W_CP5(P, E) switch (cp) { case 1: W_GO(P, E, 0, 1); break; case 4: W_GO(P, E, 0, 4); break; case 5: W_GO(P, E, 0, 5); break; \
     case 13: W_GO(P, E, 0, 13); break; default: W_GO(P, E, 0, 0); break; }

@@ -70,7 +70,14 @@ def _packable(cin, cout):
     return cin % 64 == 0 and cin >= 128 and cout >= 192
 
 
-def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, packed=True):
+def fused_tail(B, N, SA, K, L, Bt, kernel_mode=0, packed=True, cus=256):
+    """Mirror of srf_mask_decode_supported() (srf_pwconv.hip): whether srf_forward runs its tail as one GEMM launch."""
+    return (kernel_mode == 0 and packed and SA * K <= 64 and _packable(B, SA * N) and (SA * N) % 8 == 0 and N % 8 == 0 and
+            B % 32 == 0 and L % 4 == 0 and Bt <= 1024 and Bt * B * L * 4 < 2 ** 31 and
+            Bt * ((SA * N + 255) // 256) * ((L + 127) // 128) >= cus)
+
+
+def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, packed=True, fuse_tail=True):
     """(family, algorithmic_bytes, flops) for every kernel launch of one srf_forward, in launch order
     (mirrors srf_api.hip).  Bytes = tensors each kernel must read + write once, fp32."""
     L = frames(T, K, D)
@@ -108,6 +115,14 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, p
                 out.append(("dwconv5", f * Bg * nC * (lin + lout), 2.0 * 5 * Bg * nC * lout))
             out.append(("merge", f * Bg * nC * (sum(L >> k for k in range(D)) + L), 2.0 * D * Bg * nC * L))
         out.append(pw(nC, nB, Bg, extra_in=nB))
+    if fuse_tail and fused_tail(B, N, SA, K, L, Bt, kernel_mode, packed):
+        # K5: mask GEMM + decoder contraction in one launch (srf_pwconv_x3w.hip EPI 4): the masked tensor is never stored;
+        # per-256-channel partial frames [Bt, nparts, SA K, L] instead, summed by the overlap-add
+        M, nparts = SA * K, (SA * N + 255) // 256
+        out.append(("pack_decoder", f * SA * N * M + 8192.0 * 8 * nparts, 0.0))
+        out.append(("pw_mask_decode", f * Bt * L * (B + N + nparts * M), 2.0 * Bt * L * SA * N * (B + M)))
+        out.append(("overlap_add", f * Bt * (nparts * M * L + SA * T), 3.0 * nparts * Bt * SA * T))
+        return out
     out.append(pw(B, SA * N, Bt, extra_in=N))
     out.append(("transpose", f * 2 * SA * N * SA * K, 0.0))
     out.append(("zero_fill", f * 64 * ((SA * K + 63) // 64), 0.0))   # the frame GEMM's zero bias

@@ -104,8 +104,8 @@ def test_unfused_pyramid_agrees(manifest, name):
 
 
 # (case, bench batch, kernel families the single-stream forward MUST have been dispatched to)
-_X3V = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_conv_x3v<3>"}
-_BENCH_BATCH = [("cfg2_improved_u16", 32, _X3V), ("cfg3_groupcomm_u8", 32, {"pw_conv_x3v<1>", "pw_conv_x3v<3>", "pw_conv_small"}),
+_X3V = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_mask_decode"}
+_BENCH_BATCH = [("cfg2_improved_u16", 32, _X3V), ("cfg3_groupcomm_u8", 32, {"pw_conv_x3v<1>", "pw_mask_decode", "pw_conv_small"}),
                 ("cfg4_improved_u36_n2048", 32, _X3V), ("cfg5_improved_u36_n4096", 16, _X3V)]
 
 
@@ -143,13 +143,15 @@ def test_bench_batch_examples_match_reference_golden(manifest, case, batch, fami
         assert not missing, "single-stream forward did not run %s (ran %s)" % (sorted(missing), sorted(tr.names))
         count = {n: sum(1 for k, _ in tr.launches if k == n) for n in tr.names}
         U = cfg.num_blocks
-        if cfg.variant == "improved":     # bottleneck, U x proj_1x1, U x res_conv, mask -- ALL on the 256 x 128 kernel
-            assert (count["pw_conv_x3v<1>"], count["pw_conv_x3v<0>"], count["pw_conv_x3v<2>"], count["pw_conv_x3v<3>"]) == \
+        if cfg.variant == "improved":     # bottleneck, U x proj_1x1, U x res_conv, mask + decoder -- ALL on the 256 x 128 kernel
+            assert (count["pw_conv_x3v<1>"], count["pw_conv_x3v<0>"], count["pw_conv_x3v<2>"], count["pw_mask_decode"]) == \
                 (1, U, U, 1), count
         else:                             # GroupComm: bottleneck + mask on it, the per-group convs on the thin-shape kernel
-            assert (count["pw_conv_x3v<1>"], count["pw_conv_x3v<3>"], count["pw_conv_small"]) == (1, 1, 2 * U), count
-        # (the only GEMM left on the 128 x 128 kernels is the decoder's 42-row frame GEMM)
-        assert sum(v for k, v in count.items() if k.startswith("pw_conv_bf16x3") or k == "pw_conv_mfma") == 1, count
+            assert (count["pw_conv_x3v<1>"], count["pw_mask_decode"], count["pw_conv_small"]) == (1, 1, 2 * U), count
+        # (the fused tail contracts the masked values with the decoder inside the mask GEMM: no GEMM is left on the 128 x 128
+        # kernels and the masked tensor is never stored)
+        assert sum(v for k, v in count.items() if k.startswith("pw_conv_bf16x3") or k == "pw_conv_mfma") == 0, count
+        assert "pw_conv_x3v<3>" not in count and "transpose" not in count, count
         eng.multi_stream = True
         for parts in eng._split_candidates(batch)[1:]:        # the explicit splits: halves and 5 : 3
             out = torch.empty_like(out)
@@ -164,6 +166,49 @@ def test_bench_batch_examples_match_reference_golden(manifest, case, batch, fami
         check(out, "auto-tuned %s" % (eng._split_choice.get((x.device.index, batch, x.shape[-1])),))
     finally:
         eng.multi_stream = True
+
+
+@pytest.mark.parametrize("case,batch", [("cfg2_improved_u16", 32), ("cfg3_groupcomm_u8", 32), ("cfg1_improved_u8", 24)])
+@pytest.mark.parametrize("recipe", [False, True])
+def test_fused_tail_agrees_with_materialised_masked_tensor(manifest, case, batch, recipe):
+    """K5 A/B: the mask GEMM fused with the decoder's contraction (partial frames, no masked tensor) against the same forward
+    with debug flag 32768 = mask GEMM -> masked tensor -> frame GEMM -> overlap-add; plain forward and the separate() recipe
+    (rescale + mixture consistency folded into the overlap-add).  Run-to-run identical (fixed summation order)."""
+    from sudo_rm_rf_amd import ops
+    cfg, sd, wav, gold = load_case(manifest, case)
+    model = build(cfg, sd)
+    nb = wav.shape[0]
+    reps = np.concatenate([wav] * ((batch + nb - 1) // nb), axis=0)[:batch]
+    x = torch.from_numpy(reps).to(DEV) * (3.0 if recipe else 1.0) + (0.25 if recipe else 0.0)
+    eng = model._engine()
+
+    def run():
+        with torch.no_grad(), ops.kernel_trace(DEV) as tr:
+            out = eng.separate(model, x, True) if recipe else model(x)
+        return out.clone(), tr.names
+
+    try:
+        eng.multi_stream = False
+        fused, names = run()
+        assert "pw_mask_decode" in names, sorted(names)
+        again, _ = run()
+        assert torch.equal(fused, again)
+        ops.set_debug_flags(32768)
+        plain, names = run()
+        assert "pw_mask_decode" not in names and "pw_conv_x3v<3>" in names, sorted(names)
+    finally:
+        ops.set_debug_flags(0)
+        eng.multi_stream = True
+    if not recipe:      # the masked tensor does not exist after a fused forward: asking for it must fail, not return partial frames
+        plan = eng.last_plan
+        with pytest.raises(Exception, match="not materialised"):
+            plan.debug_fetch(2, (batch, cfg.num_sources * cfg.enc_num_basis, plan.frames))
+    err = float((fused - plain).abs().max())
+    print(f"{case} batch {batch} recipe={recipe}: fused vs materialised tail max abs diff = {err:.3e}")
+    assert err <= 2e-5 * max(1.0, float(plain.abs().max()))
+    if not recipe:
+        worst = max(float(np.abs(fused[i].cpu().numpy() - gold["out"][i % nb]).max()) for i in range(batch))
+        assert worst <= TOL
 
 
 def test_run_to_run_determinism(manifest):
