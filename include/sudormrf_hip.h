@@ -110,7 +110,8 @@ int srf_profile_get(int i, const char** name, float* ms);
  *   16       per-level depthwise + merge kernels instead of the fused pyramid (inference and training)
  *   32 / 64  LDS pyramid kernels instead of the register ones      128       non-persistent pyramid pass 1
  *   256      leftover GEMM tiles as whole tiles (no quarter tiles) 512       quarter tiles last
- *   1024     TAC forward with one time step per lane               2048      one-tile-per-block GEMM everywhere
+ *   1024     TAC forward with one time step per lane               2048      one-tile-per-block 128 x 128 GEMM everywhere
+ *                                                                            (also: no 64 x 64 tiles for small launches)
  *   16384    round 2's 256 x 128 GEMM (srf_pwconv_x3v.hip) instead of round 3's (srf_pwconv_x3w.hip)
  *   32768    WITHOUT the fused tail: mask GEMM -> masked tensor -> decoder frame GEMM -> overlap-add as separate launches
  *   bits 12-13, 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating)

@@ -43,7 +43,10 @@ __global__ __launch_bounds__(256) void srf_encoder_fast_kernel(const float* __re
   const int la = l0 + lane, lb = l0 + 64 + lane;
   const bool va = la < L, vb = lb < L;
   double ds = 0.0, dq = 0.0;
-  for (int n = wave; n < N; n += 4) {
+  // blockIdx.z: a slice of the basis (small batches: 25 blocks per 4-s example would leave 9 of 10 CUs idle)
+  const int per = ((N + (int)gridDim.z - 1) / (int)gridDim.z + 3) & ~3;
+  const int n_lo = blockIdx.z * per, n_hi = min(N, n_lo + per);
+  for (int n = n_lo + wave; n < n_hi; n += 4) {
     const float* wn = w + (size_t)n * KT;
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void srf_encoder_fast_kernel(const float* __re
     ds += (double)s;
     dq += (double)q;
   }
-  if (sums) srf_block_stats_atomic<4>(ds, dq, srf_stat_slot(sums, b, blockIdx.x), red);
+  if (sums) srf_block_stats_atomic<4>(ds, dq, srf_stat_slot(sums, b, blockIdx.x + blockIdx.z * gridDim.x), red);
 }
 
 // Generic path: any A, any odd K.  64 frames per block, window in dynamic LDS, taps read from LDS in
@@ -132,7 +135,10 @@ int srf_encoder_impl(const float* wav, const float* w, float* out, double* sums,
   SRF_CHECK_ARG(Bt <= 65535, "srf_encoder: batch %d too large for one launch", Bt);
   hipStream_t st = (hipStream_t)stream;
   if (srf_kernel_mode() != 1 && A == 1 && K == 21) {
-    dim3 grid((L + 127) / 128, Bt);
+    const long bxy = (long)((L + 127) / 128) * Bt, want = 2L * srf_device_cus();
+    int nz = bxy >= want ? 1 : (int)((want + bxy - 1) / bxy);
+    nz = nz > N / 16 ? (N / 16 > 0 ? N / 16 : 1) : nz;       // at least 16 basis functions per block
+    dim3 grid((L + 127) / 128, Bt, nz);
     hipLaunchKernelGGL(srf_encoder_fast_kernel<21>, grid, dim3(256), 0, st, wav, w, out, sums, T, N, L, in_stats);
   } else {
     const int H = K / 2;

@@ -204,6 +204,8 @@ __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int
 }
 
 int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st);
+int srf_pw_w4_launch(const PwArgs& a, int pro, hipStream_t st);   // 64 x 64 tiles for small launches (srf_pwconv_w4.hip)
+bool srf_pw_w4_wanted(const PwArgs& a);
 int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
 int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);   // round 3 (srf_pwconv_x3w.hip)
 bool srf_x3w_supported(int Bt, int pro);
@@ -357,6 +359,8 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
       return SRF_OK;
     }
   }
+  // launches that would leave CUs idle on 128 x 128 tiles (a batch-1 forward): 64 x 64 tiles, four times the blocks
+  if (mfma_ok && mode == 0 && (Cin % 64 == 0) && srf_aligned16(y) && srf_pw_w4_wanted(a)) return srf_pw_w4_launch(a, pro_sel, st);
   if (mfma_ok && mode == 0 && (Cin % 64 == 0)) return srf_pw_bf16x3_launch(a, pro_sel, st);
   if (mfma_ok) {
     const int nMt = (Cout + PW_BM - 1) / PW_BM, nLt = (L + PW_BN - 1) / PW_BN;
