@@ -105,7 +105,8 @@ int srf_profile_get(int i, const char** name, float* ms);
  * NOT part of the drop-in surface: process-wide switches between kernel variants for A/B measurements and bisection
  * (tools/, bench.py --debug-flags, a handful of tests).  They act on every thread's subsequent launches; a caller that does
  * not define SRF_DIAGNOSTICS before including this header does not see them.  Default 0 = the shipped paths.
- *   2        swap the GEMM's fragment-read order                   4         without the 256 x 128 GEMM (128 x 128 kernels)
+ *   2        round-2 GEMM: swap the fragment-read order; round-3 GEMM: no m-tile groups (round 2's tile order)
+ *   4        without the 256 x 128 GEMM (128 x 128 kernels)
  *   8        WITHOUT pre-packed weights (srf_forward packs by default)
  *   16       per-level depthwise + merge kernels instead of the fused pyramid (inference and training)
  *   32 / 64  LDS pyramid kernels instead of the register ones      128       non-persistent pyramid pass 1

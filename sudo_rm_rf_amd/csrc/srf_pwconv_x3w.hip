@@ -70,7 +70,7 @@ template <int PRO, int EPI, int ABL = 0, int CP = 0>
 __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt,
                                                             int total, int rounds, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ bias_r,
-                                                            const char* __restrict__ wdpack, float* __restrict__ zpart, int zM) {
+                                                            const char* __restrict__ wdpack, float* __restrict__ zpart, int zM, int mgrp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // W_NSTAGE * W_STAGE (+ the statistics table)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -116,20 +116,33 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     __syncthreads();
   }
 
+  // Tile order: virtual id v = mi + G (lt + nLt (b + Bt grp)), m-tile = grp G + mi.  G = nMt (one group; the default) is the
+  // order of srf_pwconv_x3v.hip: the nMt blocks that share one activation tile are neighbours on one XCD.  G < nMt (host: when
+  // the packed weights exceed what an XCD's 4-MB L2 can keep -- the mask GEMMs of cfg 4 / cfg 5, 8 / 16 MB) gives every XCD a
+  // GROUP of G m-tiles whose weight slabs stay L2-resident while it walks the (example, time) tiles; all XCDs walk those in the
+  // same order at the same pace, so the activation tile one of them fetched from HBM is a MALL hit for the others.  Before:
+  // every XCD re-fetched ALL weights every round -- PMC, cfg-5 mask GEMM: 35.2 GB of L2 misses per launch against 3.8 GB
+  // algorithmic; with groups 15.6 GB and 6.31-6.36 vs 6.48-6.49 ms (same box).  (Non-temporal loads of the encoder multiplier
+  // on top: 12.7 GB, but no faster at cfg 5 and 1 % slower at cfg 4 -- not kept.)
   struct TileCur {
-    int i, v, mt, lt, b, q;   // q: -1 = full tile, 0..3 = quarter of its parent tile; v < 0: no tile
+    int i, v, mt, lt, b, q, mi, grp;   // q: -1 = full tile, 0..3 = quarter of its parent tile; v < 0: no tile
   };
+  const int G = mgrp;
   const int vstep = nblk >> 3;
-  const int st_b = vstep / (nMt * nLt), st_r = vstep - st_b * (nMt * nLt);
-  const int st_l = st_r / nMt, st_m = st_r - st_l * nMt;
+  const int st_mi = vstep % G, st_r1 = vstep / G;
+  const int st_l = st_r1 % nLt, st_r2 = st_r1 / nLt;
+  const int st_b = st_r2 % a.Bt, st_g = st_r2 / a.Bt;
   const int qfirst = (a.epi_mask >> 12) & 1 ? nq_mine : 0;     // tiles [0, qfirst) are quarter tiles, then the full ones
   auto is_quarter = [&](int i) { return qfirst ? i < qfirst : i >= rounds; };
   auto cur_from_v = [&](TileCur& c, int v) {
-    const int t = v / nMt;
+    const int t = v / G;
     c.v = v;
-    c.mt = v - t * nMt;
-    c.b = t / nLt;
-    c.lt = t - c.b * nLt;
+    c.mi = v - t * G;
+    const int u = t / nLt;
+    c.lt = t - u * nLt;
+    c.grp = u / a.Bt;
+    c.b = u - c.grp * a.Bt;
+    c.mt = c.grp * G + c.mi;
   };
   auto cur_set = [&](TileCur& c, int i) {   // by division: a block's first tile and its quarter tiles
     int p = blockIdx.x + (i - qfirst) * nblk;
@@ -150,13 +163,17 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     }
     c.i = i;
     c.v += vstep;
-    c.mt += st_m;
-    int cy = c.mt >= nMt ? 1 : 0;
-    c.mt -= cy ? nMt : 0;
+    c.mi += st_mi;
+    int cy = c.mi >= G ? 1 : 0;
+    c.mi -= cy ? G : 0;
     c.lt += st_l + cy;
     cy = c.lt >= nLt ? 1 : 0;
     c.lt -= cy ? nLt : 0;
     c.b += st_b + cy;
+    cy = c.b >= a.Bt ? 1 : 0;
+    c.b -= cy ? a.Bt : 0;
+    c.grp += st_g + cy;
+    c.mt = c.grp * G + c.mi;
   };
   // ---- B staging geometry: thread -> time step n = tid & 127, k-group kg = tid >> 7 (wave-uniform), 8 k rows
   const int b_n = tid & 127, b_c = wave >> 1, b_kg = b_c * 8;
@@ -885,12 +902,24 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
   if (nb > total) nb = total - total % 8;   // (the tile cursors need nb % 8 == 0; the host dispatches this kernel for total >= #CUs)
   SRF_CHECK_ARG(nb >= 8, "srf_pw_conv: too few tiles for the 256 x 128 kernel");
   const int rounds = (srf_debug_flags() & 256) ? (int)((total + nb - 1) / nb) : (int)(total / nb);
+  // m-tile groups (see the tile cursors): as many m-tiles as keep their packed weight slabs (256 x Cin x 4 B each) within half
+  // of an XCD's 4-MB L2, when the whole weight image does not fit it.  Debug flag 2 (the round-2 kernel's fragment-read order,
+  // unused by this kernel) = one group = the round-2 tile order, for A/B.
+  int mgrp = nMt;
+  {
+    const long slab = (long)W_BM * a.Cin * 4, image = slab * nMt;
+    if (image > (3L << 20) && !(srf_debug_flags() & 2)) {
+      int g = (int)((2L << 20) / slab);
+      while (g > 1 && nMt % g) --g;
+      if (g >= 1 && g < nMt) mgrp = g;
+    }
+  }
   dim3 grid((unsigned)nb), block(512);
   PwArgs ap = a;
   if (!(srf_debug_flags() & 512)) ap.epi_mask |= 1 << 12;   // quarter tiles first (flag 512: last)
   ap.epi_mask |= ((srf_debug_flags() >> 22) & 3) << 8;      // diagnostics: start-up stagger units (flag bits 22-23)
   const bool res = a.residual != nullptr, mask = !res && (a.epi_mask & 1);
-#define W_GO(P, E, A, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M)
+#define W_GO(P, E, A, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
   // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated above),
   // 1 << 25 = in-kernel timeline (tools/gemm_timeline.py), 1 << 30 = epilogue without its stores
   const int abl = ((srf_debug_flags() >> 16) & 63) | ((srf_debug_flags() & (1 << 25)) ? 64 : 0) |
