@@ -151,6 +151,9 @@ static int srf_zero_launch(void* p, size_t bytes, hipStream_t st) {
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
 int srf_overlap_add_launch(const float* z, float* out, int Bt, int Co, int K, int L, int T, int nparts, const float* stats,
                            const float* wav, int mc, hipStream_t st);
+bool srf_pw_conv_preadd_supported(int Cin, int Cout, int L, const void* const* ptrs, int nptrs);
+int srf_pw_conv_preadd(const float* x, const float* q, const srf_norm* qnorm, float* u, const float* w, const float* bias,
+                       float* y, int Bt, int Cin, int Cout, int L, double* out_sums, hipStream_t st);
 bool srf_mask_decode_supported(int Bt, int Cin, int Cout, int L, int M);
 size_t srf_mask_decode_pack_bytes(int Cout);
 int srf_mask_decode_pack(const float* wd, void* dst, int Ci, int M, hipStream_t st);
@@ -425,6 +428,7 @@ static int srf_forward_impl(const srf_plan* p, const float* const* P, int num_pa
     const float* const* Pu = Pb + p->p_ublock_off;
     int s0 = 1 + i * p->slots_per_block;
     const float* xin = cur;
+    bool tac_norm_fused = false;
     if (gc) {
       // TAC (groupcomm_sudormrf_v2.py:356-384): q = TAC MLPs, u = x + GlobLN_(b,g)(q)
       float* xq = fptr(p->off_xq);
@@ -432,16 +436,26 @@ static int srf_forward_impl(const srf_plan* p, const float* const* P, int num_pa
       rc = srf_tac(cur, xq, Pb, Bt, G, nB, 3 * nB, L, slot(s0), stream);
       if (rc) return rc;
       srf_norm tn{slot(s0), Pb[9], Pb[10], nullptr};
-      rc = srf_gln_apply_add(cur, xq, xu, &tn, Bg, nB, L, stream);
+      // u = x + GlobLN(q): folded into the proj conv's operand load where the thin-shape kernel runs it (it writes u for
+      // the block's residual as it goes); else its own kernel
+      const void* al[4] = {cur, xq, xu, y1};
+      tac_norm_fused = srf_pw_conv_preadd_supported(nB, nC, L, al, 4);
+      if (tac_norm_fused) {
+        rc = srf_pw_conv_preadd(cur, xq, &tn, xu, Pu[0], Pu[1], y1, Bg, nB, nC, L, slot(s0 + 1), st);
+      } else {
+        rc = srf_gln_apply_add(cur, xq, xu, &tn, Bg, nB, L, stream);
+      }
       if (rc) return rc;
       xin = xu;
       s0 += 1;
     }
     // proj_1x1 conv (+ statistics for its GlobLN)            improved_sudormrf.py:205
     const int pu_index = p->p_block0 + i * p->p_block_stride + p->p_ublock_off;
-    rc = srf_pw_conv_packed(xin, Pu[0], packed(pu_index), Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0),
-                            0, nullptr, 0, stream);
-    if (rc) return rc;
+    if (!tac_norm_fused) {
+      rc = srf_pw_conv_packed(xin, Pu[0], packed(pu_index), Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0),
+                              0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
     // depthwise pyramid + upsample/add                         :206-216
     // unfused path: the merged tensor aliases y1 (dead once every level has been produced); fused path:
     // its own buffer (the otherwise unused level-0 buffer), because pass 2 re-reads y1 with halos

@@ -17,6 +17,12 @@ struct PwArgs {
   int Cin, Cout, L, Bt;
   int mul_channels;
   int epi_mask;
+  // srf_pwconv_small.hip only: the conv's input is u = x + GlobLN(pre_q) (GroupComm's TAC norm + residual,
+  // groupcomm_sudormrf_v2.py:381-384, folded into this conv's load); u is also written to pre_u (the block's residual)
+  const float* pre_q = nullptr;
+  float* pre_u = nullptr;
+  SrfNormDev pre_nrm = {nullptr, nullptr, nullptr, nullptr};
+  double pre_inv_count = 0.0;
 };
 
 

@@ -269,6 +269,43 @@ int srf_mask_decode(const float* x, const float* w, const void* w_packed, const 
                                       M, st);
 }
 
+// ---- GroupComm (library-internal; srf_forward): proj_1x1 with the TAC's "x + GlobLN(q)" folded into its operand load ----
+// y = W u + bias, u = x + GlobLN_qnorm(q) written to `u` as well (the block's residual); out_sums as in srf_pw_conv.
+// Only the register-resident thin-shape kernel (srf_pwconv_small.hip) has this prologue.
+bool srf_pw_conv_preadd_supported(int Cin, int Cout, int L, const void* const* ptrs, int nptrs) {
+  if (srf_kernel_mode() == 1 || !srf_pw_small_supported(Cin, Cout, L)) return false;
+  for (int i = 0; i < nptrs; ++i)
+    if (!srf_aligned16(ptrs[i])) return false;
+  return true;
+}
+int srf_pw_conv_preadd(const float* x, const float* q, const srf_norm* qnorm, float* u, const float* w, const float* bias,
+                       float* y, int Bt, int Cin, int Cout, int L, double* out_sums, hipStream_t st) {
+  SRF_CHECK_ARG(x && q && qnorm && qnorm->sums && qnorm->gamma && qnorm->beta && u && w && bias && y, "srf_pw_conv_preadd: null pointer");
+  const void* ptrs[4] = {x, q, u, y};
+  SRF_CHECK_ARG(srf_pw_conv_preadd_supported(Cin, Cout, L, ptrs, 4), "srf_pw_conv_preadd: unsupported shape");
+  PwArgs a;
+  a.x = x;
+  a.w = w;
+  a.bias = bias;
+  a.y = y;
+  a.residual = nullptr;
+  a.out_sums = out_sums;
+  a.mul = nullptr;
+  a.nrm = srf_norm_dev(nullptr);
+  a.inv_count = 1.0 / ((double)Cin * (double)L);
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.L = L;
+  a.Bt = Bt;
+  a.mul_channels = 1;
+  a.epi_mask = 0;
+  a.pre_q = q;
+  a.pre_u = u;
+  a.pre_nrm = srf_norm_dev(qnorm);
+  a.pre_inv_count = 1.0 / ((double)Cin * (double)L);
+  return srf_pw_small_launch(a, st);
+}
+
 extern "C" size_t srf_packed_pw_weight_bytes(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0 || !srf_x3v_supported(Cin, Cout, 4)) return 0;
   return srf_x3v_packed_bytes(Cout, Cin);

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void srf_pw_small_kernel(
     // weights / bias / affine again as noalias kernel arguments: only then are they provably not
     // clobbered by the stores to y and fetched with scalar loads (SGPR operands) instead of VMEM
     const float* __restrict__ wgt, const float* __restrict__ bias, const float* __restrict__ gamma,
-    const float* __restrict__ beta) {
+    const float* __restrict__ beta, const float* __restrict__ pre_gamma, const float* __restrict__ pre_beta) {
   typedef typename SrfVec<VEC>::type vecf;
   constexpr int MC = 4;   // outputs per pass: MC*CIN weights must fit the SGPR file
   const int lane = threadIdx.x & 63;
@@ -48,6 +48,24 @@ __global__ __launch_bounds__(256) void srf_pw_small_kernel(
   vecf x[CIN];
 #pragma unroll
   for (int k = 0; k < CIN; ++k) x[k] = *reinterpret_cast<const vecf*>(xb + (size_t)k * a.L);
+  if (a.pre_q) {
+    // u = x + GlobLN(q) on load -- exactly srf_gln_apply_kernel<true>'s arithmetic (fmaf(q, gamma rstd, beta - mean gamma rstd),
+    // then the add), so the fused forward is bitwise the unfused one -- and u goes out once, for the block's residual.
+    // Saves the separate kernel's launch and one read of the [Bt, B, L] tensor per block.
+    float pm, pr;
+    srf_finalize_stats(a.pre_nrm.sums, b, a.pre_inv_count, pm, pr);
+    const float* qb = a.pre_q + (size_t)b * CIN * a.L + lc;
+    float* ub = a.pre_u + (size_t)b * CIN * a.L + lc;
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) {
+      const vecf qv = *reinterpret_cast<const vecf*>(qb + (size_t)k * a.L);
+      const float sc = pre_gamma[k] * pr;
+      const float sh = pre_beta[k] - pm * sc;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[k][v] = x[k][v] + fmaf(qv[v], sc, sh);
+      if (valid) *reinterpret_cast<vecf*>(ub + (size_t)k * a.L) = x[k];
+    }
+  }
   if (has_norm) {
 #pragma unroll
     for (int k = 0; k < CIN; ++k) {
@@ -120,7 +138,7 @@ static void srf_pw_small_go(const PwArgs& a, hipStream_t st) {
   const long total = (long)a.Bt * wavesPerRow;
   dim3 grid((unsigned)((total + 3) / 4)), block(256);
   hipLaunchKernelGGL((srf_pw_small_kernel<CIN, COUT, VEC>), grid, block, 0, st, a, wavesPerRow, (int)total,
-                     a.w, a.bias, a.nrm.gamma, a.nrm.beta);
+                     a.w, a.bias, a.nrm.gamma, a.nrm.beta, a.pre_nrm.gamma, a.pre_nrm.beta);
 }
 
 template <int CIN>

@@ -95,12 +95,19 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, p
         return ("pw_conv", f * bt * L * (cin + cout + extra_in), 2.0 * bt * cin * cout * L)
 
     out.append(pw(N, B, Bt))
+    preadd = False
     for _ in range(U):
         if variant == "groupcomm":
             n, h = nB, 3 * nB
             out.append(("tac", f * Bt * B * L * 2, 2.0 * Bt * L * (2 * G * n * h + h * h + n * h + G * n * h)))
-            out.append(("gln_apply_add", f * Bt * B * L * 3, 3.0 * Bt * B * L))
-        out.append(pw(nB, nC, Bg))
+            # u = x + GlobLN(q): folded into the proj conv's load on the thin-shape kernel (srf_pw_conv_preadd_supported)
+            preadd = kernel_mode != 1 and nB in (8, 16, 32) and nC in (8, 16, 32, 64) and L % 4 == 0
+            if preadd:
+                out.append(("pw_conv", f * Bg * L * (3 * nB + nC), 2.0 * Bg * nB * nC * L + 3.0 * Bt * B * L))
+            else:
+                out.append(("gln_apply_add", f * Bt * B * L * 3, 3.0 * Bt * B * L))
+        if not (variant == "groupcomm" and preadd):
+            out.append(pw(nB, nC, Bg))
         dw_flops = 2.0 * 5 * Bg * nC * sum(L >> k for k in range(D))
         if kernel_mode != 1 and pyramid_fused(nC, L, D):
             if pyramid_tiled(L, D) and not pyramid_regs(L, D):
