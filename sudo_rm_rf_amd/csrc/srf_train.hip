@@ -23,6 +23,9 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
                      int mode, void* stream);
 bool srf_dwconv5_bwd_rowwise_ok(int Lin, int stride, const void* const* ptrs, int nptrs);
 bool srf_pyramid_reg_supported(int L, int D);
+bool srf_pw_conv_preadd_supported(int Cin, int Cout, int L, const void* const* ptrs, int nptrs);
+int srf_pw_conv_preadd(const float* x, const float* q, const srf_norm* qnorm, float* u, const float* w, const float* bias,
+                       float* y, int Bt, int Cin, int Cout, int L, double* out_sums, hipStream_t st);
 int srf_pyramid_impl(const float* y1, float* merged, const srf_norm* in_norm, const float* const* w,
                      const float* const* bias, const float* const* gamma, const float* const* beta, int groups, int C,
                      int L, int D, void* scratch, double* out_sums, float* const* lv_out, double* const* lv_sums,
@@ -224,6 +227,7 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
     float* y1 = (float*)(blk + t.y1);
     float* merged = (float*)(blk + t.merged);
     const float* xin = xbuf(i);
+    bool tac_norm_fused = false;
     if (gc) {
       // TAC: q = MLPs(x), u = x + GlobLN_(b,g)(q)                 groupcomm_sudormrf_v2.py:356-384
       float* q = (float*)(blk + t.q);
@@ -231,13 +235,22 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
       rc = srf_tac(xin, q, Pb, Bt, G, nB, 3 * nB, L, slot(s0), stream);
       if (rc) return rc;
       srf_norm tn{slot(s0), Pb[9], Pb[10], nullptr};
-      rc = srf_gln_apply_add(xin, q, u, &tn, Bg, nB, L, stream);
+      // u = x + GlobLN(q) folded into the proj conv's operand load where the thin-shape kernel runs it (as in srf_forward;
+      // bitwise the separate kernels' results, u is still written: the backward reads it)
+      const void* al[4] = {xin, q, u, y1};
+      tac_norm_fused = srf_pw_conv_preadd_supported(nB, nC, L, al, 4);
+      if (tac_norm_fused)
+        rc = srf_pw_conv_preadd(xin, q, &tn, u, Pu[0], Pu[1], y1, Bg, nB, nC, L, slot(s0 + 1), st);
+      else
+        rc = srf_gln_apply_add(xin, q, u, &tn, Bg, nB, L, stream);
       if (rc) return rc;
       xin = u;
       s0 += 1;
     }
-    rc = srf_pw_conv(xin, Pu[0], Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0), 0, nullptr, 0, stream);
-    if (rc) return rc;
+    if (!tac_norm_fused) {
+      rc = srf_pw_conv(xin, Pu[0], Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0), 0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
     // The pyramid: the two fused passes of the inference path with the per-level conv outputs d_k and their
     // statistics written on the side (what the backward reads) when the register-resident kernels cover the shape;
     // otherwise D depthwise kernels + the merge kernel.
