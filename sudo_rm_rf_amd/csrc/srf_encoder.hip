@@ -135,7 +135,10 @@ int srf_encoder_impl(const float* wav, const float* w, float* out, double* sums,
   SRF_CHECK_ARG(Bt <= 65535, "srf_encoder: batch %d too large for one launch", Bt);
   hipStream_t st = (hipStream_t)stream;
   if (srf_kernel_mode() != 1 && A == 1 && K == 21) {
-    const long bxy = (long)((L + 127) / 128) * Bt, want = 2L * srf_device_cus();
+    // basis slices per (time tile, example): many small blocks -- measured cfg 2 / 4 / 5: 96 / 365 / 1199 us with one slice,
+    // 74 / 284 / 1105 at 8 blocks per CU, 74 / 245 / 857 at 64 (each function's 21 scalar tap loads sit in front of its
+    // FMAs; more resident wavefronts hide them.  Taps through the vector-memory path with a software prefetch: slower, 108 us)
+    const long bxy = (long)((L + 127) / 128) * Bt, want = 64L * srf_device_cus();
     int nz = bxy >= want ? 1 : (int)((want + bxy - 1) / bxy);
     nz = nz > N / 16 ? (N / 16 > 0 ? N / 16 : 1) : nz;       // at least 16 basis functions per block
     dim3 grid((L + 127) / 128, Bt, nz);
