@@ -379,13 +379,76 @@ __global__ __launch_bounds__(256) void srf_pairsum_kernel(const float* __restric
   out[i] = v.x + v.y;
 }
 
+// The whole chain in one pass (round 3): a thread owns 2^(D-1) consecutive samples of g_merged and writes its 2^(D-1-k) sums
+// of every level k -- the same additions in the same order as the chain of pair-sum launches (bitwise equal), but g_merged is
+// read once and no level is read back: 406 MB instead of 590 MB per cfg-2 block, one launch instead of four.
+struct MergeBwdArgs {
+  const float* g;
+  float* lv[SRF_MAX_DEPTH];
+  long chunks;    // rows * (L >> (D - 1))
+};
+template <int D>
+__global__ __launch_bounds__(256) void srf_merge_bwd_fused_kernel(MergeBwdArgs a) {
+  constexpr int N = 1 << (D - 1);
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.chunks) return;
+  float v[N];
+  if constexpr (N >= 4) {
+    const float4* src = reinterpret_cast<const float4*>(a.g) + i * (N / 4);
+#pragma unroll
+    for (int j = 0; j < N / 4; ++j) {
+      const float4 t = src[j];
+      v[4 * j] = t.x;
+      v[4 * j + 1] = t.y;
+      v[4 * j + 2] = t.z;
+      v[4 * j + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = a.g[i * N + j];
+  }
+#pragma unroll
+  for (int k = 1; k < D; ++k) {
+    const int n = N >> k;                 // this thread's outputs at level k
+#pragma unroll
+    for (int j = 0; j < n; ++j) v[j] = v[2 * j] + v[2 * j + 1];
+    float* dst = a.lv[k] + i * n;
+    if (n >= 4) {
+#pragma unroll
+      for (int j = 0; j < n / 4; ++j) reinterpret_cast<float4*>(dst)[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    } else if (n == 2) {
+      *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+    } else {
+      dst[0] = v[0];
+    }
+  }
+}
+
 // g_levels[0] is not written (it IS g_merged); g_levels[k] : [rows, L >> k] for k = 1..D-1
 extern "C" int srf_merge_bwd(const float* g_merged, float* const* g_levels, int D, long rows, int L, void* stream) {
   SRF_CHECK_ARG(g_merged && g_levels && D >= 1 && D <= SRF_MAX_DEPTH && rows > 0 && L > 0, "srf_merge_bwd: bad arguments");
   SRF_CHECK_ARG((L % (1 << (D - 1))) == 0, "srf_merge_bwd: L must be a multiple of 2^(D-1)");
+  for (int k = 1; k < D; ++k) SRF_CHECK_ARG(g_levels[k] != nullptr, "srf_merge_bwd: null level %d", k);
+  if (D == 1) return SRF_OK;
+  bool aligned = srf_aligned16(g_merged);
+  for (int k = 1; k < D; ++k) aligned = aligned && srf_aligned16(g_levels[k]);
+  if (aligned && D >= 3 && srf_kernel_mode() != 1) {
+    MergeBwdArgs a;
+    a.g = g_merged;
+    for (int k = 0; k < SRF_MAX_DEPTH; ++k) a.lv[k] = (k >= 1 && k < D) ? g_levels[k] : nullptr;
+    a.chunks = rows * (long)(L >> (D - 1));
+    const dim3 grid((unsigned)((a.chunks + 255) / 256)), block(256);
+    switch (D) {
+      case 3: hipLaunchKernelGGL(srf_merge_bwd_fused_kernel<3>, grid, block, 0, (hipStream_t)stream, a); break;
+      case 4: hipLaunchKernelGGL(srf_merge_bwd_fused_kernel<4>, grid, block, 0, (hipStream_t)stream, a); break;
+      case 5: hipLaunchKernelGGL(srf_merge_bwd_fused_kernel<5>, grid, block, 0, (hipStream_t)stream, a); break;
+      default: hipLaunchKernelGGL(srf_merge_bwd_fused_kernel<6>, grid, block, 0, (hipStream_t)stream, a); break;
+    }
+    SRF_CHECK_LAUNCH("merge_bwd", stream);
+    return SRF_OK;
+  }
   const float* src = g_merged;
   for (int k = 1; k < D; ++k) {
-    SRF_CHECK_ARG(g_levels[k] != nullptr, "srf_merge_bwd: null level %d", k);
     const long n_out = rows * (long)(L >> k);
     hipLaunchKernelGGL(srf_pairsum_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                        g_levels[k], n_out);

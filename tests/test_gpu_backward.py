@@ -90,8 +90,11 @@ def test_gln_bwd(Bt, C, L, act):
     assert rel_err(gx2, 2 * x.grad) <= 3e-5 and rel_err(dg2, 2 * gamma.grad) <= 3e-5 and rel_err(db2, 2 * beta.grad) <= 3e-5
 
 
-@pytest.mark.parametrize("Bt,C,L,D", [(2, 16, 3200, 5), (3, 5, 64, 3), (1, 7, 32, 6), (2, 4, 10, 1)])
+@pytest.mark.parametrize("Bt,C,L,D", [(2, 16, 3200, 5), (3, 5, 64, 3), (1, 7, 32, 6), (2, 4, 10, 1), (2, 8, 640, 6), (3, 4, 48, 4),
+                                      (1, 3, 12, 2)])
 def test_merge_bwd(Bt, C, L, D):
+    """The one-pass kernel (every level's pair sums from one read of g_merged) against torch autograd AND bitwise against the
+    chain of pair-sum launches (kernel mode 1): same additions, same order."""
     from sudo_rm_rf_amd import ops
     levels = [rnd(Bt, C, L >> k, seed=20 + k).requires_grad_(True) for k in range(D)]
     out = levels[-1]
@@ -102,6 +105,13 @@ def test_merge_bwd(Bt, C, L, D):
     got = ops.merge_bwd(dev32(gm), D)
     for k in range(D):
         assert rel_err(got[k], levels[k].grad) <= 1e-6
+    try:
+        ops.set_kernel_mode(1)
+        chain = ops.merge_bwd(dev32(gm), D)
+    finally:
+        ops.set_kernel_mode(0)
+    for k in range(D):
+        assert torch.equal(got[k], chain[k])
 
 
 @pytest.mark.parametrize("Bt,C,Lin,stride", [(2, 64, 3200, 1), (2, 64, 3200, 2), (3, 20, 200, 2), (1, 3, 7, 1),
