@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 11
+#define SRF_ABI_VERSION 12
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -187,6 +187,16 @@ int srf_pack_pw_weights(const float* const* w, void* const* packed, const int* C
 int srf_pw_conv_packed(const float* x, const float* w, const void* w_packed, const float* bias, float* y,
                        int Bt, int Cin, int Cout, int L, const srf_norm* in_norm, const float* residual,
                        double* out_sums, int epilogue_mask, const float* mul, int mul_channels, void* stream);
+
+/* The same GEMM with THREE bf16 parts per operand (h + m + l = 24 mantissa bits) and six MFMAs per product block: results in
+ * the exact-fp32 class (what srf_forward_train needs: the two-part kernel's 2^-17 representation error is amplified by the
+ * early layers' gradients) at ~1.6 x the two-part kernel's time.  Weights packed by srf_pack3_pw_weights (bytes:
+ * srf_packed3_pw_weight_bytes, 0 = shape not taken).  No mask epilogue; residual only together with a GlobLN + PReLU
+ * prologue (the res_conv form).  w_packed3 = NULL or a shape / launch size the kernel does not take: exactly srf_pw_conv. */
+size_t srf_packed3_pw_weight_bytes(int Cout, int Cin);
+int srf_pack3_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n, void* stream);
+int srf_pw_conv_packed3(const float* x, const float* w, const void* w_packed3, const float* bias, float* y, int Bt, int Cin,
+                        int Cout, int L, const srf_norm* in_norm, const float* residual, double* out_sums, void* stream);
 
 /* Depthwise k=5, padding 2: y[r,j] = bias[c] + sum_k w[c,k] * f(x[r, stride*j+k-2]), r=(b,c), zero
  * outside AFTER f (the reference pads the normalised tensor).  x: [Bt,C,Lin], y: [Bt,C,Lout],

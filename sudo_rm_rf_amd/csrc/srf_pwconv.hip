@@ -269,6 +269,59 @@ int srf_mask_decode(const float* x, const float* w, const void* w_packed, const 
                                       M, st);
 }
 
+// ---- three-part split GEMM (six bf16 MFMAs per product block: the exact-fp32 class at ~1.6 x the 3-MFMA kernel's time instead
+// of the exact-fp32 MFMA kernel's 2.5 x) -- the training forward's 1x1 convolutions (srf_forward_train) ----------------------
+int srf_pw_x3w3_launch(const PwArgs& a, const char* wpack3, int pro, hipStream_t st);
+size_t srf_x3w_packed3_bytes(int Cout, int Cin);
+int srf_x3w_pack3_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
+
+extern "C" size_t srf_packed3_pw_weight_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || !srf_x3v_supported(Cin, Cout, 4)) return 0;
+  return srf_x3w_packed3_bytes(Cout, Cin);
+}
+extern "C" int srf_pack3_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n,
+                                    void* stream) {
+  SRF_CHECK_ARG(w && packed && Cout && Cin && n > 0, "srf_pack3_pw_weights: bad arguments");
+  for (int i = 0; i < n; ++i)
+    SRF_CHECK_ARG(w[i] && packed[i] && srf_packed3_pw_weight_bytes(Cout[i], Cin[i]) > 0 && srf_aligned16(packed[i]),
+                  "srf_pack3_pw_weights: entry %d unsupported (Cout=%d Cin=%d)", i, Cout[i], Cin[i]);
+  return srf_x3w_pack3_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
+}
+// y = W f(x) + bias (+ residual), out_sums as in srf_pw_conv; w_packed3 from srf_pack3_pw_weights (NULL, a shape the
+// 256 x 128 kernel does not take, or a launch of fewer tiles than CUs: srf_pw_conv under the caller's kernel mode).
+extern "C" int srf_pw_conv_packed3(const float* x, const float* w, const void* w_packed3, const float* bias, float* y, int Bt,
+                                   int Cin, int Cout, int L, const srf_norm* in_norm, const float* residual, double* out_sums,
+                                   void* stream) {
+  SRF_CHECK_ARG(x && w && bias && y, "srf_pw_conv: null pointer");
+  SRF_CHECK_ARG(Bt > 0 && Cin > 0 && Cout > 0 && L > 0, "srf_pw_conv: bad sizes");
+  const SrfNormDev nd = srf_norm_dev(in_norm);
+  const int pro = nd.sums ? (nd.prelu ? 2 : 1) : (nd.prelu ? 3 : 0);
+  const bool form_ok = (pro == 2) == (residual != nullptr);      // the built forms: res_conv has the residual, the others none
+  const bool ok = w_packed3 && form_ok && srf_kernel_mode() != 1 && srf_x3v_supported(Cin, Cout, L) && srf_x3w_supported(Bt, pro) &&
+                  srf_aligned16(x) && srf_aligned16(w_packed3) && srf_aligned16(y) && (!residual || srf_aligned16(residual)) &&
+                  (long)Bt * Cin * L * 4 < (1L << 31) && !(srf_debug_flags() & 4) &&
+                  (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus();
+  if (!ok) return srf_pw_conv(x, w, bias, y, Bt, Cin, Cout, L, in_norm, residual, out_sums, 0, nullptr, 0, stream);
+  if (nd.sums) SRF_CHECK_ARG(nd.gamma && nd.beta, "srf_pw_conv: norm without gamma/beta");
+  PwArgs a;
+  a.x = x;
+  a.w = w;
+  a.bias = bias;
+  a.y = y;
+  a.residual = residual;
+  a.out_sums = out_sums;
+  a.mul = nullptr;
+  a.nrm = nd;
+  a.inv_count = 1.0 / ((double)Cin * (double)L);
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.L = L;
+  a.Bt = Bt;
+  a.mul_channels = 1;
+  a.epi_mask = 0;
+  return srf_pw_x3w3_launch(a, reinterpret_cast<const char*>(w_packed3), pro, (hipStream_t)stream);
+}
+
 // ---- GroupComm (library-internal; srf_forward): proj_1x1 with the TAC's "x + GlobLN(q)" folded into its operand load ----
 // y = W u + bias, u = x + GlobLN_qnorm(q) written to `u` as well (the block's residual); out_sums as in srf_pw_conv.
 // Only the register-resident thin-shape kernel (srf_pwconv_small.hip) has this prologue.

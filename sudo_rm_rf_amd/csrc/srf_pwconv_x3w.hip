@@ -66,7 +66,12 @@ __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8
 // gamma / beta come again as noalias kernel arguments so that they are fetched with scalar loads.
 // Work distribution, barrier protocol and LDS images: see srf_pwconv_x3v.hip (unchanged).
 // CP: cache policy of the streamed tensors (see the launch function).
-template <int PRO, int EPI, int ABL = 0, int CP = 0>
+// NP: 2 = two bf16 parts per operand (hi | lo, three MFMAs per product block: the inference GEMM); 3 = THREE parts (h | m | l =
+//     24 mantissa bits, the exact-fp32 class) and six MFMAs -- l*h, h*l, m*m, m*h, h*m, h*h -- for the training forward
+//     (VERDICT r2 next 4).  Same stages, DMA, swizzle and fragment reads: a k-tile then holds 16 k instead of 32 -- the "hi"
+//     image carries h (slots 0-15) and m (slots 16-31) of those 16 k, the "lo" image l (slots 0-15) -- so what was the second
+//     k-sub-step's fragment pair is the m part (srf_x3w_pack3_kernel writes the weights that way, lds_store the activations).
+template <int PRO, int EPI, int ABL = 0, int CP = 0, int NP = 2>
 __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt,
                                                             int total, int rounds, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ bias_r,
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;   // full tiles: 4 x 2 wavefronts, 64 x 64 each
   const int Cin = a.Cin, L = a.L;
-  const int nk = Cin / W_BK;                 // even, >= 4 (host checks)
+  constexpr int KT = NP == 3 ? 16 : W_BK;    // k per pipeline step
+  const int nk = Cin / KT;                   // even, >= 4 (host checks)
   const int nblk = gridDim.x;
   const int nquart = 4 * (total - rounds * nblk);                                   // quarter tiles of the leftover round
   const int nq_mine = ((int)blockIdx.x < nquart) ? (nquart - (int)blockIdx.x + nblk - 1) / nblk : 0;
@@ -176,8 +182,11 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     c.mt = c.grp * G + c.mi;
   };
   // ---- B staging geometry: thread -> time step n = tid & 127, k-group kg = tid >> 7 (wave-uniform), 8 k rows
-  const int b_n = tid & 127, b_c = wave >> 1, b_kg = b_c * 8;
-  const int b_lds = 2 * W_A_IMG + w_swz(b_n, b_c);
+  //      (NP 3: 4 k rows per thread; h -> chunk b_c >> 1 of the hi image, m -> chunk 2 + (b_c >> 1), l -> chunk b_c >> 1 of the lo
+  //      image, at byte (b_c & 1) * 8 of the 16-byte chunk)
+  const int b_n = tid & 127, b_c = wave >> 1, b_kg = NP == 3 ? b_c * 4 : b_c * 8;
+  const int b_lds = NP == 3 ? 2 * W_A_IMG + w_swz(b_n, b_c >> 1) + (b_c & 1) * 8 : 2 * W_A_IMG + w_swz(b_n, b_c);
+  const int b_lds_m = 2 * W_A_IMG + w_swz(b_n, 2 + (b_c >> 1)) + (b_c & 1) * 8;   // NP 3 only
   __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
 
   struct TileP {
@@ -227,8 +236,8 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       return;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * W_BK + j) * L * 4, (CP & 4) ? 2 : 0));
+    for (int j = 0; j < (NP == 3 ? 4 : 8); ++j)
+      r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * KT + j) * L * 4, (CP & 4) ? 2 : 0));
   };
   // GlobLN / PReLU / split of k-tile kt (tile t) -> B images of `stage`
   auto lds_store = [&](const Regs& r, const TileP& t, int kt, int stage) __attribute__((always_inline)) {
@@ -238,6 +247,34 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       return;
     }
     char* base = smem + stage * W_STAGE + b_lds;
+    if constexpr (NP == 3) {
+      float x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = r.b[j];
+      asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 ph, pm, pl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x0 = x[j];
+        if (PRO == 1 || PRO == 2) {
+          const int k = kt * KT + b_kg + j;
+          const float sc = gamma[k] * t.rstd;
+          x0 = fmaf(x0, sc, beta[k] - t.mean * sc);
+        }
+        if (PRO == 2 || PRO == 3) x0 = srf_prelu(x0, slope);
+        const __bf16 h = (__bf16)x0;
+        const float r1 = x0 - (float)h;
+        const __bf16 m = (__bf16)r1;
+        ph[j] = h;
+        pm[j] = m;
+        pl[j] = (__bf16)(r1 - (float)m);
+      }
+      *reinterpret_cast<bf16x4*>(base) = ph;
+      *reinterpret_cast<bf16x4*>(smem + stage * W_STAGE + b_lds_m) = pm;
+      *reinterpret_cast<bf16x4*>(base + W_B_IMG) = pl;
+      return;
+    }
     float vb[8];
     // Opaque at the point of use: volatile asm statements keep their order, so the conversion below -- and with it the
     // compiler's counted wait for this register set's loads -- cannot be hoisted above the previous step's barrier.  (One
@@ -296,8 +333,9 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f.ah[t] = *reinterpret_cast<const bf16x8*>(base + a_off[t][ks]);
-      f.al[t] = *reinterpret_cast<const bf16x8*>(base + W_A_IMG + a_off[t][ks]);
       f.bh[t] = *reinterpret_cast<const bf16x8*>(base + b_off[t][ks]);
+      if (NP == 3 && ks == 1) continue;     // (NP 3: "sub-step 1" = the m parts, which live in the hi images only)
+      f.al[t] = *reinterpret_cast<const bf16x8*>(base + W_A_IMG + a_off[t][ks]);
       f.bl[t] = *reinterpret_cast<const bf16x8*>(base + W_B_IMG + b_off[t][ks]);
     }
   };
@@ -318,6 +356,43 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
 #pragma unroll
       for (int mi = 0; mi < NT; ++mi)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+  };
+  // NP 3: f = {h, l} fragments (sub-step 0), g = {m} fragments (sub-step 1).  Smallest terms first: l*h, h*l | m*m, m*h, h*m, h*h
+  auto mma3_a = [&](const Frags& f, auto full_tag) __attribute__((always_inline)) {
+    constexpr int NT = decltype(full_tag)::value ? 2 : 1;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);
+  };
+  auto mma3_b = [&](const Frags& f, const Frags& g, auto full_tag) __attribute__((always_inline)) {
+    constexpr int NT = decltype(full_tag)::value ? 2 : 1;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.ah[mi], g.bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.ah[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], g.bh[ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
@@ -356,7 +431,8 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     arr = (lane == idx) ? (add ? arr + val : val) : arr;
   };
   auto step = [&](Regs& nx, int kt, auto full_tag, auto have0_tag, auto pref_tag) __attribute__((always_inline)) {
-    constexpr bool HAVE0 = decltype(have0_tag)::value, PREF = decltype(pref_tag)::value;
+    // (NP 3: always the just-in-time flavour -- the h fragments of sub-step 0 are needed again with the m fragments)
+    constexpr bool HAVE0 = NP == 3 ? false : decltype(have0_tag)::value, PREF = NP == 3 ? false : decltype(pref_tag)::value;
     const int s1 = s0 == W_NSTAGE - 1 ? 0 : s0 + 1, s2 = s1 == W_NSTAGE - 1 ? 0 : s1 + 1;
     int k1, k2, k3;
     const TileP t1 = pick(kt + 1, k1), t2 = pick(kt + 2, k2), t3 = pick(kt + 3, k3);
@@ -373,10 +449,16 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     }
     gload_a(t2, k2, s2);
     gload_b(nx, t3, k3);
-    mma(f0, full_tag);
-    if constexpr (!HAVE0) {
+    if constexpr (NP == 3) {
+      mma3_a(f0, full_tag);
       read_frags(f1, s0, 1, full_tag);
-      mma(f1, full_tag);
+      mma3_b(f0, f1, full_tag);
+    } else {
+      mma(f0, full_tag);
+      if constexpr (!HAVE0) {
+        read_frags(f1, s0, 1, full_tag);
+        mma(f1, full_tag);
+      }
     }
     if constexpr (ABL & 64) {
       const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
@@ -388,7 +470,9 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       tl_put(tl_wait, kt & 31, t1 - t0, true);
       tl_put(tl_bar, kt & 31, t2 - t1, true);
     } else {
-      asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+      // (in flight behind the DMA of k-tile kt + 1: last step's activation loads, this step's DMA and activation loads)
+      if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     if constexpr (PREF) read_frags(f0, s1, 0, full_tag);     // next k-tile's first half, under this one's second
@@ -805,9 +889,13 @@ bool srf_x3w_supported(int Bt, int pro) { return !(pro == 1 || pro == 2) || Bt <
 
 // fuse_wd != null: the mask epilogue fused with the decoder's contraction (EPI 4; pro 3, mask epilogue, fuse_M <= 64)
 static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, const char* fuse_wd, float* fuse_z, int fuse_M,
-                                 hipStream_t st);
+                                 hipStream_t st, int np = 2);
 int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
   return srf_pw_x3w_launch_any(a, wpack, pro, nullptr, nullptr, 0, st);
+}
+// three-part operands, six MFMAs per product block (the training forward); wpack3: srf_x3w_pack3_launch's image
+int srf_pw_x3w3_launch(const PwArgs& a, const char* wpack3, int pro, hipStream_t st) {
+  return srf_pw_x3w_launch_any(a, wpack3, pro, nullptr, nullptr, 0, st, 3);
 }
 
 // ---- K5: decoder weights as MFMA A fragments.  w: the ConvTranspose1d weight [Ci][M] (M = sources x taps <= 64), split into
@@ -844,6 +932,65 @@ int srf_x3w_pack_dec_launch(const float* w, void* dst, int Ci, int M, hipStream_
   return SRF_OK;
 }
 
+// ---- three-part weights (NP 3): per (m-tile, 16-k tile) the stage image of srf_x3v_pack_kernel -- [256 rows][32 slots] bf16,
+// XOR-swizzled 16-byte chunks, "hi" image then "lo" image -- with h | m of the tile's 16 k in the hi image (chunks 0-1 | 2-3)
+// and l in chunks 0-1 of the lo image (chunks 2-3: zero, never read).  w = h + m + l to 24 bits.
+struct W3PackEntry {
+  const float* w;
+  char* dst;
+  int Cout, Cin;
+};
+constexpr int SRF_W3_MAX_PACK = 48;
+struct W3PackTable {
+  W3PackEntry e[SRF_W3_MAX_PACK];
+};
+__global__ __launch_bounds__(256) void srf_x3w_pack3_kernel(W3PackTable t) {
+  const W3PackEntry e = t.e[blockIdx.y];
+  const int nKt = e.Cin / 16;
+  const int nMt = (e.Cout + W_BM - 1) / W_BM;
+  const long total = (long)nMt * nKt * W_BM * 2;   // one thread per (row, 8-k packet)
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int c = (int)(id & 1);
+    const int row = (int)((id >> 1) % W_BM);
+    const long tile = (id >> 1) / W_BM;
+    const int kt = (int)(tile % nKt), mt = (int)(tile / nKt);
+    const int m = mt * W_BM + row;
+    bf16x8 ph, pm, pl, zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (m < e.Cout) ? e.w[(size_t)m * e.Cin + kt * 16 + c * 8 + j] : 0.f;
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 mm = (__bf16)r1;
+      ph[j] = h;
+      pm[j] = mm;
+      pl[j] = (__bf16)(r1 - (float)mm);
+      zero[j] = (__bf16)0.f;
+    }
+    char* base = e.dst + (size_t)tile * W_WTILE_BYTES;
+    *reinterpret_cast<bf16x8*>(base + w_swz(row, c)) = ph;
+    *reinterpret_cast<bf16x8*>(base + w_swz(row, 2 + c)) = pm;
+    *reinterpret_cast<bf16x8*>(base + W_A_IMG + w_swz(row, c)) = pl;
+    *reinterpret_cast<bf16x8*>(base + W_A_IMG + w_swz(row, 2 + c)) = zero;
+  }
+}
+size_t srf_x3w_packed3_bytes(int Cout, int Cin) {
+  return (size_t)((Cout + W_BM - 1) / W_BM) * (size_t)(Cin / 16) * (size_t)W_WTILE_BYTES;
+}
+int srf_x3w_pack3_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {
+  for (int base = 0; base < n; base += SRF_W3_MAX_PACK) {
+    W3PackTable t;
+    const int cnt = (n - base) < SRF_W3_MAX_PACK ? (n - base) : SRF_W3_MAX_PACK;
+    for (int i = 0; i < SRF_W3_MAX_PACK; ++i) {
+      const int j = base + (i < cnt ? i : 0);
+      t.e[i] = W3PackEntry{w[j], dst[j], Cout[j], Cin[j]};
+    }
+    hipLaunchKernelGGL(srf_x3w_pack3_kernel, dim3(64, cnt), dim3(256), 0, st, t);
+    SRF_CHECK_LAUNCH("pack_pw_weights3", st);
+  }
+  return SRF_OK;
+}
+
 // The model's tail in one GEMM launch: partial decoder frames zpart[Bt][ceil(Cout / 256)][M][L] instead of the masked tensor
 int srf_pw_x3w_fused_tail_launch(const PwArgs& a, const char* wpack, const char* wdpack, float* zpart, int M, hipStream_t st) {
   SRF_CHECK_ARG(wdpack && zpart && M > 0 && M <= 64, "srf_mask_decode: bad arguments");
@@ -853,7 +1000,7 @@ int srf_pw_x3w_fused_tail_launch(const PwArgs& a, const char* wpack, const char*
 }
 
 static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, const char* fuse_wd, float* fuse_z, int fuse_M,
-                                 hipStream_t st) {
+                                 hipStream_t st, int np) {
   const int nMt = (a.Cout + W_BM - 1) / W_BM, nLt = (a.L + W_BN - 1) / W_BN;
   const long total = (long)a.Bt * nMt * nLt;
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
@@ -877,6 +1024,9 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
         (const void*)&srf_pw_x3w_kernel<3, 2, 0, 4>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, 5>,
         (const void*)&srf_pw_x3w_kernel<3, 2, 0, 13>,
         (const void*)&srf_pw_x3w_kernel<3, 4, 0, 0>, (const void*)&srf_pw_x3w_kernel<3, 4, 0, 4>,
+        // three-part operands (training forward)
+        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 0, 3>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 5, 3>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 5, 3>, (const void*)&srf_pw_x3w_kernel<3, 0, 0, 5, 3>,
         // any other prologue / epilogue combination (unit tests, stand-alone srf_pw_conv callers)
         (const void*)&srf_pw_x3w_kernel<0, 3>, (const void*)&srf_pw_x3w_kernel<1, 3>,
         (const void*)&srf_pw_x3w_kernel<2, 3>, (const void*)&srf_pw_x3w_kernel<3, 3>,
@@ -907,7 +1057,7 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
   // unused by this kernel) = one group = the round-2 tile order, for A/B.
   int mgrp = nMt;
   {
-    const long slab = (long)W_BM * a.Cin * 4, image = slab * nMt;
+    const long slab = (long)W_BM * a.Cin * 4 * (np == 3 ? 2 : 1), image = slab * nMt;
     if (image > (3L << 20) && !(srf_debug_flags() & 2)) {
       int g = (int)((2L << 20) / slab);
       while (g > 1 && nMt % g) --g;
@@ -967,6 +1117,18 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
   const int cp_flag = (srf_debug_flags() >> 26) & 15;
   static const int kDefaultCp[4] = {0, 5, 5, 5};
   const int cp = cp_flag ? cp_flag - 1 : kDefaultCp[pro < 0 || pro > 3 ? 0 : pro];
+  if (np == 3) {
+#define W_GO3(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, C, 3>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
+    SRF_CHECK_ARG(!mask && !fuse_wd && (pro == 2) == res && !(pro != 2 && res), "srf_pw_conv (three-part): form not built");
+    if (pro == 0) W_GO3(0, 0, 0);
+    else if (pro == 1) W_GO3(1, 0, 5);
+    else if (pro == 2) W_GO3(2, 1, 5);
+    else W_GO3(3, 0, 5);
+#undef W_GO3
+    static const char* const kLabel3[4] = {"pw_conv_x3w3<0>", "pw_conv_x3w3<1>", "pw_conv_x3w3<2>", "pw_conv_x3w3<3>"};
+    SRF_CHECK_LAUNCH(kLabel3[pro < 0 || pro > 3 ? 3 : pro], st);
+    return SRF_OK;
+  }
   if (fuse_wd) {
     if (cp & 4) W_GO(3, 4, 0, 4);
     else W_GO(3, 4, 0, 0);

@@ -23,6 +23,11 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
                      int mode, void* stream);
 bool srf_dwconv5_bwd_rowwise_ok(int Lin, int stride, const void* const* ptrs, int nptrs);
 bool srf_pyramid_reg_supported(int L, int D);
+extern "C" size_t srf_packed3_pw_weight_bytes(int Cout, int Cin);
+extern "C" int srf_pack3_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n, void* stream);
+extern "C" int srf_pw_conv_packed3(const float* x, const float* w, const void* w_packed3, const float* bias, float* y, int Bt,
+                                   int Cin, int Cout, int L, const srf_norm* in_norm, const float* residual, double* out_sums,
+                                   void* stream);
 bool srf_pw_conv_preadd_supported(int Cin, int Cout, int L, const void* const* ptrs, int nptrs);
 int srf_pw_conv_preadd(const float* x, const float* q, const srf_norm* qnorm, float* u, const float* w, const float* bias,
                        float* y, int Bt, int Cin, int Cout, int L, double* out_sums, hipStream_t st);
@@ -79,7 +84,7 @@ static TrainLayout train_layout(const srf_plan* p) {
 
 struct ScratchLayout {
   size_t dec, gv, genc, gxa, gxb, gf, go, gd, gn[SRF_MAX_DEPTH], gu[SRF_MAX_DEPTH], frames, wt, zeros, wdpad, wg,
-      gln, gln2, dw, gq, gxm, tac, total;
+      gln, gln2, dw, gq, gxm, tac, pk3, total;
   int dec_rows;
 };
 
@@ -138,6 +143,12 @@ static ScratchLayout scratch_layout(const srf_plan* p) {
   s.gq = gc ? take(F * Bt * B * L) : 0;
   s.gxm = gc ? take(F * Bt * B * L) : 0;
   s.tac = gc ? take(srf_tac_bwd_scratch_bytes(p->Bt, c.group_size, p->nB, p->L)) : 0;
+  // three-part weight images of the forward's 1x1 convolutions (packed once per step by srf_forward_train)
+  {
+    size_t pk = al256(srf_packed3_pw_weight_bytes(B, N)) + al256(srf_packed3_pw_weight_bytes(SAN, B));
+    pk += (size_t)c.num_blocks * (al256(srf_packed3_pw_weight_bytes(p->nC, p->nB)) + al256(srf_packed3_pw_weight_bytes(p->nB, p->nC)));
+    s.pk3 = take(pk);
+  }
   s.total = off;
   return s;
 }
@@ -203,16 +214,49 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
   auto xbuf = [&](int i) { return (float*)(sv + t.x0 + t.x_stride * i); };
   SRF_CHECK_HIP(hipMemsetAsync(stats, 0, p->stats_bytes, st));
 
+  const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;
+  const int G = gc ? c.group_size : 1, Bg = p->Bg, nB = p->nB, nC = p->nC;
+  // The 1x1 convolutions of the exact forward (kernel mode 2) run on the THREE-part split GEMM (six bf16 MFMAs per product
+  // block, 24-bit operands: srf_pwconv_x3w.hip NP 3) where the 256 x 128 kernel takes the launch; their weights are split and
+  // laid out once per step, here.  Debug flag 1 << 31: the exact-fp32 MFMA kernel instead (A/B).
+  const bool three = srf_kernel_mode() == 2 && !((unsigned)srf_debug_flags() & 0x80000000u);
+  std::vector<const float*> pk_w;
+  std::vector<void*> pk_d;
+  std::vector<int> pk_co, pk_ci;
+  size_t pk_off = s.pk3;
+  auto pack3 = [&](const float* w, int cout, int cin) -> const void* {
+    const size_t bytes = srf_packed3_pw_weight_bytes(cout, cin);
+    if (!three || !bytes) return nullptr;
+    void* d = sc + pk_off;
+    pk_off += al256(bytes);
+    pk_w.push_back(w);
+    pk_d.push_back(d);
+    pk_co.push_back(cout);
+    pk_ci.push_back(cin);
+    return d;
+  };
+  const float* const* Ptail = P + p->p_tail;
+  const void* pk_bottleneck = pack3(P[3], B, N);
+  std::vector<const void*> pk_proj(U, nullptr), pk_res(U, nullptr);
+  for (int i = 0; i < U; ++i) {
+    const float* const* Pu_ = P + p->p_block0 + (size_t)i * p->p_block_stride + p->p_ublock_off;
+    pk_proj[i] = pack3(Pu_[0], nC, nB);
+    pk_res[i] = pack3((Pu_ + 5 + 4 * D)[3], nB, nC);
+  }
+  const void* pk_mask = pack3(Ptail[1], p->SA * N, B);
+  if (!pk_w.empty()) {
+    rc = srf_pack3_pw_weights(pk_w.data(), pk_d.data(), pk_co.data(), pk_ci.data(), (int)pk_w.size(), stream);
+    if (rc) return rc;
+  }
+
   float* enc = (float*)(sv + t.enc);
   rc = srf_encoder(wav, P[0], enc, slot(0), Bt, p->A, p->T, N, K, L, stream);
   if (rc) return rc;
   {
     srf_norm ln{slot(0), P[1], P[2], nullptr};
-    rc = srf_pw_conv(enc, P[3], P[4], xbuf(0), Bt, N, B, L, &ln, nullptr, nullptr, 0, nullptr, 0, stream);
+    rc = srf_pw_conv_packed3(enc, P[3], pk_bottleneck, P[4], xbuf(0), Bt, N, B, L, &ln, nullptr, nullptr, stream);
     if (rc) return rc;
   }
-  const bool gc = c.variant == SRF_VARIANT_GROUPCOMM;
-  const int G = gc ? c.group_size : 1, Bg = p->Bg, nB = p->nB, nC = p->nC;
   // fused pyramid with level outputs (register-resident kernels only); its scratch lives in the backward's gradient
   // buffers gf | go | gd, idle during the forward.  Debug flag 16 (as in srf_forward) selects the per-level kernels.
   const size_t F_ = sizeof(float);
@@ -248,7 +292,7 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
       s0 += 1;
     }
     if (!tac_norm_fused) {
-      rc = srf_pw_conv(xin, Pu[0], Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0), 0, nullptr, 0, stream);
+      rc = srf_pw_conv_packed3(xin, Pu[0], pk_proj[i], Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0), stream);
       if (rc) return rc;
     }
     // The pyramid: the two fused passes of the inference path with the per-level conv outputs d_k and their
@@ -305,7 +349,7 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
     }
     const float* const* Pf = Pu + 5 + 4 * D;
     srf_norm fn{slot(s0 + 1 + D), Pf[0], Pf[1], Pf[2]};
-    rc = srf_pw_conv(merged, Pf[3], Pf[4], xbuf(i + 1), Bg, nC, nB, L, &fn, xin, nullptr, 0, nullptr, 0, stream);
+    rc = srf_pw_conv_packed3(merged, Pf[3], pk_res[i], Pf[4], xbuf(i + 1), Bg, nC, nB, L, &fn, xin, nullptr, stream);
     if (rc) return rc;
   }
   const float* const* Pt = P + p->p_tail;
@@ -313,7 +357,7 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
   float* v = (float*)(sv + t.v);
   {
     srf_norm pre{nullptr, nullptr, nullptr, Pt[0]};
-    rc = srf_pw_conv(xbuf(U), Pt[1], Pt[2], m, Bt, B, p->SA * N, L, &pre, nullptr, nullptr, 0, nullptr, 0, stream);
+    rc = srf_pw_conv_packed3(xbuf(U), Pt[1], pk_mask, Pt[2], m, Bt, B, p->SA * N, L, &pre, nullptr, nullptr, stream);
     if (rc) return rc;
   }
   rc = srf_mask_apply(m, enc, v, Bt, p->SA, N, L, stream);

@@ -96,6 +96,35 @@ def pack_pw_weight(weight):
     return packed
 
 
+def pack3_pw_weight(weight):
+    """Three-part (h | m | l) bf16 image of a 1x1 weight for the six-MFMA GEMM (None if the shape does not qualify)."""
+    dev = _chk(weight)
+    Cout = weight.shape[0]
+    Cin = weight.numel() // Cout
+    lib = _lib.load()
+    nbytes = lib.srf_packed3_pw_weight_bytes(Cout, Cin)
+    if not nbytes:
+        return None
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.srf_pack3_pw_weights((C.c_void_p * 1)(weight.data_ptr()), (C.c_void_p * 1)(packed.data_ptr()),
+                                        (C.c_int * 1)(Cout), (C.c_int * 1)(Cin), 1, _lib.current_stream(dev)),
+               "srf_pack3_pw_weights")
+    return packed
+
+
+def pw_conv3(x, weight, bias, packed3, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None, residual=None, out_sums=None):
+    """1x1 conv on the three-part split GEMM (srf_pw_conv_packed3): the training forward's GEMM."""
+    dev = _chk(x, weight, bias, in_sums, in_gamma, in_beta, in_prelu, residual, out_sums)
+    Bt, Cin, L = x.shape
+    Cout = weight.shape[0]
+    y = torch.empty((Bt, Cout, L), dtype=torch.float32, device=dev)
+    rc = _lib.load().srf_pw_conv_packed3(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(packed3), _lib.ptr(bias), _lib.ptr(y), Bt, Cin,
+                                         Cout, L, _norm(in_sums, in_gamma, in_beta, in_prelu), _lib.ptr(residual),
+                                         _lib.ptr(out_sums), _lib.current_stream(dev))
+    _lib.check(rc, "srf_pw_conv_packed3")
+    return y
+
+
 def pw_conv(x, weight, bias, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None, residual=None,
             out_sums=None, mask_mul=None, packed=None):
     """1x1 conv with fused prologue / epilogue.  x [Bt,Cin,L], weight [Cout,Cin(,1)] -> [Bt,Cout,L]."""
