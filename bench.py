@@ -411,7 +411,8 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
             "value": world * batch * (T / fs) * args.steps / r["seconds"], "unit": "trained-seconds/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (forward GEMMs exact fp32 MFMA; backward GEMMs split-bf16 x3, fp32 accumulate)",
+            "dtype": "f32 (forward GEMMs: three-part split-bf16, 6 MFMAs per product block, 24-bit operands = exact-fp32 class; "
+                     "backward GEMMs: two-part split-bf16, 3 MFMAs; fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%s training step, batch %d per GPU, T=%d" % (args.workload, batch, T),
                        "global_batch": batch * world, "parallelism": "data-parallel x%d, one gradient all-reduce" % world},
