@@ -6,6 +6,8 @@
 //   mask ReLU * encoder output      improved_sudormrf.py:296-298
 //   conv_transpose1d / conv1d frame gathers for the decoder / encoder weight gradients  :247-251,272-279
 #include "srf_common.h"
+#include <algorithm>
+#include <vector>
 
 // =============================================================================================
 // GlobLN (+PReLU) backward.   z = gamma_c * xh + beta_c, xh = (x - mean_b) * rstd_b, out = PReLU_a(z)
@@ -86,8 +88,39 @@ __global__ __launch_bounds__(256) void srf_gln_bwd_reduce_kernel(GlnBwdArgs a) {
 // (GroupComm folds 512 groups onto 16 channels: one thread per channel walking all groups took 130 us); results are
 // atomically added to the parameter gradients.
 // GlobLN: rowpart[.][0] -> dbeta, [1] -> dgamma, [2] -> slope (all channels into one scalar)
-__global__ __launch_bounds__(256) void srf_gln_bwd_params_kernel(const float* __restrict__ rowpart, int groups, int C,
-                                                                 float* dgamma, float* dbeta, float* dslope) {
+// ---- deferred parameter-gradient reductions (round 3) --------------------------------------------------------------------
+// Every GlobLN / depthwise-conv backward ends with a tiny kernel that folds its per-row partials into the parameter gradients:
+// ~190 launches of ~5 us per cfg-2 training step, each in the dependent chain of the stream.  When the caller gives every call
+// its OWN scratch slice (srf_backward does, for the blocks' norms and convs: SrfDeferScope), the partials stay valid, the call
+// only records a descriptor, and srf_defer_flush() folds them all in a handful of batched launches at the end of the backward.
+struct GlnParamsDesc {
+  const float* rowpart;
+  float *dgamma, *dbeta, *dslope;
+  int groups, C;
+};
+struct DwParamsDesc {
+  const float* rowpart;
+  float *dw, *dbias;
+  int groups, C;
+};
+constexpr int SRF_PB_MAX = 40;
+struct GlnParamsTable {
+  GlnParamsDesc d[SRF_PB_MAX];
+};
+struct DwParamsTable {
+  DwParamsDesc d[SRF_PB_MAX];
+};
+struct SrfDeferCtx {
+  bool on = false;
+  std::vector<GlnParamsDesc> gln;
+  std::vector<DwParamsDesc> dw;
+};
+static thread_local SrfDeferCtx g_defer;
+void srf_defer_set(bool on) { g_defer.on = on; }
+bool srf_defer_on() { return g_defer.on; }
+
+__device__ __forceinline__ void srf_gln_bwd_params_body(const float* __restrict__ rowpart, int groups, int C, float* dgamma,
+                                                        float* dbeta, float* dslope) {
   __shared__ float red[8][32][3];
   const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -125,6 +158,16 @@ __global__ __launch_bounds__(256) void srf_gln_bwd_params_kernel(const float* __
       if (cl == 0 && t2 != 0.f) atomicAdd(dslope, t2);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void srf_gln_bwd_params_kernel(const float* __restrict__ rowpart, int groups, int C,
+                                                                 float* dgamma, float* dbeta, float* dslope) {
+  srf_gln_bwd_params_body(rowpart, groups, C, dgamma, dbeta, dslope);
+}
+__global__ __launch_bounds__(256) void srf_gln_bwd_params_batch_kernel(GlnParamsTable t) {
+  const GlnParamsDesc d = t.d[blockIdx.z];
+  if ((int)blockIdx.x * 32 >= d.C || (int)blockIdx.y * 64 >= d.groups) return;   // (block-uniform)
+  srf_gln_bwd_params_body(d.rowpart, d.groups, d.C, d.dgamma, d.dbeta, d.dslope);
 }
 
 __global__ __launch_bounds__(256) void srf_gln_bwd_apply_kernel(GlnBwdArgs a, int chunks) {
@@ -337,7 +380,8 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
   a.C = C;
   a.L = L;
   a.accumulate = accumulate_gx;
-  if (!pre_reduced) SRF_CHECK_HIP(hipMemsetAsync(a.bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
+  // (deferred mode: the caller's scratch slices are zeroed once per backward)
+  if (!pre_reduced && !g_defer.on) SRF_CHECK_HIP(hipMemsetAsync(a.bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
   const bool v4 = (L % 4) == 0 && srf_aligned16(gout) && srf_aligned16(x) && (!gx || srf_aligned16(gx)) &&
                   (!gout2 || srf_aligned16(gout2)) && srf_kernel_mode() != 1 && !(srf_debug_flags() & (1 << 30));
   const dim3 grid4((unsigned)((rows + 3) / 4));
@@ -349,9 +393,13 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
     SRF_CHECK_LAUNCH("gln_bwd_reduce", st);
   }
   if (dgamma || dbeta || (dslope && norm->prelu)) {
-    hipLaunchKernelGGL(srf_gln_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
-                       dim3(256), 0, st, a.rowpart, groups, C, dgamma, dbeta, norm->prelu ? dslope : nullptr);
-    SRF_CHECK_LAUNCH("gln_bwd_params", st);
+    if (g_defer.on) {
+      g_defer.gln.push_back(GlnParamsDesc{a.rowpart, dgamma, dbeta, norm->prelu ? dslope : nullptr, groups, C});
+    } else {
+      hipLaunchKernelGGL(srf_gln_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
+                         dim3(256), 0, st, a.rowpart, groups, C, dgamma, dbeta, norm->prelu ? dslope : nullptr);
+      SRF_CHECK_LAUNCH("gln_bwd_params", st);
+    }
   }
   if (no_apply) return SRF_OK;
   if (v4)
@@ -952,8 +1000,8 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, l
 }
 
 // dw[c][t] += sum_g rowpart[g][c][t] (t < 5), dbias[c] += sum_g rowpart[g][c][5]; same blocking as above
-__global__ __launch_bounds__(256) void srf_dwconv5_bwd_params_kernel(const float* __restrict__ rowpart, int groups, int C,
-                                                                     float* dw, float* dbias) {
+__device__ __forceinline__ void srf_dwconv5_bwd_params_body(const float* __restrict__ rowpart, int groups, int C, float* dw,
+                                                            float* dbias) {
   __shared__ float red[8][32][6];
   const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -982,6 +1030,53 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_params_kernel(const float
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void srf_dwconv5_bwd_params_kernel(const float* __restrict__ rowpart, int groups, int C,
+                                                                     float* dw, float* dbias) {
+  srf_dwconv5_bwd_params_body(rowpart, groups, C, dw, dbias);
+}
+__global__ __launch_bounds__(256) void srf_dwconv5_bwd_params_batch_kernel(DwParamsTable t) {
+  const DwParamsDesc d = t.d[blockIdx.z];
+  if ((int)blockIdx.x * 32 >= d.C || (int)blockIdx.y * 64 >= d.groups) return;   // (block-uniform)
+  srf_dwconv5_bwd_params_body(d.rowpart, d.groups, d.C, d.dw, d.dbias);
+}
+
+// Fold every recorded partial into its parameter gradients (batched launches of up to SRF_PB_MAX reductions) and clear the list.
+int srf_defer_flush(hipStream_t st) {
+  for (size_t base = 0; base < g_defer.gln.size(); base += SRF_PB_MAX) {
+    GlnParamsTable t;
+    const int cnt = (int)std::min<size_t>(SRF_PB_MAX, g_defer.gln.size() - base);
+    int maxC = 0, maxG = 0;
+    for (int i = 0; i < SRF_PB_MAX; ++i) {
+      t.d[i] = g_defer.gln[base + (i < cnt ? i : 0)];
+      if (i < cnt) {
+        maxC = std::max(maxC, t.d[i].C);
+        maxG = std::max(maxG, t.d[i].groups);
+      }
+    }
+    hipLaunchKernelGGL(srf_gln_bwd_params_batch_kernel, dim3((unsigned)((maxC + 31) / 32), (unsigned)((maxG + 63) / 64), (unsigned)cnt),
+                       dim3(256), 0, st, t);
+    SRF_CHECK_LAUNCH("gln_bwd_params", st);
+  }
+  g_defer.gln.clear();
+  for (size_t base = 0; base < g_defer.dw.size(); base += SRF_PB_MAX) {
+    DwParamsTable t;
+    const int cnt = (int)std::min<size_t>(SRF_PB_MAX, g_defer.dw.size() - base);
+    int maxC = 0, maxG = 0;
+    for (int i = 0; i < SRF_PB_MAX; ++i) {
+      t.d[i] = g_defer.dw[base + (i < cnt ? i : 0)];
+      if (i < cnt) {
+        maxC = std::max(maxC, t.d[i].C);
+        maxG = std::max(maxG, t.d[i].groups);
+      }
+    }
+    hipLaunchKernelGGL(srf_dwconv5_bwd_params_batch_kernel, dim3((unsigned)((maxC + 31) / 32), (unsigned)((maxG + 63) / 64), (unsigned)cnt),
+                       dim3(256), 0, st, t);
+    SRF_CHECK_LAUNCH("dwconv5_bwd_params", st);
+  }
+  g_defer.dw.clear();
+  return SRF_OK;
 }
 
 extern "C" size_t srf_dwconv5_bwd_scratch_bytes(int groups, int C) {
@@ -1052,7 +1147,7 @@ int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_n
       a.gadd = gadd;
       a.nrm_bsums = reinterpret_cast<double*>(gln_scratch);
       a.nrm_rowpart = reinterpret_cast<float*>(a.nrm_bsums + (size_t)groups * SRF_STAT_BUCKETS * 2);
-      SRF_CHECK_HIP(hipMemsetAsync(a.nrm_bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
+      if (!g_defer.on) SRF_CHECK_HIP(hipMemsetAsync(a.nrm_bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
       if (ax) {
         a.ax = ax;
         a.anrm = srf_norm_dev(anorm);
@@ -1089,9 +1184,13 @@ int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_n
   SRF_CHECK_LAUNCH("dwconv5_bwd", st);
   }
   if (dw || dbias) {
-    hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
-                       dim3(256), 0, st, a.rowpart, groups, C, dw, dbias);
-    SRF_CHECK_LAUNCH("dwconv5_bwd_params", st);
+    if (g_defer.on) {
+      g_defer.dw.push_back(DwParamsDesc{a.rowpart, dw, dbias, groups, C});
+    } else {
+      hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
+                         dim3(256), 0, st, a.rowpart, groups, C, dw, dbias);
+      SRF_CHECK_LAUNCH("dwconv5_bwd_params", st);
+    }
   }
   return SRF_OK;
 }

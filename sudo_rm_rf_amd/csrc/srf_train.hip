@@ -23,6 +23,8 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
                      int mode, void* stream);
 bool srf_dwconv5_bwd_rowwise_ok(int Lin, int stride, const void* const* ptrs, int nptrs);
 bool srf_pyramid_reg_supported(int L, int D);
+void srf_defer_set(bool on);          // srf_backward.hip: deferred parameter-gradient reductions
+int srf_defer_flush(hipStream_t st);
 extern "C" size_t srf_packed3_pw_weight_bytes(int Cout, int Cin);
 extern "C" int srf_pack3_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n, void* stream);
 extern "C" int srf_pw_conv_packed3(const float* x, const float* w, const void* w_packed3, const float* bias, float* y, int Bt,
@@ -84,7 +86,7 @@ static TrainLayout train_layout(const srf_plan* p) {
 
 struct ScratchLayout {
   size_t dec, gv, genc, gxa, gxb, gf, go, gd, gn[SRF_MAX_DEPTH], gu[SRF_MAX_DEPTH], frames, wt, zeros, wdpad, wg,
-      gln, gln2, dw, gq, gxm, tac, pk3, total;
+      gln, gln2, dw, gq, gxm, tac, pk3, arena, arena_bytes, gln_slice, dw_slice, total;
   int dec_rows;
 };
 
@@ -143,6 +145,12 @@ static ScratchLayout scratch_layout(const srf_plan* p) {
   s.gq = gc ? take(F * Bt * B * L) : 0;
   s.gxm = gc ? take(F * Bt * B * L) : 0;
   s.tac = gc ? take(srf_tac_bwd_scratch_bytes(p->Bt, c.group_size, p->nB, p->L)) : 0;
+  // per-call scratch slices of the blocks' norm / depthwise-conv backwards (zeroed once per backward; their parameter-gradient
+  // reductions are deferred to one batched flush: srf_backward.hip, SrfDeferCtx): per block D + 2 norm slices and D conv slices
+  s.gln_slice = al256(srf_gln_bwd_scratch_bytes(p->Bg, p->nC));
+  s.dw_slice = al256(srf_dwconv5_bwd_scratch_bytes(p->Bg, p->nC));
+  s.arena_bytes = (size_t)c.num_blocks * ((size_t)(D + 2) * s.gln_slice + (size_t)D * s.dw_slice);
+  s.arena = take(s.arena_bytes);
   // three-part weight images of the forward's 1x1 convolutions (packed once per step by srf_forward_train)
   {
     size_t pk = al256(srf_packed3_pw_weight_bytes(B, N)) + al256(srf_packed3_pw_weight_bytes(SAN, B));
@@ -394,6 +402,13 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
   void* wg = sc + s.wg;
   const size_t zmax = max3(C, SAN, N);
   SRF_CHECK_HIP(hipMemsetAsync(zeros, 0, sizeof(float) * zmax, st));
+  // the blocks' norm / conv backwards get one scratch slice per call (statistic buckets zeroed here, once) and leave their
+  // parameter-gradient reductions to one batched flush after the block loop
+  SRF_CHECK_HIP(hipMemsetAsync(sc + s.arena, 0, s.arena_bytes, st));
+  srf_defer_set(false);
+  struct DeferOff {
+    ~DeferOff() { srf_defer_set(false); }
+  } defer_off_on_exit;
 
   const int pt = p->p_tail;
   // ---- decoder: out = overlap_add(W_d^T v)                       improved_sudormrf.py:272-279,300
@@ -452,7 +467,10 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     if (rc) return rc;
     rc = srf_pw_conv(gx, wt, zeros, gf, Bg, nB, nC, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
     if (rc) return rc;
-    rc = srf_gln_bwd(gf, nullptr, merged, &fn, Bg, nC, L, gf, 0, Gu[pf], Gu[pf + 1], Gu[pf + 2], sc + s.gln, stream);
+    char* gln_sl = sc + s.arena + (size_t)i * ((size_t)(D + 2) * s.gln_slice + (size_t)D * s.dw_slice);   // D + 2 norm slices,
+    char* dw_sl = gln_sl + (size_t)(D + 2) * s.gln_slice;                                                 // then D conv slices
+    srf_defer_set(true);
+    rc = srf_gln_bwd(gf, nullptr, merged, &fn, Bg, nC, L, gf, 0, Gu[pf], Gu[pf + 1], Gu[pf + 2], gln_sl, stream);
     if (rc) return rc;                                       // gf now holds g_merged = g_n_0 (merge part)
     float* gn[SRF_MAX_DEPTH];
     gn[0] = gf;
@@ -464,8 +482,8 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     // is in its registers); and it evaluates the apply pass of its OWN level's norm on load.  So per level: one
     // parameter-sum kernel + one conv-backward kernel, g_d never written; only the deepest level needs a reduce
     // pass.  The two norm scratch areas alternate (level k's sums are read while level k-1's are written).
-    int pre_reduced = 0, pp = 0;
-    char* gsc[2] = {sc + s.gln, sc + s.gln2};
+    // (one slice per call -- the alternation is now simply "this call's slice, the next call's slice")
+    int pre_reduced = 0, pp = 1;
     const float* g_o = go;   // where level 0's conv leaves the gradient w.r.t. o = PReLU(GlobLN(y1))
     for (int k = D - 1; k >= 0; --k) {
       const float* const* Pk = Pu + 5 + 4 * k;   // conv.weight, conv.bias, norm.gamma, norm.beta
@@ -503,19 +521,22 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
       const bool on_load = !gout2 && gout1 != gin && srf_dwconv5_bwd_rowwise_ok(Lin, stride, ptrs, 5);
       if (!on_load && k == 0) gin = go;
       if (k == 0) g_o = gin;
-      rc = srf_gln_bwd_impl(gout1, gout2, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, gsc[pp],
+      char* cur_sl = gln_sl + (size_t)pp * s.gln_slice;
+      char* next_sl = cur_sl + s.gln_slice;
+      rc = srf_gln_bwd_impl(gout1, gout2, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, cur_sl,
                             (pre_reduced ? 1 : 0) | (on_load ? 2 : 0), stream);
       if (rc) return rc;
-      rc = srf_dwconv5_bwd_impl(on_load ? gout1 : gd, src, &in, Pk[0], Bg, nC, Lin, stride, gin, Gk[0], Gk[1], sc + s.dw,
-                                gadd, gsc[pp ^ 1], &pre_reduced, on_load ? dk : nullptr, on_load ? &nk : nullptr,
-                                on_load ? gsc[pp] : nullptr, stream);
+      rc = srf_dwconv5_bwd_impl(on_load ? gout1 : gd, src, &in, Pk[0], Bg, nC, Lin, stride, gin, Gk[0], Gk[1],
+                                dw_sl + (size_t)k * s.dw_slice, gadd, next_sl, &pre_reduced, on_load ? dk : nullptr,
+                                on_load ? &nk : nullptr, on_load ? cur_sl : nullptr, stream);
       if (rc) return rc;
-      pp ^= 1;
+      pp += 1;
     }
     // proj_1x1: y1 = W_p xin + b_p, o = PReLU(GlobLN(y1))
     srf_norm pn{slot(s0), Pu[2], Pu[3], Pu[4]};
-    rc = srf_gln_bwd_impl(g_o, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], gsc[pp], pre_reduced,
-                          stream);   // go = g_y1
+    rc = srf_gln_bwd_impl(g_o, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], gln_sl + (size_t)pp * s.gln_slice,
+                          pre_reduced, stream);   // go = g_y1
+    srf_defer_set(false);
     if (rc) return rc;
     rc = srf_pw_wgrad(go, xin, nullptr, Bg, nB, nC, L, Gu[0], Gu[1], 1, wg, stream);
     if (rc) return rc;
@@ -555,6 +576,9 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     rc = srf_gln_bwd(gv, nullptr, enc, &ln, Bt, N, L, genc, 1, G[1], G[2], nullptr, sc + s.gln, stream);
     if (rc) return rc;
   }
+  // ---- the blocks' deferred parameter-gradient reductions, batched
+  rc = srf_defer_flush(st);
+  if (rc) return rc;
   // ---- encoder weight                                           :247-251,286
   rc = srf_frames_gather(wav, frames, Bt, p->A, p->T, K, h, h, L, p->A * K, stream);
   if (rc) return rc;
