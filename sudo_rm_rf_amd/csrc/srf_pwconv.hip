@@ -19,6 +19,7 @@
 #include "srf_common.h"
 
 #include "srf_pw.h"
+#include <vector>
 
 // ---------------------------------------------------------------------------------------------
 // generic VALU kernel
@@ -362,6 +363,29 @@ int srf_pw_conv_preadd(const float* x, const float* q, const srf_norm* qnorm, fl
 extern "C" size_t srf_packed_pw_weight_bytes(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0 || !srf_x3v_supported(Cin, Cout, 4)) return 0;
   return srf_x3v_packed_bytes(Cout, Cin);
+}
+
+// Whether srf_pw_conv_packed will serve this launch from the packed image alone (the 256 x 128 kernel, whole or chunked over
+// examples) -- then the fp32 weight argument is never read (the backward skips its transposed copy).  Mirrors the dispatch.
+bool srf_pw_packed_only(const void* w_packed, const float* x, int Bt, int Cin, int Cout, int L) {
+  if (!w_packed || srf_kernel_mode() != 0 || (srf_debug_flags() & 4)) return false;
+  if ((Cin % PW_BK) || (L % 4) || Cout < 32 || Cin < 32 || !srf_aligned16(x) || !srf_aligned16(w_packed)) return false;
+  if (srf_pw_small_supported(Cin, Cout, L) || !srf_x3v_supported(Cin, Cout, L)) return false;
+  if ((long)Bt * Cin * L * 4 >= (1L << 31)) return false;      // (the chunked form decides per chunk: keep the copy)
+  return (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus();
+}
+
+// (library-internal: the backward's data-gradient GEMMs) w[i] is the FORWARD weight [Cin][Cout]; the image is that of its
+// transpose [Cout][Cin] -- no transposed copy is made
+int srf_pack_pw_weights_transposed(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n,
+                                   hipStream_t st) {
+  std::vector<int> neg(Cin, Cin + n);
+  for (int i = 0; i < n; ++i) {
+    SRF_CHECK_ARG(w[i] && packed[i] && srf_packed_pw_weight_bytes(Cout[i], Cin[i]) > 0 && srf_aligned16(packed[i]),
+                  "srf_pack_pw_weights: entry %d unsupported (Cout=%d Cin=%d)", i, Cout[i], Cin[i]);
+    neg[i] = -Cin[i];
+  }
+  return srf_x3v_pack_launch(w, reinterpret_cast<char* const*>(packed), Cout, neg.data(), n, st);
 }
 
 extern "C" int srf_pack_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin,

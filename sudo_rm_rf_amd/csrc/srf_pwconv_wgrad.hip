@@ -317,6 +317,28 @@ __global__ __launch_bounds__(256) void srf_wgrad_reduce_kernel(const float* __re
     out[dst] = beta != 0.f ? fmaf(beta, out[dst], s) : s;
 }
 
+// The weight AND the bias partials of one wgrad in one launch (round 3: the separate bias reduction was a 12-us launch for
+// 256-512 sums): threads [0, rows * cols_out) fold dW as srf_wgrad_reduce_kernel does, the next `rows` threads the bias.
+__global__ __launch_bounds__(256) void srf_wgrad_reduce2_kernel(const float* __restrict__ part, float* __restrict__ out, int rows,
+                                                                int cols, int cols_out, int ld_out,
+                                                                const float* __restrict__ bias_part, float* __restrict__ bias_out,
+                                                                int P, float beta) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long nw = (long)rows * cols_out;
+  if (i < nw) {
+    const int m = (int)(i / cols_out), n = (int)(i - (long)m * cols_out);
+    const size_t src = (size_t)m * cols + n, stride = (size_t)rows * cols, dst = (size_t)m * ld_out + n;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(size_t)p * stride + src];
+    out[dst] = beta != 0.f ? fmaf(beta, out[dst], s) : s;
+  } else if (i < nw + rows) {
+    const int m = (int)(i - nw);
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += bias_part[(size_t)p * rows + m];
+    bias_out[m] = beta != 0.f ? fmaf(beta, bias_out[m], s) : s;
+  }
+}
+
 // dst [rows][ld] <- sum over P partials [P][rows][cols] (first cols_out columns)
 static int wg_reduce_launch(const float* part, float* out, int rows, int cols, int cols_out, int ld_out, int P,
                             int accumulate, hipStream_t st) {
@@ -423,11 +445,18 @@ extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* i
   }
   SRF_CHECK_LAUNCH("pw_wgrad", st);
   }
-  int rc = wg_reduce_launch(a.part, dw, Cout, Cin, dw_cols, dw_ld, a.P, accumulate, st);
-  if (rc) return rc;
-  if (dbias) {
-    rc = wg_reduce_launch(a.bias_part, dbias, Cout, 1, 1, 1, a.P, accumulate, st);
+  int rc;
+  if (dbias && !(a.P >= 64 && (long)Cout * dw_cols * 4 <= 65536)) {   // (large outputs: no partial split, one launch for both)
+    const long n = (long)Cout * dw_cols + Cout;
+    hipLaunchKernelGGL(srf_wgrad_reduce2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin, dw_cols,
+                       dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
+  } else {
+    rc = wg_reduce_launch(a.part, dw, Cout, Cin, dw_cols, dw_ld, a.P, accumulate, st);
     if (rc) return rc;
+    if (dbias) {
+      rc = wg_reduce_launch(a.bias_part, dbias, Cout, 1, 1, 1, a.P, accumulate, st);
+      if (rc) return rc;
+    }
   }
   SRF_CHECK_LAUNCH("pw_wgrad_reduce", st);
   return SRF_OK;

@@ -39,14 +39,16 @@ __host__ __device__ __forceinline__ int v_swz(int r, int c) { return r * 64 + ((
 struct VPackEntry {
   const float* w;
   char* dst;
-  int Cout, Cin;
+  int Cout, Cin;   // Cin < 0: w is stored TRANSPOSED ([|Cin|][Cout]) -- the backward's data-gradient GEMMs use W^T
 };
 struct VPackTable {
   VPackEntry e[SRF_V_MAX_PACK];
 };
 
 __global__ __launch_bounds__(256) void srf_x3v_pack_kernel(VPackTable t) {
-  const VPackEntry e = t.e[blockIdx.y];
+  VPackEntry e = t.e[blockIdx.y];
+  const bool trans = e.Cin < 0;
+  e.Cin = trans ? -e.Cin : e.Cin;
   const int nKt = e.Cin / V_BK;
   const int nMt = (e.Cout + V_BM - 1) / V_BM;
   const long total = (long)nMt * nKt * V_BM * 4;   // one thread per 8-k packet
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(256) void srf_x3v_pack_kernel(VPackTable t) {
     bf16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float v = (m < e.Cout) ? e.w[(size_t)m * e.Cin + kt * V_BK + c * 8 + j] : 0.f;
+      const int k = kt * V_BK + c * 8 + j;
+      const float v = (m < e.Cout) ? (trans ? e.w[(size_t)k * e.Cout + m] : e.w[(size_t)m * e.Cin + k]) : 0.f;
       const __bf16 h = (__bf16)v;
       hi[j] = h;
       lo[j] = (__bf16)(v - (float)h);

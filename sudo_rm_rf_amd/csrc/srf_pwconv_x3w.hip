@@ -1024,6 +1024,7 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
         (const void*)&srf_pw_x3w_kernel<3, 2, 0, 4>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, 5>,
         (const void*)&srf_pw_x3w_kernel<3, 2, 0, 13>,
         (const void*)&srf_pw_x3w_kernel<3, 4, 0, 0>, (const void*)&srf_pw_x3w_kernel<3, 4, 0, 4>,
+        (const void*)&srf_pw_x3w_kernel<0, 1, 0, 0>,
         // three-part operands (training forward)
         (const void*)&srf_pw_x3w_kernel<0, 0, 0, 0, 3>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 5, 3>,
         (const void*)&srf_pw_x3w_kernel<2, 1, 0, 5, 3>, (const void*)&srf_pw_x3w_kernel<3, 0, 0, 5, 3>,
@@ -1142,6 +1143,7 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
   if (pro == 0 && !res && !mask) { W_CP4(0, 0) }
   else if (pro == 1 && !res && !mask) { W_CP4(1, 0) }
   else if (pro == 2 && res) { W_CP5(2, 1) }
+  else if (pro == 0 && res) W_GO(0, 1, 0, 0);      // (the backward's data-gradient GEMM of proj_1x1: W^T g + skip gradient)
   else if (pro == 3 && mask) { W_CP5(3, 2) }
   else if (pro == 0) W_GO(0, 3, 0, 0);
   else if (pro == 1) W_GO(1, 3, 0, 0);

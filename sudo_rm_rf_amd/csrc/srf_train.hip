@@ -23,6 +23,9 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
                      int mode, void* stream);
 bool srf_dwconv5_bwd_rowwise_ok(int Lin, int stride, const void* const* ptrs, int nptrs);
 bool srf_pyramid_reg_supported(int L, int D);
+int srf_pack_pw_weights_transposed(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n,
+                                   hipStream_t st);   // srf_pwconv.hip
+bool srf_pw_packed_only(const void* w_packed, const float* x, int Bt, int Cin, int Cout, int L);   // srf_pwconv.hip
 void srf_defer_set(bool on);          // srf_backward.hip: deferred parameter-gradient reductions
 int srf_defer_flush(hipStream_t st);
 extern "C" size_t srf_packed3_pw_weight_bytes(int Cout, int Cin);
@@ -86,7 +89,7 @@ static TrainLayout train_layout(const srf_plan* p) {
 
 struct ScratchLayout {
   size_t dec, gv, genc, gxa, gxb, gf, go, gd, gn[SRF_MAX_DEPTH], gu[SRF_MAX_DEPTH], frames, wt, zeros, wdpad, wg,
-      gln, gln2, dw, gq, gxm, tac, pk3, arena, arena_bytes, gln_slice, dw_slice, total;
+      gln, gln2, dw, gq, gxm, tac, pk3, pkT, arena, arena_bytes, gln_slice, dw_slice, total;
   int dec_rows;
 };
 
@@ -151,6 +154,12 @@ static ScratchLayout scratch_layout(const srf_plan* p) {
   s.dw_slice = al256(srf_dwconv5_bwd_scratch_bytes(p->Bg, p->nC));
   s.arena_bytes = (size_t)c.num_blocks * ((size_t)(D + 2) * s.gln_slice + (size_t)D * s.dw_slice);
   s.arena = take(s.arena_bytes);
+  // two-part images of the TRANSPOSED weights for the backward's data-gradient GEMMs (packed once per backward)
+  {
+    size_t pk = al256(srf_packed_pw_weight_bytes(B, SAN)) + al256(srf_packed_pw_weight_bytes(N, B));
+    pk += (size_t)c.num_blocks * (al256(srf_packed_pw_weight_bytes(p->nC, p->nB)) + al256(srf_packed_pw_weight_bytes(p->nB, p->nC)));
+    s.pkT = take(pk);
+  }
   // three-part weight images of the forward's 1x1 convolutions (packed once per step by srf_forward_train)
   {
     size_t pk = al256(srf_packed3_pw_weight_bytes(B, N)) + al256(srf_packed3_pw_weight_bytes(SAN, B));
@@ -411,6 +420,36 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
   } defer_off_on_exit;
 
   const int pt = p->p_tail;
+  // The data-gradient GEMMs g_x = W^T g run on the 256 x 128 split-bf16 kernel with the TRANSPOSED weights pre-split into its
+  // stage images, all of them in one launch here (shapes / launches that kernel does not take keep the transposed fp32 copy
+  // `wt` and the 128 x 128 kernels).
+  std::vector<const float*> pk_w;
+  std::vector<void*> pk_d;
+  std::vector<int> pk_co, pk_ci;
+  size_t pk_off = s.pkT;
+  auto packT = [&](const float* w, int cout_d, int cin_d) -> const void* {   // w: forward weight [cin_d][cout_d]
+    const size_t bytes = srf_packed_pw_weight_bytes(cout_d, cin_d);
+    if (!bytes || srf_kernel_mode() != 0) return nullptr;
+    void* d = sc + pk_off;
+    pk_off += al256(bytes);
+    pk_w.push_back(w);
+    pk_d.push_back(d);
+    pk_co.push_back(cout_d);
+    pk_ci.push_back(cin_d);
+    return d;
+  };
+  const void* pkT_mask = packT(P[pt + 1], B, SAN);
+  const void* pkT_bott = packT(P[3], N, B);
+  std::vector<const void*> pkT_res(U, nullptr), pkT_proj(U, nullptr);
+  for (int i = 0; i < U; ++i) {
+    const float* const* Pu_ = P + p->p_block0 + (size_t)i * p->p_block_stride + p->p_ublock_off;
+    pkT_res[i] = packT(Pu_[5 + 4 * D + 3], p->nC, p->nB);    // res_conv: forward [nB][nC], gradient GEMM nB -> nC
+    pkT_proj[i] = packT(Pu_[0], p->nB, p->nC);               // proj_1x1: forward [nC][nB], gradient GEMM nC -> nB
+  }
+  if (!pk_w.empty()) {
+    rc = srf_pack_pw_weights_transposed(pk_w.data(), pk_d.data(), pk_co.data(), pk_ci.data(), (int)pk_w.size(), st);
+    if (rc) return rc;
+  }
   // ---- decoder: out = overlap_add(W_d^T v)                       improved_sudormrf.py:272-279,300
   float* frames = fp(s.frames);
   rc = srf_frames_gather(grad_out, frames, Bt, SA, p->T, K, h, h, L, s.dec_rows, stream);
@@ -435,9 +474,10 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     srf_norm pre{nullptr, nullptr, nullptr, P[pt]};
     rc = srf_pw_wgrad(gv, xbuf(U), &pre, Bt, B, SAN, L, G[pt + 1], G[pt + 2], 1, wg, stream);
     if (rc) return rc;
-    rc = srf_transpose_launch(P[pt + 1], wt, SAN, B, st);   // [SAN][B] -> [B][SAN]
+    if (!srf_pw_packed_only(pkT_mask, gv, Bt, SAN, B, L))    // (the packed image of W^T serves the GEMM: no fp32 copy needed)
+      rc = srf_transpose_launch(P[pt + 1], wt, SAN, B, st);   // [SAN][B] -> [B][SAN]
     if (rc) return rc;
-    rc = srf_pw_conv(gv, wt, zeros, gx, Bt, SAN, B, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+    rc = srf_pw_conv_packed(gv, wt, pkT_mask, zeros, gx, Bt, SAN, B, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
     if (rc) return rc;
     rc = srf_prelu_bwd(gx, xbuf(U), P[pt], gx, G[pt], (long)Bt * B * L, stream);
     if (rc) return rc;
@@ -463,9 +503,10 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     srf_norm fn{slot(s0 + 1 + D), Pu[pf], Pu[pf + 1], Pu[pf + 2]};
     rc = srf_pw_wgrad(gx, merged, &fn, Bg, nC, nB, L, Gu[pf + 3], Gu[pf + 4], 1, wg, stream);
     if (rc) return rc;
-    rc = srf_transpose_launch(Pu[pf + 3], wt, nB, nC, st);    // [nB][nC] -> [nC][nB]
+    if (!srf_pw_packed_only(pkT_res[i], gx, Bg, nB, nC, L))
+      rc = srf_transpose_launch(Pu[pf + 3], wt, nB, nC, st);    // [nB][nC] -> [nC][nB]
     if (rc) return rc;
-    rc = srf_pw_conv(gx, wt, zeros, gf, Bg, nB, nC, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+    rc = srf_pw_conv_packed(gx, wt, pkT_res[i], zeros, gf, Bg, nB, nC, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
     if (rc) return rc;
     char* gln_sl = sc + s.arena + (size_t)i * ((size_t)(D + 2) * s.gln_slice + (size_t)D * s.dw_slice);   // D + 2 norm slices,
     char* dw_sl = gln_sl + (size_t)(D + 2) * s.gln_slice;                                                 // then D conv slices
@@ -540,9 +581,10 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     if (rc) return rc;
     rc = srf_pw_wgrad(go, xin, nullptr, Bg, nB, nC, L, Gu[0], Gu[1], 1, wg, stream);
     if (rc) return rc;
-    rc = srf_transpose_launch(Pu[0], wt, nC, nB, st);          // [nC][nB] -> [nB][nC]
+    if (!srf_pw_packed_only(pkT_proj[i], go, Bg, nC, nB, L))
+      rc = srf_transpose_launch(Pu[0], wt, nC, nB, st);          // [nC][nB] -> [nB][nC]
     if (rc) return rc;
-    rc = srf_pw_conv(go, wt, zeros, gx_other, Bg, nC, nB, L, nullptr, gx, nullptr, 0, nullptr, 0, stream);   // + skip
+    rc = srf_pw_conv_packed(go, wt, pkT_proj[i], zeros, gx_other, Bg, nC, nB, L, nullptr, gx, nullptr, 0, nullptr, 0, stream);   // + skip
     if (rc) return rc;
     float* tmp = gx;
     gx = gx_other;
@@ -568,10 +610,11 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     srf_norm ln{slot(0), P[1], P[2], nullptr};
     rc = srf_pw_wgrad(gx, enc, &ln, Bt, N, B, L, G[3], G[4], 1, wg, stream);
     if (rc) return rc;
-    rc = srf_transpose_launch(P[3], wt, B, N, st);           // [B][N] -> [N][B]
+    if (!srf_pw_packed_only(pkT_bott, gx, Bt, B, N, L))
+      rc = srf_transpose_launch(P[3], wt, B, N, st);           // [B][N] -> [N][B]
     if (rc) return rc;
     // g_ln into the (now free) gv buffer, then GlobLN backward accumulated onto the mask path's g_enc
-    rc = srf_pw_conv(gx, wt, zeros, gv, Bt, B, N, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+    rc = srf_pw_conv_packed(gx, wt, pkT_bott, zeros, gv, Bt, B, N, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
     if (rc) return rc;
     rc = srf_gln_bwd(gv, nullptr, enc, &ln, Bt, N, L, genc, 1, G[1], G[2], nullptr, sc + s.gln, stream);
     if (rc) return rc;
