@@ -28,6 +28,10 @@ struct GlnBwdArgs {
   double* bsums;        // [groups][SRF_STAT_BUCKETS][2]  {S1, S2}
   float* gx;
   int C, L, accumulate;
+  // apply pass only (srf_gln_bwd_apply_v4_kernel): the merge backward folded in -- gx is then g_merged = g_n_0 and level k's
+  // gradient g_n_k[j] = g_n_{k-1}[2j] + g_n_{k-1}[2j+1] goes to mlv[k] ([rows, L >> k], k = 1 .. mD - 1); mD <= 1 = off
+  float* mlv[SRF_MAX_DEPTH] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int mD = 0;
 };
 
 __global__ __launch_bounds__(256) void srf_gln_bwd_reduce_kernel(GlnBwdArgs a) {
@@ -341,6 +345,24 @@ __global__ __launch_bounds__(256) void srf_gln_bwd_apply_v4_kernel(GlnBwdArgs a,
           o.w += t.w;
         }
         gx[f] = o;
+        // ---- merge backward on the way out (round 3): the chain of pair sums srf_merge_bwd would compute from the tensor just
+        // written -- same additions, same order (bitwise equal) -- without reading it back.  A lane holds 4 consecutive samples:
+        // levels 1 and 2 are lane-local, from level 3 on 2, 4, 8 neighbouring lanes (consecutive float4 of the row) combine.
+        // (L % 2^(mD-1) == 0, so a group of lanes never straddles the row's end: all of its lanes are inside this branch.)
+        if (a.mD > 1) {
+          const float p0 = o.x + o.y, p1 = o.z + o.w;
+          reinterpret_cast<float2*>(a.mlv[1] + row * (long)(a.L >> 1))[f] = make_float2(p0, p1);
+          float sacc = p0 + p1;
+          if (a.mD > 2) a.mlv[2][row * (long)(a.L >> 2) + f] = sacc;
+#pragma unroll
+          for (int k = 3; k < SRF_MAX_DEPTH; ++k) {
+            if (k < a.mD) {
+              const int grp = 1 << (k - 2);                       // lanes per output
+              sacc = sacc + __shfl_down(sacc, grp >> 1, 64);      // (lane, lane + grp/2): left + right half, like the chain
+              if ((lane & (grp - 1)) == 0) a.mlv[k][row * (long)(a.L >> k) + (f >> (k - 2))] = sacc;
+            }
+          }
+        }
       }
     }
   }
@@ -357,9 +379,26 @@ extern "C" size_t srf_gln_bwd_scratch_bytes(int groups, int C) {
 // mode bit 0 (pre-reduced): `scratch` already holds this norm's row partials and S1/S2 buckets (written by the fused
 // srf_dwconv5_bwd_impl for exactly this gout/x pair) -- no reduce pass.  mode bit 1: no apply pass (the consumer,
 // srf_dwconv5_bwd_impl in apply-on-load form, evaluates it from `scratch`; gx may be NULL).
+// One-shot request by the NEXT srf_gln_bwd_impl call on this thread: fold the merge backward (srf_merge_bwd on its output gx)
+// into its apply pass.  srf_gln_bwd_merge_taken() tells afterwards whether that happened (vectorised apply kernel, aligned
+// level buffers); if not, the caller runs srf_merge_bwd itself.
+static thread_local struct {
+  float* lv[SRF_MAX_DEPTH];
+  int D;
+  bool taken;
+} g_merge_sink = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 0, false};
+void srf_gln_bwd_merge_sink(float* const* levels, int D) {
+  g_merge_sink.D = (levels && D > 1 && D <= SRF_MAX_DEPTH) ? D : 0;
+  g_merge_sink.taken = false;
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) g_merge_sink.lv[k] = (k >= 1 && k < g_merge_sink.D) ? levels[k] : nullptr;
+}
+bool srf_gln_bwd_merge_taken() { return g_merge_sink.taken; }
+
 int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
                      int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch,
                      int mode, void* stream) {
+  const int sink_D = g_merge_sink.D;      // (consumed by this call, whatever happens)
+  g_merge_sink.D = 0;
   const int pre_reduced = mode & 1, no_apply = (mode >> 1) & 1;
   SRF_CHECK_ARG(gout && x && norm && norm->sums && norm->gamma && norm->beta && (gx || no_apply) && scratch,
                 "srf_gln_bwd: null pointer");
@@ -402,6 +441,15 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
     }
   }
   if (no_apply) return SRF_OK;
+  if (v4 && sink_D > 1 && (L % (1 << (sink_D - 1))) == 0 && !accumulate_gx) {
+    bool ok = true;
+    for (int k = 1; k < sink_D; ++k) ok = ok && g_merge_sink.lv[k] && srf_aligned16(g_merge_sink.lv[k]);
+    if (ok) {
+      a.mD = sink_D;
+      for (int k = 1; k < sink_D; ++k) a.mlv[k] = g_merge_sink.lv[k];
+      g_merge_sink.taken = true;
+    }
+  }
   if (v4)
     hipLaunchKernelGGL(srf_gln_bwd_apply_v4_kernel, grid4, dim3(256), 0, st, a, rows);
   else

@@ -26,6 +26,8 @@ bool srf_pyramid_reg_supported(int L, int D);
 int srf_pack_pw_weights_transposed(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n,
                                    hipStream_t st);   // srf_pwconv.hip
 bool srf_pw_packed_only(const void* w_packed, const float* x, int Bt, int Cin, int Cout, int L);   // srf_pwconv.hip
+void srf_gln_bwd_merge_sink(float* const* levels, int D);   // srf_backward.hip: merge backward folded into the next gln apply
+bool srf_gln_bwd_merge_taken();
 void srf_defer_set(bool on);          // srf_backward.hip: deferred parameter-gradient reductions
 int srf_defer_flush(hipStream_t st);
 extern "C" size_t srf_packed3_pw_weight_bytes(int Cout, int Cin);
@@ -511,13 +513,16 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     char* gln_sl = sc + s.arena + (size_t)i * ((size_t)(D + 2) * s.gln_slice + (size_t)D * s.dw_slice);   // D + 2 norm slices,
     char* dw_sl = gln_sl + (size_t)(D + 2) * s.gln_slice;                                                 // then D conv slices
     srf_defer_set(true);
-    rc = srf_gln_bwd(gf, nullptr, merged, &fn, Bg, nC, L, gf, 0, Gu[pf], Gu[pf + 1], Gu[pf + 2], gln_sl, stream);
-    if (rc) return rc;                                       // gf now holds g_merged = g_n_0 (merge part)
     float* gn[SRF_MAX_DEPTH];
     gn[0] = gf;
     for (int k = 1; k < D; ++k) gn[k] = fp(s.gn[k]);
-    rc = srf_merge_bwd(gf, gn, D, (long)Bg * nC, L, stream);
-    if (rc) return rc;
+    srf_gln_bwd_merge_sink(gn, D);       // the merge backward rides on the norm's apply pass (the levels' pair sums of its output)
+    rc = srf_gln_bwd(gf, nullptr, merged, &fn, Bg, nC, L, gf, 0, Gu[pf], Gu[pf + 1], Gu[pf + 2], gln_sl, stream);
+    if (rc) return rc;                                       // gf now holds g_merged = g_n_0 (merge part)
+    if (!srf_gln_bwd_merge_taken()) {
+      rc = srf_merge_bwd(gf, gn, D, (long)Bg * nC, L, stream);
+      if (rc) return rc;
+    }
     // Level k's conv backward also produces the COMPLETE gradient w.r.t. its (normalised) input -- its own input
     // gradient + the merge part gn[k-1] -- and the reduce pass of that input's GlobLN backward (the input tensor
     // is in its registers); and it evaluates the apply pass of its OWN level's norm on load.  So per level: one
