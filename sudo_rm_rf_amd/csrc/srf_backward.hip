@@ -121,6 +121,11 @@ struct SrfDeferCtx {
 };
 static thread_local SrfDeferCtx g_defer;
 void srf_defer_set(bool on) { g_defer.on = on; }
+void srf_defer_clear() {   // (a backward that failed half-way must not leave its records to the next one)
+  g_defer.on = false;
+  g_defer.gln.clear();
+  g_defer.dw.clear();
+}
 bool srf_defer_on() { return g_defer.on; }
 
 __device__ __forceinline__ void srf_gln_bwd_params_body(const float* __restrict__ rowpart, int groups, int C, float* dgamma,

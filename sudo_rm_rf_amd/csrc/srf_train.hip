@@ -29,6 +29,7 @@ bool srf_pw_packed_only(const void* w_packed, const float* x, int Bt, int Cin, i
 void srf_gln_bwd_merge_sink(float* const* levels, int D);   // srf_backward.hip: merge backward folded into the next gln apply
 bool srf_gln_bwd_merge_taken();
 void srf_defer_set(bool on);          // srf_backward.hip: deferred parameter-gradient reductions
+void srf_defer_clear();
 int srf_defer_flush(hipStream_t st);
 extern "C" size_t srf_packed3_pw_weight_bytes(int Cout, int Cin);
 extern "C" int srf_pack3_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n, void* stream);
@@ -416,7 +417,7 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
   // the blocks' norm / conv backwards get one scratch slice per call (statistic buckets zeroed here, once) and leave their
   // parameter-gradient reductions to one batched flush after the block loop
   SRF_CHECK_HIP(hipMemsetAsync(sc + s.arena, 0, s.arena_bytes, st));
-  srf_defer_set(false);
+  srf_defer_clear();
   struct DeferOff {
     ~DeferOff() { srf_defer_set(false); }
   } defer_off_on_exit;
