@@ -196,7 +196,8 @@ extern "C" size_t srf_train_scratch_bytes(const srf_plan* p) { return p ? scratc
 static int forward_train_impl(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
                               void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
 
-// The training forward runs its 1x1 convolutions on the EXACT fp32 MFMA path unless debug flag 1<<28 is set.
+// The training forward runs its 1x1 convolutions in the EXACT-fp32 CLASS (kernel mode 2: since round 3 the three-part split
+// GEMM where the 256 x 128 kernel takes the launch, else the exact fp32 MFMA kernel) unless debug flag 1<<28 is set.
 // The split-bf16 GEMMs are accurate to ~2^-17 of sum|terms| per output -- far inside the 1e-4 forward bar -- but
 // the gradients of the first blocks' parameters are ill-conditioned with respect to exactly that rounding:
 // injecting 2^-17 noise into the bottleneck GEMM's output alone moves d loss / d sm.0.proj_1x1.conv.weight by 5 %
