@@ -118,7 +118,8 @@ int srf_profile_get(int i, const char** name, float* ms);
  *   bits 12-13, 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating)
  *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
  *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)
- *   1<<29 / 1<<30  chunked depthwise-backward / scalar GlobLN-backward kernels and no backward fusion */
+ *   1<<29 / 1<<30  chunked depthwise-backward / scalar GlobLN-backward kernels and no backward fusion
+ *   1<<31    training forward on the exact-fp32 MFMA kernel instead of the three-part split GEMM (pass INT_MIN) */
 #ifdef SRF_DIAGNOSTICS
 void srf_set_debug_flags(int flags);
 #endif
