@@ -212,7 +212,11 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
 bool srf_x3w_supported(int Bt, int pro);
 // the 256 x 128 kernel: round 3's unless debug flag 16384 asks for round 2's (same-box A/B) or the launch has more examples
 // than the statistics table of the round-3 kernel holds
+int srf_pw_x3s_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);   // round 4 (srf_pwconv_x3s.hip)
+bool srf_x3s_supported(int Bt, int pro);
 static int srf_pw_256_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
+  const char* sel = getenv("SRF_GEMM");
+  if (sel && sel[0] == 'x' && sel[2] == 's' && srf_x3s_supported(a.Bt, pro)) return srf_pw_x3s_launch(a, wpack, pro, st);
   if (!(srf_debug_flags() & 16384) && srf_x3w_supported(a.Bt, pro)) return srf_pw_x3w_launch(a, wpack, pro, st);
   return srf_pw_x3v_launch(a, wpack, pro, st);
 }

@@ -235,6 +235,17 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(r.b[j]));
       return;
     }
+    if constexpr ((ABL & 512) != 0) {     // diagnostics (results wrong): the same 16 KB per k-tile as TWO 16-byte loads per thread
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const int vo = t.b_vo - (b_kg * L + (tid & 127)) * 4 + ((wave * 4 + (lane >> 5)) * L + (lane & 31) * 4) * 4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b_rs, vo, (kt * KT + 2 * h) * L * 4, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.b[4 * h + j] = __uint_as_float(v[j]);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < (NP == 3 ? 4 : 8); ++j)
       r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * KT + j) * L * 4, (CP & 4) ? 2 : 0));
@@ -438,6 +449,10 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     const TileP t1 = pick(kt + 1, k1), t2 = pick(kt + 2, k2), t3 = pick(kt + 3, k3);
     if constexpr (!HAVE0) read_frags(f0, s0, 0, full_tag);
     if constexpr (HAVE0) read_frags(f1, s0, 1, full_tag);
+    // diagnostics / experiment (results stay correct): wavefronts 4..7 -- the SIMD partners of 0..3 -- multiply BEFORE they
+    // convert and issue their loads, so that one partner's memory-instruction queueing runs under the other's MFMAs
+    const bool mma_first = (ABL & 256) != 0 && NP != 3 && wave >= 4;
+    if (mma_first) mma(f0, full_tag);
     if constexpr (ABL & 64) {      // how long the step sits in the activation conversion (its wait for the loads of two steps ago)
       const unsigned ta = (unsigned)__builtin_amdgcn_s_memtime();
       lds_store(nx, t1, k1, s1);
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       read_frags(f1, s0, 1, full_tag);
       mma3_b(f0, f1, full_tag);
     } else {
-      mma(f0, full_tag);
+      if (!mma_first) mma(f0, full_tag);
       if constexpr (!HAVE0) {
         read_frags(f1, s0, 1, full_tag);
         mma(f1, full_tag);
@@ -1042,7 +1057,10 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
         (const void*)&srf_pw_x3w_kernel<2, 1, 3>, (const void*)&srf_pw_x3w_kernel<2, 1, 4>,
         (const void*)&srf_pw_x3w_kernel<2, 1, 16>, (const void*)&srf_pw_x3w_kernel<2, 1, 19>,
         (const void*)&srf_pw_x3w_kernel<2, 1, 20>, (const void*)&srf_pw_x3w_kernel<2, 1, 23>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 64>};
+        (const void*)&srf_pw_x3w_kernel<2, 1, 64>,
+        (const void*)&srf_pw_x3w_kernel<0, 0, 256>, (const void*)&srf_pw_x3w_kernel<0, 0, 512>,
+        (const void*)&srf_pw_x3w_kernel<0, 0, 768>, (const void*)&srf_pw_x3w_kernel<2, 1, 256>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 512>, (const void*)&srf_pw_x3w_kernel<2, 1, 768>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
@@ -1073,8 +1091,9 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
 #define W_GO(P, E, A, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
   // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated above),
   // 1 << 25 = in-kernel timeline (tools/gemm_timeline.py), 1 << 30 = epilogue without its stores
+  const int env_abl = getenv("SRF_X3W_ABL") ? atoi(getenv("SRF_X3W_ABL")) : 0;     // round-4 experiments: ABL bits 256 / 512
   const int abl = ((srf_debug_flags() >> 16) & 63) | ((srf_debug_flags() & (1 << 25)) ? 64 : 0) |
-                  ((srf_debug_flags() & (1 << 30)) ? 128 : 0);
+                  ((srf_debug_flags() & (1 << 30)) ? 128 : 0) | env_abl;
   if (abl && pro == 2 && res) {
     switch (abl) {
       case 3: W_GO(2, 1, 3, 0); break;
@@ -1084,6 +1103,9 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
       case 20: W_GO(2, 1, 20, 0); break;
       case 23: W_GO(2, 1, 23, 0); break;
       case 64: W_GO(2, 1, 64, 0); break;
+      case 256: W_GO(2, 1, 256, 0); break;
+      case 512: W_GO(2, 1, 512, 0); break;
+      case 768: W_GO(2, 1, 768, 0); break;
       default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for res_conv", abl);
     }
     SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
@@ -1104,6 +1126,9 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
       case 63: W_GO(0, 0, 63, 0); break;
       case 64: W_GO(0, 0, 64, 0); break;
       case 192: W_GO(0, 0, 192, 0); break;
+      case 256: W_GO(0, 0, 256, 0); break;
+      case 512: W_GO(0, 0, 512, 0); break;
+      case 768: W_GO(0, 0, 768, 0); break;
       default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for proj_1x1", abl);
     }
     SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);

@@ -2,7 +2,7 @@
 """Same-process interleaved A/B of the 256 x 128 split-bf16 GEMM variants on the model's launch shapes (cfg 2, cfg 4, cfg 5):
 rounds of N launches per variant, variants interleaved, median / min us per launch, outputs compared bit for bit.
 
-    python tools/gemm_ab.py [name=debug_flags ...]          default: x3w=0 x3v=16384
+    python tools/gemm_ab.py [name=debug_flags[:abl[:gemm]] ...]    default: x3w=0 x3v=16384   (abl: SRF_X3W_ABL, diagnostics builds only)
     GEMM_SHAPES=res_conv,proj_1x1 GEMM_ROUNDS=7 GEMM_ITERS=20"""
 import json
 import os
@@ -30,7 +30,16 @@ SHAPES = {  # name: (Bt, Cin, Cout, L, prologue, epilogue)
 
 def main():
     variants = [a.split("=") for a in sys.argv[1:]] or [["x3w", "0"], ["x3v", "16384"]]
-    variants = [(n, int(f)) for n, f in variants]
+    variants = [(n, f if ":" in f else f + ":0") for n, f in variants]
+
+    class _Flags:   # debug flags + the SRF_X3W_ABL environment switch of the experimental instantiations
+        @staticmethod
+        def set(spec):
+            f, abl, gemm = (spec.split(":") + ["", ""])[:3]
+            ops.set_debug_flags(int(f))
+            os.environ["SRF_X3W_ABL"] = abl or "0"
+            os.environ["SRF_GEMM"] = gemm           # "x3s": the role-split kernel (srf_pwconv_x3s.hip)
+
     only = os.environ.get("GEMM_SHAPES")
     rounds, iters = int(os.environ.get("GEMM_ROUNDS", "5")), int(os.environ.get("GEMM_ITERS", "10"))
     out = {}
@@ -57,7 +66,7 @@ def main():
         ref, times = None, {n: [] for n, _ in variants}
         same = {}
         for n, f in variants:
-            ops.set_debug_flags(f)
+            _Flags.set(f)
             y = ops.pw_conv(x, w, bias, **kw)
             torch.cuda.synchronize()
             if ref is None:
@@ -66,7 +75,7 @@ def main():
             del y
         for _ in range(rounds):
             for n, f in variants:
-                ops.set_debug_flags(f)
+                _Flags.set(f)
                 ops.pw_conv(x, w, bias, **kw)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -75,7 +84,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[n].append(e0.elapsed_time(e1) * 1e3 / iters)
-        ops.set_debug_flags(0)
+        _Flags.set("0:0")
         flop = 2.0 * Bt * Cin * Cout * L
         for n, _ in variants:
             med, mn = statistics.median(times[n]), min(times[n])
