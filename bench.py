@@ -253,8 +253,8 @@ def pmc_traffic(kernel_family, workload):
            "pw_conv_mfma": "srf_pw_mfma_kernel",
            "pyramid_moments": "srf_pyramid_reg_kernel<true", "pyramid_merge": "srf_pyramid_reg_kernel<false"
            }.get(kernel_family, kernel_family)
-    if kernel_family.startswith("pw_conv_x3v<"):             # "pw_conv_x3v<2>" -> the round-3 kernel "srf_pw_x3w_kernel<2, ..."
-        key = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3v<"):-1]
+    if kernel_family.startswith("pw_conv_x3w<"):             # family "pw_conv_x3w<2>" = every cache-policy instantiation of "srf_pw_x3w_kernel<2, ..."
+        key = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3w<"):-1]
     if kernel_family.startswith("pw_conv_bf16x3_p8<"):       # one label per prologue variant = one rocprof kernel name
         key = "srf_pw_bf16x3_p8_kernel<%s," % kernel_family[len("pw_conv_bf16x3_p8<"):-1]
     fetch, write = {}, {}
@@ -602,7 +602,7 @@ def main():
             model._engine().multi_stream = was_multi_p
             engine_mod._GRAPH_MODE = was_graph
         launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, packed=not (args.debug_flags & 8),
-                                         fuse_tail=not (args.debug_flags & (4 | 16384 | 32768)), **dims)
+                                         fuse_tail=not (args.debug_flags & (4 | 32768)), **dims)
         per = {}
         name, ms = C.c_char_p(), C.c_float()
         marks = []
@@ -630,7 +630,7 @@ def main():
             # Two ceilings for a 1x1-conv GEMM: the matrix pipe (fp32-equivalent FLOPs; the split-precision kernels issue 3
             # bf16 MFMAs per product block, so their peak is the bf16 dense peak / 3) and HBM (algorithmic bytes).  The
             # BINDING one -- the larger time floor -- is reported as the roofline, the other beside it.
-            split = dom.startswith("pw_conv_bf16x3") or dom.startswith("pw_conv_x3v")
+            split = dom.startswith("pw_conv_bf16x3") or dom.startswith("pw_conv_x3w")
             peak = roofline.MFMA_BF16_PEAK_TFLOPS / 3 if split else roofline.MFMA_F32_PEAK_TFLOPS
             mfma = {"bound": "mfma", "achieved": kd["TFLOPs"], "peak": peak, "unit": "TFLOP/s", "frac": kd["TFLOPs"] / peak,
                     "note": ("algorithmic fp32 FLOPs (2*Cin*Cout per output); peak = bf16 dense MFMA peak / 3 because "

@@ -12,21 +12,30 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libsudormrf_hip.so")
-SOURCES = ["srf_api.hip", "srf_encoder.hip", "srf_elementwise.hip", "srf_dwconv.hip", "srf_pyramid.hip", "srf_pyramid_reg.hip", "srf_pwconv.hip", "srf_pwconv_bf16x3.hip", "srf_pwconv_x3v.hip", "srf_pwconv_x3w.hip", "srf_pwconv_x3s.hip", "srf_pwconv_w4.hip", "srf_pwconv_small.hip",
+SOURCES = ["srf_api.hip", "srf_encoder.hip", "srf_elementwise.hip", "srf_dwconv.hip", "srf_pyramid.hip", "srf_pyramid_reg.hip", "srf_pwconv.hip", "srf_pwconv_bf16x3.hip", "srf_pwconv_x3w.hip", "srf_pwconv_w4.hip", "srf_pwconv_small.hip",
            "srf_tac.hip", "srf_loss.hip", "srf_pwconv_wgrad.hip", "srf_backward.hip", "srf_train.hip", "srf_augment.hip", "srf_optim.hip", "srf_feeder.hip"]
 HEADERS = [os.path.join(CSRC, "srf_common.h"), os.path.join(CSRC, "srf_pw.h"), os.path.join(CSRC, "srf_plan.h"), os.path.join(CSRC, "srf_pyr.h"),
            os.path.join(os.path.dirname(PKG), "include", "sudormrf_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
+# SRF_BUILD_EXPERIMENTS=1: a LAB build -- adds the GEMM experiments of csrc/experiments/ (role-split / one-SIMD-for-memory kernels,
+# selected at run time with SRF_GEMM=x3s | x3t), the ablated instantiations of the shipped GEMM (debug flag bits 16..21,
+# SRF_X3W_ABL) and its in-kernel timeline.  The default build -- what ships, what the tests and the bench load -- has none of it.
+EXPERIMENTS = os.environ.get("SRF_BUILD_EXPERIMENTS", "") not in ("", "0")
+EXPERIMENT_SOURCES = ["experiments/srf_pwconv_x3s.hip", "experiments/srf_pwconv_x3t.hip"]
+if EXPERIMENTS:
+    FLAGS = FLAGS + ["-DSRF_EXPERIMENTS=1"]
+    LIB = os.path.join(PKG, "libsudormrf_hip_lab.so")       # its own file (load it with SRF_LIB=...): never the product library
+    OBJ = os.path.join(CSRC, "build_lab")
 # Per-file flags.  The MFMA GEMM files are built without the SLP vectorizer: what it forms there are packed-fp32 VALU
 # instructions (v_pk_mul/fma/add_f32) out of the operand prologue's scalar code -- not fewer instructions (the persistent
 # res_conv kernel: 1721 VALU with, 1702 without), more expensive beside MFMAs (MI355X_MICROARCH.md, "price of one filler"),
 # and the source of the hazardous operand form below.
 FILE_FLAGS = {
     "srf_pwconv_bf16x3.hip": ["-fno-slp-vectorize"],
-    "srf_pwconv_x3v.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_x3w.hip": ["-fno-slp-vectorize"],
-    "srf_pwconv_x3s.hip": ["-fno-slp-vectorize"],
+    "experiments/srf_pwconv_x3s.hip": ["-fno-slp-vectorize"],
+    "experiments/srf_pwconv_x3t.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_w4.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_wgrad.hip": ["-fno-slp-vectorize"],
     "srf_pwconv.hip": ["-fno-slp-vectorize"],
@@ -71,7 +80,7 @@ def _digest(paths, extra=""):
 
 def _compile(cc, src, extra_flags):
     path = os.path.join(CSRC, src)
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    obj = os.path.join(OBJ, os.path.basename(src).replace(".hip", ".o"))
     stamp = obj + ".sha1"
     flags = FLAGS + FILE_FLAGS.get(src, []) + extra_flags
     dig = _digest([path, os.path.abspath(__file__)] + HEADERS, " ".join(flags))
@@ -85,7 +94,7 @@ def _compile(cc, src, extra_flags):
     warn = "\n".join(l for l in r.stderr.splitlines() if "argument unused during compilation" not in l)
     if warn.strip():
         sys.stderr.write(warn + "\n")
-    base = src.replace(".hip", "")
+    base = os.path.basename(src).replace(".hip", "")
     asm = os.path.join(OBJ, base + "-hip-amdgcn-amd-amdhsa-gfx950.s")
     if not os.path.exists(asm):
         raise RuntimeError("ISA lint: device assembly %s was not produced" % asm)
@@ -112,8 +121,9 @@ def build(force=False, verbose=True, extra_flags=()):
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
-        res = list(ex.map(lambda s: _compile(cc, s, extra_flags), SOURCES))
+    sources = SOURCES + (EXPERIMENT_SOURCES if EXPERIMENTS else [])
+    with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 4)) as ex:
+        res = list(ex.map(lambda s: _compile(cc, s, extra_flags), sources))
     objs = [o for o, _ in res]
     changed = any(c for _, c in res)
     if changed or not os.path.exists(LIB):

@@ -25,7 +25,7 @@
 // Prologue / epilogue semantics: srf_pw.h (PwArgs).  PRO / EPI / CP as in srf_pwconv_x3w.hip.
 #include <type_traits>
 
-#include "srf_pw.h"
+#include "../srf_pw.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -666,7 +666,7 @@ int srf_pw_x3s_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   else if (pro == 2) S_GO(2, 3, 0);
   else S_GO(3, 3, 0);
 #undef S_GO
-  static const char* const kLabel[4] = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_conv_x3v<3>"};
+  static const char* const kLabel[4] = {"pw_conv_x3w<0>", "pw_conv_x3w<1>", "pw_conv_x3w<2>", "pw_conv_x3w<3>"};
   SRF_CHECK_LAUNCH(kLabel[pro < 0 || pro > 3 ? 3 : pro], st);
   return SRF_OK;
 }

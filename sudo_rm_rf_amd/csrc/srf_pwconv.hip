@@ -207,25 +207,44 @@ __global__ __launch_bounds__(256) void srf_pw_mfma_kernel(PwArgs a, int nMt, int
 int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st);
 int srf_pw_w4_launch(const PwArgs& a, int pro, hipStream_t st);   // 64 x 64 tiles for small launches (srf_pwconv_w4.hip)
 bool srf_pw_w4_wanted(const PwArgs& a);
-int srf_pw_x3v_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
-int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);   // round 3 (srf_pwconv_x3w.hip)
+int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);   // the 256 x 128 kernel (srf_pwconv_x3w.hip)
 bool srf_x3w_supported(int Bt, int pro);
-// the 256 x 128 kernel: round 3's unless debug flag 16384 asks for round 2's (same-box A/B) or the launch has more examples
-// than the statistics table of the round-3 kernel holds
-int srf_pw_x3s_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);   // round 4 (srf_pwconv_x3s.hip)
+bool srf_x3w_shape_supported(int Cin, int Cout, int L);
+size_t srf_x3w_packed_bytes(int Cout, int Cin);
+int srf_x3w_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
+#ifdef SRF_EXPERIMENTS
+// Round-4 GEMM experiments (csrc/experiments/, SRF_BUILD_EXPERIMENTS=1 builds only; selected with SRF_GEMM=x3s | x3t; both
+// bit-identical to the shipped kernel): wavefronts split by role / one SIMD reserved for memory work.  In such a build a packed
+// weight buffer holds TWO images: [x3w image | x3t image].
+int srf_pw_x3s_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
 bool srf_x3s_supported(int Bt, int pro);
+int srf_pw_x3t_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
+bool srf_x3t_supported(int Bt, int Cin, int pro);
+size_t srf_x3t_packed_bytes(int Cout, int Cin);
+int srf_x3t_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
+#endif
 static int srf_pw_256_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
+#ifdef SRF_EXPERIMENTS
   const char* sel = getenv("SRF_GEMM");
   if (sel && sel[0] == 'x' && sel[2] == 's' && srf_x3s_supported(a.Bt, pro)) return srf_pw_x3s_launch(a, wpack, pro, st);
-  if (!(srf_debug_flags() & 16384) && srf_x3w_supported(a.Bt, pro)) return srf_pw_x3w_launch(a, wpack, pro, st);
-  return srf_pw_x3v_launch(a, wpack, pro, st);
+  if (sel && sel[0] == 'x' && sel[2] == 't' && srf_x3t_supported(a.Bt, a.Cin, pro) &&
+      (long)a.Bt * ((a.Cout + 255) / 256) * ((a.L + 191) / 192) >= srf_device_cus())
+    return srf_pw_x3t_launch(a, wpack + srf_x3w_packed_bytes(a.Cout, a.Cin), pro, st);
+#endif
+  return srf_pw_x3w_launch(a, wpack, pro, st);
 }
-size_t srf_x3v_packed_bytes(int Cout, int Cin);
-bool srf_x3v_supported(int Cin, int Cout, int L);
 int srf_pw_small_launch(const PwArgs& a, hipStream_t st);
 bool srf_pw_small_supported(int Cin, int Cout, int L);
-int srf_x3v_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n,
-                        hipStream_t st);
+
+// THE predicate of the 256 x 128 dispatch for a whole launch (srf_pw_conv_packed, srf_pw_conv_packed3 and srf_pw_packed_only all
+// use it -- ADVICE r3: the backward's "the fp32 weight is never read" shortcut was a hand-written copy of the dispatch test).
+static bool srf_pw_256_serves(const void* w_packed, const float* x, int Bt, int Cin, int Cout, int L, int pro) {
+  if (!w_packed || srf_kernel_mode() != 0 || (srf_debug_flags() & 4)) return false;
+  if ((Cin % PW_BK) || (L % 4) || Cout < 32 || Cin < 32 || !srf_aligned16(x) || !srf_aligned16(w_packed)) return false;
+  if (!srf_x3w_shape_supported(Cin, Cout, L) || !srf_x3w_supported(Bt, pro)) return false;
+  if ((long)Bt * Cin * L * 4 >= (1L << 31)) return false;      // (beyond the 32-bit buffer range: the chunked form decides per chunk)
+  return (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus();
+}
 
 // ---- K5 (library-internal; srf_forward's tail): mask GEMM + decoder contraction in one launch (srf_pwconv_x3w.hip, EPI 4)
 int srf_pw_x3w_fused_tail_launch(const PwArgs& a, const char* wpack, const char* wdpack, float* zpart, int M, hipStream_t st);
@@ -236,8 +255,8 @@ int srf_x3w_pack_dec_launch(const float* w, void* dst, int Ci, int M, hipStream_
 // srf_pw_conv_packed) and a decoder of at most 64 frame rows (sources x taps: 42 for the reference's 2 x 21).
 // Debug flag 32768 = without (the masked tensor is then materialised: srf_debug_fetch(2), A/B).
 bool srf_mask_decode_supported(int Bt, int Cin, int Cout, int L, int M) {
-  if (srf_kernel_mode() != 0 || (srf_debug_flags() & (4 | 8 | 16384 | 32768))) return false;
-  if (M <= 0 || M > 64 || Cout % 8 || Cin % PW_BK || L % 4 || !srf_x3v_supported(Cin, Cout, L) || !srf_x3w_supported(Bt, 3)) return false;
+  if (srf_kernel_mode() != 0 || (srf_debug_flags() & (4 | 8 | 32768))) return false;
+  if (M <= 0 || M > 64 || Cout % 8 || Cin % PW_BK || L % 4 || !srf_x3w_shape_supported(Cin, Cout, L) || !srf_x3w_supported(Bt, 3)) return false;
   if ((long)Bt * Cin * L * 4 >= (1L << 31)) return false;
   return (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus();
 }
@@ -281,7 +300,7 @@ size_t srf_x3w_packed3_bytes(int Cout, int Cin);
 int srf_x3w_pack3_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
 
 extern "C" size_t srf_packed3_pw_weight_bytes(int Cout, int Cin) {
-  if (Cout <= 0 || Cin <= 0 || !srf_x3v_supported(Cin, Cout, 4)) return 0;
+  if (Cout <= 0 || Cin <= 0 || !srf_x3w_shape_supported(Cin, Cout, 4)) return 0;
   return srf_x3w_packed3_bytes(Cout, Cin);
 }
 extern "C" int srf_pack3_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n,
@@ -302,10 +321,13 @@ extern "C" int srf_pw_conv_packed3(const float* x, const float* w, const void* w
   const SrfNormDev nd = srf_norm_dev(in_norm);
   const int pro = nd.sums ? (nd.prelu ? 2 : 1) : (nd.prelu ? 3 : 0);
   const bool form_ok = (pro == 2) == (residual != nullptr);      // the built forms: res_conv has the residual, the others none
-  const bool ok = w_packed3 && form_ok && srf_kernel_mode() != 1 && srf_x3v_supported(Cin, Cout, L) && srf_x3w_supported(Bt, pro) &&
-                  srf_aligned16(x) && srf_aligned16(w_packed3) && srf_aligned16(y) && (!residual || srf_aligned16(residual)) &&
-                  (long)Bt * Cin * L * 4 < (1L << 31) && !(srf_debug_flags() & 4) &&
-                  (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus();
+  // (kernel mode 2 -- the exact-fp32 MFMA kernels -- still takes this three-part split GEMM: it IS the exact-fp32 class)
+  const bool ok = form_ok && srf_kernel_mode() != 1 && srf_aligned16(y) && (!residual || srf_aligned16(residual)) &&
+                  (srf_kernel_mode() == 0 ? srf_pw_256_serves(w_packed3, x, Bt, Cin, Cout, L, pro)
+                                          : (w_packed3 && srf_x3w_shape_supported(Cin, Cout, L) && srf_x3w_supported(Bt, pro) &&
+                                             srf_aligned16(x) && srf_aligned16(w_packed3) && (long)Bt * Cin * L * 4 < (1L << 31) &&
+                                             !(srf_debug_flags() & 4) &&
+                                             (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus()));
   if (!ok) return srf_pw_conv(x, w, bias, y, Bt, Cin, Cout, L, in_norm, residual, out_sums, 0, nullptr, 0, stream);
   if (nd.sums) SRF_CHECK_ARG(nd.gamma && nd.beta, "srf_pw_conv: norm without gamma/beta");
   PwArgs a;
@@ -365,18 +387,31 @@ int srf_pw_conv_preadd(const float* x, const float* q, const srf_norm* qnorm, fl
 }
 
 extern "C" size_t srf_packed_pw_weight_bytes(int Cout, int Cin) {
-  if (Cout <= 0 || Cin <= 0 || !srf_x3v_supported(Cin, Cout, 4)) return 0;
-  return srf_x3v_packed_bytes(Cout, Cin);
+  if (Cout <= 0 || Cin <= 0 || !srf_x3w_shape_supported(Cin, Cout, 4)) return 0;
+#ifdef SRF_EXPERIMENTS
+  return srf_x3w_packed_bytes(Cout, Cin) + srf_x3t_packed_bytes(Cout, Cin);
+#else
+  return srf_x3w_packed_bytes(Cout, Cin);
+#endif
+}
+static int srf_pack_both(const float* const* w, void* const* packed, const int* Cout, const int* Cin_signed, int n, hipStream_t st) {
+  int rc = srf_x3w_pack_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin_signed, n, st);
+#ifdef SRF_EXPERIMENTS
+  if (rc) return rc;
+  std::vector<char*> second(n);     // (experiment builds: the x3t image of every entry behind its x3w image)
+  for (int i = 0; i < n; ++i)
+    second[i] = reinterpret_cast<char*>(packed[i]) + srf_x3w_packed_bytes(Cout[i], Cin_signed[i] < 0 ? -Cin_signed[i] : Cin_signed[i]);
+  rc = srf_x3t_pack_launch(w, second.data(), Cout, Cin_signed, n, st);
+#endif
+  return rc;
 }
 
-// Whether srf_pw_conv_packed will serve this launch from the packed image alone (the 256 x 128 kernel, whole or chunked over
-// examples) -- then the fp32 weight argument is never read (the backward skips its transposed copy).  Mirrors the dispatch.
+// Whether srf_pw_conv_packed will serve this launch (no prologue: the backward's data-gradient GEMMs) from the packed image
+// alone -- the 256 x 128 kernel on the whole launch -- so that the fp32 weight argument is never read (the backward skips its
+// transposed copy).
 bool srf_pw_packed_only(const void* w_packed, const float* x, int Bt, int Cin, int Cout, int L) {
-  if (!w_packed || srf_kernel_mode() != 0 || (srf_debug_flags() & 4)) return false;
-  if ((Cin % PW_BK) || (L % 4) || Cout < 32 || Cin < 32 || !srf_aligned16(x) || !srf_aligned16(w_packed)) return false;
-  if (srf_pw_small_supported(Cin, Cout, L) || !srf_x3v_supported(Cin, Cout, L)) return false;
-  if ((long)Bt * Cin * L * 4 >= (1L << 31)) return false;      // (the chunked form decides per chunk: keep the copy)
-  return (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus();
+  if (srf_pw_small_supported(Cin, Cout, L)) return false;     // (the thin-shape kernel has precedence and reads the fp32 weights)
+  return srf_pw_256_serves(w_packed, x, Bt, Cin, Cout, L, 0);
 }
 
 // (library-internal: the backward's data-gradient GEMMs) w[i] is the FORWARD weight [Cin][Cout]; the image is that of its
@@ -389,7 +424,7 @@ int srf_pack_pw_weights_transposed(const float* const* w, void* const* packed, c
                   "srf_pack_pw_weights: entry %d unsupported (Cout=%d Cin=%d)", i, Cout[i], Cin[i]);
     neg[i] = -Cin[i];
   }
-  return srf_x3v_pack_launch(w, reinterpret_cast<char* const*>(packed), Cout, neg.data(), n, st);
+  return srf_pack_both(w, packed, Cout, neg.data(), n, st);
 }
 
 extern "C" int srf_pack_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin,
@@ -399,7 +434,7 @@ extern "C" int srf_pack_pw_weights(const float* const* w, void* const* packed, c
     SRF_CHECK_ARG(w[i] && packed[i] && srf_packed_pw_weight_bytes(Cout[i], Cin[i]) > 0 &&
                       srf_aligned16(packed[i]),
                   "srf_pack_pw_weights: entry %d unsupported (Cout=%d Cin=%d)", i, Cout[i], Cin[i]);
-  return srf_x3v_pack_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
+  return srf_pack_both(w, packed, Cout, Cin, n, (hipStream_t)stream);
 }
 
 extern "C" int srf_pw_conv(const float* x, const float* w, const float* bias, float* y, int Bt, int Cin,
@@ -445,15 +480,13 @@ extern "C" int srf_pw_conv_packed(const float* x, const float* w, const void* w_
       srf_aligned16(y) && (!residual || srf_aligned16(residual)))
     return srf_pw_small_launch(a, st);
   // 256 x 128 tiles with pre-split weights: whenever the packed image is there and the launch fills the chip (fewer tiles
-  // than CUs: the 128 x 128 kernels below make twice as many)
-  if (mfma_ok && mode == 0 && w_packed && srf_x3v_supported(Cin, Cout, L) && srf_aligned16(w_packed) &&
-      (long)Bt * Cin * L * 4 < (1L << 31) && !(srf_debug_flags() & 4) &&
-      (long)Bt * ((Cout + 255) / 256) * ((L + 127) / 128) >= srf_device_cus())
+  // than CUs: the 128 x 128 kernels below make twice as many).  (That kernel never reads the fp32 weights.)
+  if (srf_pw_256_serves(w_packed, x, Bt, Cin, Cout, L, pro_sel))
     return srf_pw_256_launch(a, reinterpret_cast<const char*>(w_packed), pro_sel, st);
   // An activation tensor beyond the 2 GB reach of the kernel's 32-bit buffer offsets (cfg 5's bottleneck: 16 x 4096 x 12800
   // floats = 3.4 GB) goes out as several launches over runs of whole examples: examples are independent, every per-example
   // pointer (statistics slots included) just moves along.
-  if (mfma_ok && mode == 0 && w_packed && srf_x3v_supported(Cin, Cout, L) && srf_aligned16(w_packed) &&
+  if (mfma_ok && mode == 0 && w_packed && srf_x3w_shape_supported(Cin, Cout, L) && srf_x3w_supported(Bt, pro_sel) && srf_aligned16(w_packed) &&
       (long)Bt * Cin * L * 4 >= (1L << 31) && (long)Cin * L * 4 < (1L << 31) && !(srf_debug_flags() & 4)) {
     const int cap = (int)(((1L << 31) - 1) / ((long)Cin * L * 4));   // examples one launch can address
     const int nch = (Bt + cap - 1) / cap, per = (Bt + nch - 1) / nch;  // balanced runs of whole examples

@@ -1,7 +1,13 @@
-// K2 (round-3 fast path) -- the 256 x 128 split-precision MFMA GEMM of srf_pwconv_x3v.hip with its memory pipeline repaired.
+// K2 (fast path) -- the 256 x 128 split-precision MFMA GEMM with pre-split weights (round 2's kernel, git tag r3-gemm-x3v-kernel,
+// with its memory pipeline repaired in round 3).
 //
-// Same arithmetic, same tiles, same packed weight image, same LDS layout, same work distribution as srf_pwconv_x3v.hip (x = hi + lo
-// in bf16, three v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate, bit-identical results; reference sites
+// Block tile 256 (M) x 128 (time) x 32 (K): for Cout = 256 one block owns all of M, so an activation tile goes through GlobLN /
+// PReLU / split exactly once; the weights are split into bf16 hi | lo ONCE per forward (srf_x3w_pack_kernel) and stored tile by
+// tile as the exact, XOR-swizzled LDS image of a stage (64-byte rows of 32 bf16, 16-byte chunks swizzled by (row >> 2) & 3:
+// conflict-free ds_read_b128 fragments), so the A operand is a global_load_lds_dwordx4 DMA; 3 LDS stages of 48 KB (A_hi | A_lo |
+// B_hi | B_lo), one 512-thread block per CU, ONE barrier per k-tile; persistent blocks, operand pipeline running across tile
+// boundaries; the leftover tiles of the last round cut into quarter tiles (256 x 32) dealt to all blocks.  (x = hi + lo
+// in bf16, three v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate; reference sites
 // improved_sudormrf.py:256-259, :174, :196, :220, :268-269, :295-298).  What changed, and why (round-3 reading of the round-2
 // kernel's device assembly, tools/isa_waits.py -- VERDICT r2 weak 3: res_conv 0.40 / proj_1x1 0.32 of the HBM ceiling, "issue
 // bound"; the round-2 ablation had shown the k-loop + epilogue costing far more together than apart):
@@ -40,10 +46,10 @@ constexpr int W_A_IMG = W_BM * 64;                       // [256][32] bf16, 64-B
 constexpr int W_B_IMG = W_BN * 64;                       // [128][32] bf16
 constexpr int W_STAGE = 2 * W_A_IMG + 2 * W_B_IMG;       // A_hi | A_lo | B_hi | B_lo = 48 KB
 constexpr int W_NSTAGE = 3;
-constexpr int W_WTILE_BYTES = 2 * W_A_IMG;               // packed weights of one (m-tile, k-tile) (srf_x3v_pack_kernel's format)
+constexpr int W_WTILE_BYTES = 2 * W_A_IMG;               // packed weights of one (m-tile, k-tile) (srf_x3w_pack_kernel's format)
 constexpr int W_MAX_STAT_EXAMPLES = 1024;                // LDS statistics table: 8 KB behind the stages
 
-__device__ __forceinline__ int w_swz(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
+__host__ __device__ __forceinline__ int w_swz(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
 
 __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -64,7 +70,7 @@ __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8
 // ABL (diagnostics, results are wrong when != 0): 1 = no activation loads, 2 = no weight DMA, 4 = no MFMAs, 8 = no GlobLN / PReLU /
 // split / ds_write, 16 = no epilogue, 32 = no fragment reads.
 // gamma / beta come again as noalias kernel arguments so that they are fetched with scalar loads.
-// Work distribution, barrier protocol and LDS images: see srf_pwconv_x3v.hip (unchanged).
+// Work distribution, barrier protocol and LDS images: as in round 2's kernel (file header).
 // CP: cache policy of the streamed tensors (see the launch function).
 // NP: 2 = two bf16 parts per operand (hi | lo, three MFMAs per product block: the inference GEMM); 3 = THREE parts (h | m | l =
 //     24 mantissa bits, the exact-fp32 class) and six MFMAs -- l*h, h*l, m*m, m*h, h*m, h*h -- for the training forward
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   }
 
   // Tile order: virtual id v = mi + G (lt + nLt (b + Bt grp)), m-tile = grp G + mi.  G = nMt (one group; the default) is the
-  // order of srf_pwconv_x3v.hip: the nMt blocks that share one activation tile are neighbours on one XCD.  G < nMt (host: when
+  // order of round 2's kernel: the nMt blocks that share one activation tile are neighbours on one XCD.  G < nMt (host: when
   // the packed weights exceed what an XCD's 4-MB L2 can keep -- the mask GEMMs of cfg 4 / cfg 5, 8 / 16 MB) gives every XCD a
   // GROUP of G m-tiles whose weight slabs stay L2-resident while it walks the (example, time) tiles; all XCDs walk those in the
   // same order at the same pace, so the activation tile one of them fetched from HBM is a MALL hit for the others.  Before:
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       return;
     }
     constexpr int NT = decltype(full_tag)::value ? 2 : 1;
-    // pass-major order: independent accumulators between two MFMAs on the same one (and the summation order of x3v)
+    // pass-major order: independent accumulators between two MFMAs on the same one (and the summation order of every split-bf16 kernel of the library)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
 
   // One pipeline step = k-tile kt of the current tile (in stage s0): split k-tile kt+1 into stage s1, start the DMA of k-tile kt+2
   // into stage s2 and the activation loads of k-tile kt+3, multiply k-tile kt.  k-tile indices >= nk belong to the NEXT tile.
-  // Barrier protocol: as in srf_pwconv_x3v.hip (one barrier per step; before it every wavefront's ds_writes of k-tile kt+1 are
+  // Barrier protocol (one barrier per step; before it every wavefront's ds_writes of k-tile kt+1 are
   // done and its DMA pieces of k-tile kt+1 -- issued a step ago, >= 20 memory operations ago -- have landed).
   // Fragment schedule.  HAVE0: the first half's fragments (f0) were requested by the previous step, behind ITS barrier, i.e.
   // under the previous k-tile's last 12 MFMAs.  PREF: this step does the same for the next k-tile (stage s1 is complete for
@@ -902,6 +908,64 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
 
 bool srf_x3w_supported(int Bt, int pro) { return !(pro == 1 || pro == 2) || Bt <= W_MAX_STAT_EXAMPLES; }
 
+// ---- weight packing: W[Cout][Cin] fp32 -> per (m-tile, k-tile) [hi image | lo image], rows >= Cout zero ----------------------
+bool srf_x3w_shape_supported(int Cin, int Cout, int L) {
+  return (Cin % 64 == 0) && Cin >= 128 && (L % 4 == 0) && Cout >= 192 && (long)Cout * Cin * 4 < (1L << 31);
+}
+size_t srf_x3w_packed_bytes(int Cout, int Cin) {
+  const size_t nMt = (Cout + W_BM - 1) / W_BM, nKt = Cin / W_BK;
+  return nMt * nKt * (size_t)W_WTILE_BYTES;
+}
+constexpr int SRF_W_MAX_PACK = 96;
+struct WPackEntry {
+  const float* w;
+  char* dst;
+  int Cout, Cin;   // Cin < 0: w is stored TRANSPOSED ([|Cin|][Cout]) -- the backward's data-gradient GEMMs use W^T
+};
+struct WPackTable {
+  WPackEntry e[SRF_W_MAX_PACK];
+};
+__global__ __launch_bounds__(256) void srf_x3w_pack_kernel(WPackTable t) {
+  WPackEntry e = t.e[blockIdx.y];
+  const bool trans = e.Cin < 0;
+  e.Cin = trans ? -e.Cin : e.Cin;
+  const int nKt = e.Cin / W_BK;
+  const int nMt = (e.Cout + W_BM - 1) / W_BM;
+  const long total = (long)nMt * nKt * W_BM * 4;   // one thread per 8-k packet
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int c = (int)(id & 3);
+    const int row = (int)((id >> 2) % W_BM);
+    const long tile = (id >> 2) / W_BM;
+    const int kt = (int)(tile % nKt), mt = (int)(tile / nKt);
+    const int m = mt * W_BM + row;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kt * W_BK + c * 8 + j;
+      const float v = (m < e.Cout) ? (trans ? e.w[(size_t)k * e.Cout + m] : e.w[(size_t)m * e.Cin + k]) : 0.f;
+      const __bf16 h = (__bf16)v;
+      hi[j] = h;
+      lo[j] = (__bf16)(v - (float)h);
+    }
+    char* base = e.dst + (size_t)tile * W_WTILE_BYTES + w_swz(row, c);
+    *reinterpret_cast<bf16x8*>(base) = hi;
+    *reinterpret_cast<bf16x8*>(base + W_A_IMG) = lo;
+  }
+}
+int srf_x3w_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {
+  for (int base = 0; base < n; base += SRF_W_MAX_PACK) {
+    WPackTable t;
+    const int cnt = (n - base) < SRF_W_MAX_PACK ? (n - base) : SRF_W_MAX_PACK;
+    for (int i = 0; i < SRF_W_MAX_PACK; ++i) {
+      const int j = base + (i < cnt ? i : 0);
+      t.e[i] = WPackEntry{w[j], dst[j], Cout[j], Cin[j]};
+    }
+    hipLaunchKernelGGL(srf_x3w_pack_kernel, dim3(64, cnt), dim3(256), 0, st, t);
+    SRF_CHECK_LAUNCH("pack_pw_weights", st);
+  }
+  return SRF_OK;
+}
+
 // fuse_wd != null: the mask epilogue fused with the decoder's contraction (EPI 4; pro 3, mask epilogue, fuse_M <= 64)
 static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, const char* fuse_wd, float* fuse_z, int fuse_M,
                                  hipStream_t st, int np = 2);
@@ -947,7 +1011,7 @@ int srf_x3w_pack_dec_launch(const float* w, void* dst, int Ci, int M, hipStream_
   return SRF_OK;
 }
 
-// ---- three-part weights (NP 3): per (m-tile, 16-k tile) the stage image of srf_x3v_pack_kernel -- [256 rows][32 slots] bf16,
+// ---- three-part weights (NP 3): per (m-tile, 16-k tile) the stage image of srf_x3w_pack_kernel -- [256 rows][32 slots] bf16,
 // XOR-swizzled 16-byte chunks, "hi" image then "lo" image -- with h | m of the tile's 16 k in the hi image (chunks 0-1 | 2-3)
 // and l in chunks 0-1 of the lo image (chunks 2-3: zero, never read).  w = h + m + l to 24 bits.
 struct W3PackEntry {
@@ -1046,7 +1110,8 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
         // any other prologue / epilogue combination (unit tests, stand-alone srf_pw_conv callers)
         (const void*)&srf_pw_x3w_kernel<0, 3>, (const void*)&srf_pw_x3w_kernel<1, 3>,
         (const void*)&srf_pw_x3w_kernel<2, 3>, (const void*)&srf_pw_x3w_kernel<3, 3>,
-        // diagnostics: ablated pipelines and the in-kernel timeline (proj_1x1 and res_conv forms)
+#ifdef SRF_EXPERIMENTS
+        // diagnostics (SRF_BUILD_EXPERIMENTS=1 builds only): ablated pipelines and the in-kernel timeline (proj_1x1 / res_conv forms)
         (const void*)&srf_pw_x3w_kernel<0, 0, 3>, (const void*)&srf_pw_x3w_kernel<0, 0, 4>,
         (const void*)&srf_pw_x3w_kernel<0, 0, 7>, (const void*)&srf_pw_x3w_kernel<0, 0, 12>,
         (const void*)&srf_pw_x3w_kernel<0, 0, 16>, (const void*)&srf_pw_x3w_kernel<0, 0, 19>,
@@ -1060,7 +1125,9 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
         (const void*)&srf_pw_x3w_kernel<2, 1, 64>,
         (const void*)&srf_pw_x3w_kernel<0, 0, 256>, (const void*)&srf_pw_x3w_kernel<0, 0, 512>,
         (const void*)&srf_pw_x3w_kernel<0, 0, 768>, (const void*)&srf_pw_x3w_kernel<2, 1, 256>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 512>, (const void*)&srf_pw_x3w_kernel<2, 1, 768>};
+        (const void*)&srf_pw_x3w_kernel<2, 1, 512>, (const void*)&srf_pw_x3w_kernel<2, 1, 768>,
+#endif
+        (const void*)&srf_pw_x3w_kernel<0, 1, 0, 0>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
@@ -1089,6 +1156,7 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
   ap.epi_mask |= ((srf_debug_flags() >> 22) & 3) << 8;      // diagnostics: start-up stagger units (flag bits 22-23)
   const bool res = a.residual != nullptr, mask = !res && (a.epi_mask & 1);
 #define W_GO(P, E, A, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
+#ifdef SRF_EXPERIMENTS
   // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated above),
   // 1 << 25 = in-kernel timeline (tools/gemm_timeline.py), 1 << 30 = epilogue without its stores
   const int env_abl = getenv("SRF_X3W_ABL") ? atoi(getenv("SRF_X3W_ABL")) : 0;     // round-4 experiments: ABL bits 256 / 512
@@ -1134,6 +1202,7 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
     SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
     return SRF_OK;
   }
+#endif
   // Cache policy (CP) of the four model forms: bit 0 = non-temporal output stores, bit 2 = non-temporal activation loads,
   // bit 3 = non-temporal residual / mask-multiplier loads.  Every CU re-reads the whole packed weight image from L2 for every
   // tile, while activations, residuals and outputs stream through once: marked non-temporal they stop displacing the weights.
@@ -1177,8 +1246,7 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
 #undef W_CP5
 #undef W_CP4
 #undef W_GO
-  // (profiler family names stay those of round 2: the tests and bench.py's launch model key on them)
-  static const char* const kLabel[4] = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_conv_x3v<3>"};
+  static const char* const kLabel[4] = {"pw_conv_x3w<0>", "pw_conv_x3w<1>", "pw_conv_x3w<2>", "pw_conv_x3w<3>"};
   SRF_CHECK_LAUNCH(kLabel[pro < 0 || pro > 3 ? 3 : pro], st);
   return SRF_OK;
 }

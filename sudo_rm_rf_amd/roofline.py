@@ -66,7 +66,7 @@ def pyramid_tiled(L, D):
 
 
 def _packable(cin, cout):
-    """Mirror of srf_x3v_supported(): 1x1 convs whose weights srf_forward pre-splits (srf_pwconv_x3v.hip)."""
+    """Mirror of srf_x3w_shape_supported(): 1x1 convs whose weights srf_forward pre-splits (srf_pwconv_x3w.hip)."""
     return cin % 64 == 0 and cin >= 128 and cout >= 192
 
 

@@ -104,9 +104,9 @@ def test_unfused_pyramid_agrees(manifest, name):
 
 
 # (case, bench batch, kernel families the single-stream forward MUST have been dispatched to)
-_X3V = {"pw_conv_x3v<0>", "pw_conv_x3v<1>", "pw_conv_x3v<2>", "pw_mask_decode"}
-_BENCH_BATCH = [("cfg2_improved_u16", 32, _X3V), ("cfg3_groupcomm_u8", 32, {"pw_conv_x3v<1>", "pw_mask_decode", "pw_conv_small"}),
-                ("cfg4_improved_u36_n2048", 32, _X3V), ("cfg5_improved_u36_n4096", 16, _X3V)]
+_X3W = {"pw_conv_x3w<0>", "pw_conv_x3w<1>", "pw_conv_x3w<2>", "pw_mask_decode"}
+_BENCH_BATCH = [("cfg2_improved_u16", 32, _X3W), ("cfg3_groupcomm_u8", 32, {"pw_conv_x3w<1>", "pw_mask_decode", "pw_conv_small"}),
+                ("cfg4_improved_u36_n2048", 32, _X3W), ("cfg5_improved_u36_n4096", 16, _X3W)]
 
 
 @pytest.mark.parametrize("case,batch,families", _BENCH_BATCH, ids=[c for c, _, _ in _BENCH_BATCH])
@@ -144,14 +144,14 @@ def test_bench_batch_examples_match_reference_golden(manifest, case, batch, fami
         count = {n: sum(1 for k, _ in tr.launches if k == n) for n in tr.names}
         U = cfg.num_blocks
         if cfg.variant == "improved":     # bottleneck, U x proj_1x1, U x res_conv, mask + decoder -- ALL on the 256 x 128 kernel
-            assert (count["pw_conv_x3v<1>"], count["pw_conv_x3v<0>"], count["pw_conv_x3v<2>"], count["pw_mask_decode"]) == \
+            assert (count["pw_conv_x3w<1>"], count["pw_conv_x3w<0>"], count["pw_conv_x3w<2>"], count["pw_mask_decode"]) == \
                 (1, U, U, 1), count
         else:                             # GroupComm: bottleneck + mask on it, the per-group convs on the thin-shape kernel
-            assert (count["pw_conv_x3v<1>"], count["pw_mask_decode"], count["pw_conv_small"]) == (1, 1, 2 * U), count
+            assert (count["pw_conv_x3w<1>"], count["pw_mask_decode"], count["pw_conv_small"]) == (1, 1, 2 * U), count
         # (the fused tail contracts the masked values with the decoder inside the mask GEMM: no GEMM is left on the 128 x 128
         # kernels and the masked tensor is never stored)
         assert sum(v for k, v in count.items() if k.startswith("pw_conv_bf16x3") or k == "pw_conv_mfma") == 0, count
-        assert "pw_conv_x3v<3>" not in count and "transpose" not in count, count
+        assert "pw_conv_x3w<3>" not in count and "transpose" not in count, count
         eng.multi_stream = True
         for parts in eng._split_candidates(batch)[1:]:        # the explicit splits: halves and 5 : 3
             out = torch.empty_like(out)
@@ -195,7 +195,7 @@ def test_fused_tail_agrees_with_materialised_masked_tensor(manifest, case, batch
         assert torch.equal(fused, again)
         ops.set_debug_flags(32768)
         plain, names = run()
-        assert "pw_mask_decode" not in names and "pw_conv_x3v<3>" in names, sorted(names)
+        assert "pw_mask_decode" not in names and "pw_conv_x3w<3>" in names, sorted(names)
     finally:
         ops.set_debug_flags(0)
         eng.multi_stream = True

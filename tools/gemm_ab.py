@@ -2,7 +2,7 @@
 """Same-process interleaved A/B of the 256 x 128 split-bf16 GEMM variants on the model's launch shapes (cfg 2, cfg 4, cfg 5):
 rounds of N launches per variant, variants interleaved, median / min us per launch, outputs compared bit for bit.
 
-    python tools/gemm_ab.py [name=debug_flags[:abl[:gemm]] ...]    default: x3w=0 x3v=16384   (abl: SRF_X3W_ABL, diagnostics builds only)
+    python tools/gemm_ab.py [name=debug_flags[:abl[:gemm]] ...]    default: x3w=0 x3t=0:0:x3t   (abl / gemm: lab builds only -- SRF_BUILD_EXPERIMENTS=1, SRF_LIB=.../libsudormrf_hip_lab.so)
     GEMM_SHAPES=res_conv,proj_1x1 GEMM_ROUNDS=7 GEMM_ITERS=20"""
 import json
 import os
@@ -29,7 +29,7 @@ SHAPES = {  # name: (Bt, Cin, Cout, L, prologue, epilogue)
 
 
 def main():
-    variants = [a.split("=") for a in sys.argv[1:]] or [["x3w", "0"], ["x3v", "16384"]]
+    variants = [a.split("=") for a in sys.argv[1:]] or [["x3w", "0"], ["x3t", "0:0:x3t"]]
     variants = [(n, f if ":" in f else f + ":0") for n, f in variants]
 
     class _Flags:   # debug flags + the SRF_X3W_ABL environment switch of the experimental instantiations

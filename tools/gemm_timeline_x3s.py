@@ -12,7 +12,8 @@ from sudo_rm_rf_amd import _lib, ops  # noqa: E402
 
 DEV = "cuda:0"
 SHAPES = {"proj_1x1": (32, 256, 512, 3200, 0, False), "res_conv": (32, 512, 256, 3200, 2, True)}
-os.environ["SRF_GEMM"] = "x3s"
+GEMM = os.environ.get("TL_GEMM", "x3s")
+os.environ["SRF_GEMM"] = GEMM
 lib = _lib.load()
 for name, (Bt, Cin, Cout, L, pro, res) in SHAPES.items():
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -52,7 +53,9 @@ for name, (Bt, Cin, Cout, L, pro, res) in SHAPES.items():
         us[tl] = e0.elapsed_time(e1) * 100
     t = trace.cpu().numpy().view(np.uint32).reshape(256, 12, 8).astype(np.float64)
     print("== %s: %.1f us plain, %.1f us instrumented" % (name, us["0"], us["1"]))
-    for role, sl in (("multiply", slice(0, 8)), ("stage X ", slice(8, 10)), ("DMA     ", slice(10, 12))):
+    roles = ((("multiply", [0, 1, 2, 3, 4, 5, 6, 7]), ("stage X ", [8, 9]), ("DMA     ", [10, 11])) if GEMM == "x3s" else
+             (("multiply", [0, 1, 2, 4, 5, 6]), ("loaders ", [3, 7])))
+    for role, sl in roles:
         r = t[:, sl, :].reshape(-1, 8)
         tot = r[:, 0].mean()
         print("  %s total %8.0f ticks | barrier %5.1f %% | wait %5.1f %% | epilogue %5.1f %% | other %5.1f %% | barriers %4.0f | ticks/us %.0f"

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(768) void split_probe(const char* __restrict__ smal
     for (int i = 0; i < 16; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[i][e] = (__bf16)(0.001f * (lane + i + e));
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    while ((WORK & 4) ? steps < 2000 : __builtin_amdgcn_s_memrealtime() - t0 < ticks) {
       const int stage = (int)(steps % 3) * 49152;
       if constexpr (WORK & 1) {
 #pragma unroll
@@ -225,7 +225,14 @@ __global__ __launch_bounds__(768) void split_probe(const char* __restrict__ smal
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(f[i]));
       }
+      if constexpr (WORK & 4) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       ++steps;
+    }
+    if (WORK & 4) {
+      if (lane == 0 && wave == 0) counts[3] = __builtin_amdgcn_s_memrealtime() - t0;
     }
     float t = 0.f;
 #pragma unroll
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(768) void split_probe(const char* __restrict__ smal
   size_t ao = 0, xo = 0;
   if (one_simd) {
     if (wave > 7) return;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    while ((WORK & 4) ? steps < 2000 : __builtin_amdgcn_s_memrealtime() - t0 < ticks) {
       const unsigned stage = (unsigned)(steps % 3) * 49152u;
       if (wave == 3) {
 #pragma unroll
@@ -258,6 +265,7 @@ __global__ __launch_bounds__(768) void split_probe(const char* __restrict__ smal
         for (int i = 0; i < 16; ++i) dma(xs + xo + i * 1024, lds0 + stage + 32768 + i * 1024);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       }
+      if constexpr (WORK & 4) __builtin_amdgcn_s_barrier();
       ao += 32768;
       if (ao + 32768 > small_bytes) ao = 0;
       xo += 16384;
@@ -296,6 +304,21 @@ void run_split(const char* name, const char* small_buf, size_t small_bytes, cons
   unsigned long long* counts;
   CHECK(hipMalloc(&counts, 32));
   const unsigned ticks = 200000;      // 2 ms
+  if (WORK & 4) {
+    CHECK(hipFuncSetAttribute((const void*)&split_probe<WORK, LOAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152));
+    for (int rep = 0; rep < 2; ++rep) {
+      CHECK(hipMemset(counts, 0, 32));
+      hipLaunchKernelGGL((split_probe<WORK, LOAD>), dim3(ncu), dim3(512), 3 * 49152, 0, small_buf, small_bytes, big, slice, ticks, counts, sink);
+      CHECK(hipDeviceSynchronize());
+    }
+    unsigned long long h[4];
+    CHECK(hipMemcpy(h, counts, 32, hipMemcpyDeviceToHost));
+    const double us = h[3] / 100.0;
+    printf("%-58s 2000 steps with a block barrier each: %.3f us per step (block 0); 48 MFMAs per SIMD and step = %.0f %% of the pipe at 2.4 GHz\n",
+           name, us / 2000, 100.0 * 48 * 32 / 2400.0 / (us / 2000));
+    CHECK(hipFree(counts));
+    return;
+  }
   CHECK(hipFuncSetAttribute((const void*)&split_probe<WORK, LOAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152));
   for (int rep = 0; rep < 2; ++rep) {
     CHECK(hipMemset(counts, 0, 32));
@@ -389,6 +412,8 @@ int main(int argc, char** argv) {
   run_split<1, 1>("split: loaders + multipliers (reads only)", small_buf, small_bytes, big, slice, ncu, (float*)sink);
   run_split<3, 4>("ONE SIMD for the 2 loaders, 6 multipliers (reads + MFMAs)", small_buf, small_bytes, big, slice, ncu, (float*)sink);
   run_split<2, 4>("ONE SIMD for the 2 loaders, 6 multipliers (MFMAs only)", small_buf, small_bytes, big, slice, ncu, (float*)sink);
+  run_split<7, 4>("ONE SIMD for the 2 loaders, 6 multipliers, BARRIER per step", small_buf, small_bytes, big, slice, ncu, (float*)sink);
+  run_split<6, 4>("same, multipliers without the LDS reads", small_buf, small_bytes, big, slice, ncu, (float*)sink);
   run_split<3, 5>("ONE SIMD for the 2 loaders, 9 multipliers (reads + MFMAs)", small_buf, small_bytes, big, slice, ncu, (float*)sink);
   run_split<3, 2>("split: loaders at s_setprio 3 + multipliers (reads + MFMAs)", small_buf, small_bytes, big, slice, ncu, (float*)sink);
   run_split<2, 2>("split: loaders at s_setprio 3 + multipliers (MFMAs only)", small_buf, small_bytes, big, slice, ncu, (float*)sink);
