@@ -110,14 +110,35 @@ def flat_gradient_view(params):
         grads[0].untyped_storage(), grads[0].storage_offset(), (total,), (1,))
 
 
+def clamp_global_mean(local_loss, min=-30.0, max=30.0):
+    """The reference runner clamps the BATCH-mean loss (run_improved_sudormrf.py:169-171: `torch.clamp(l, min=-30., max=+30.)` on
+    the mean over the whole DataParallel batch, losses/sisdr.py:307).  Under batch sharding every rank only has its shard's mean
+    l_r; clamping that (what round 3 did) differs from the reference whenever one shard saturates and the batch mean does not (or
+    the other way round): the clamp gates the gradient of a whole shard.  This is the exact form: one all-reduce of the SCALAR
+    loss gives L = mean_r l_r (equal shards); the returned tensor has the value clamp(L) and the gradient
+    d/d l_r = [min <= L <= max] (torch.clamp's own mask, inclusive) -- so after `allreduce_gradients` (sum over ranks / world) every
+    rank holds exactly the gradient of clamp(mean of the full batch), saturated or not.  The gate stays on the device: no host
+    synchronisation.  World size 1: identical to torch.clamp(local_loss, min, max)."""
+    _, ws, _ = world()
+    if not (dist.is_initialized() and ws > 1):
+        return torch.clamp(local_loss, min=min, max=max)
+    with torch.no_grad():
+        g = local_loss.detach().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        g = g / ws
+        gate = ((g >= min) & (g <= max)).to(local_loss.dtype)
+        value = torch.clamp(g, min=min, max=max)
+    return local_loss * gate + (value - local_loss.detach() * gate)
+
+
 def allreduce_gradients(parameters, average=True):
     """The training step's only collective: ONE all-reduce of the flat fp32 gradient over
     RCCL / xGMI after backward, then 1/world scaling -- what replaces the reference's DataParallel gather of
     replica gradients onto GPU 0 (run_improved_sudormrf.py:118).  Every rank then runs the identical
     clip_grad_norm_ + Adam step on identical gradients, so the replicas stay bit-identical without a broadcast.
     With equal shard sizes the averaged gradient equals the gradient of the reference's batch-mean loss
-    (losses/sisdr.py:307); the +-30 clamp of the runner acts on each shard's mean here (it only gates the gradient
-    when the loss is saturated).
+    (losses/sisdr.py:307); for the runner's +-30 clamp of that batch mean use `clamp_global_mean` on the shard loss (a plain
+    torch.clamp there would gate each shard by its own mean: different from the reference when a shard saturates).
 
     IN PLACE when the gradients already are views of one flat buffer (the HIP training step's are): one collective on
     that buffer, one scaling kernel, no concatenation and no copy back (round 2 did `torch.cat` + ~1 230 `copy_`

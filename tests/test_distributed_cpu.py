@@ -168,6 +168,75 @@ def test_two_rank_gloo_training_glue(tmp_path):
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
 
 
+def _clamp_worker(rank, world, port, q):
+    """Exact batch-mean clamp under sharding: rank 0's shard loss saturates (> +30), the batch mean does not
+    (and a second case the other way round): the sharded step must reproduce the single-process gradient of
+    clamp(mean over the full batch) -- a per-shard clamp would drop (or keep) a whole shard's gradient."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sudo_rm_rf_amd import distributed as D
+    torch.set_num_threads(1)
+    D.init_from_env(backend="gloo")
+    out = []
+    # per-example "losses" = w . x_b; batch of 4, two per rank.  case A: shard means (+50, -20) -> batch mean +15 (inside);
+    # case B: shard means (+50, +40) -> batch mean +45 (saturated: zero gradient everywhere); case C: (-10, +20): nothing clamps
+    for shard_means in ((50.0, -20.0), (50.0, 40.0), (-10.0, 20.0)):
+        w = torch.nn.Parameter(torch.tensor([1.0, 2.0, -1.0], dtype=torch.float64))
+        base = torch.tensor([[1.0, 0.5, 0.25], [0.5, 1.0, 2.0], [2.0, -1.0, 0.5], [-0.5, 0.25, 1.0]], dtype=torch.float64)
+        x = base.clone()
+        for r in range(world):            # scale every shard so that its mean loss is the prescribed value
+            cur = (x[2 * r:2 * r + 2] @ w.detach()).mean()
+            x[2 * r:2 * r + 2] *= shard_means[r] / cur
+        # reference: one process, the whole batch
+        wf = torch.nn.Parameter(w.detach().clone())
+        lf = torch.clamp((x @ wf).mean(), min=-30.0, max=30.0)
+        lf.backward()
+        # sharded
+        ll = (x[2 * rank:2 * rank + 2] @ w).mean()
+        l = D.clamp_global_mean(ll, min=-30.0, max=30.0)
+        l.backward()
+        D.allreduce_gradients([w])
+        # what a per-shard clamp would have produced (must differ in case A)
+        wp = torch.nn.Parameter(w.detach().clone())
+        torch.clamp((x[2 * rank:2 * rank + 2] @ wp).mean(), min=-30.0, max=30.0).backward()
+        D.allreduce_gradients([wp])
+        out.append((float(l), float(lf), (w.grad - wf.grad).abs().max().item(), (wp.grad - wf.grad).abs().max().item()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_exact_batch_mean_clamp():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_clamp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, out in res:
+        (la, lfa, ea, pa), (lb, lfb, eb, pb), (lc, lfc, ec, pc) = out
+        assert la == pytest.approx(15.0) and lfa == pytest.approx(15.0) and ea < 1e-12      # inside: exact ...
+        assert pa > 1e-3                                                                    # ... where a per-shard clamp is not
+        assert lb == pytest.approx(30.0) and lfb == pytest.approx(30.0) and eb < 1e-12      # saturated batch mean: zero gradient
+        assert lc == pytest.approx(5.0) and ec < 1e-12 and pc < 1e-12                       # nothing clamps: all three agree
+
+
+def test_clamp_global_mean_single_process_is_torch_clamp():
+    from sudo_rm_rf_amd import distributed as D
+    for v in (-40.0, 3.0, 31.0):
+        a = torch.tensor(v, requires_grad=True)
+        b = torch.tensor(v, requires_grad=True)
+        D.clamp_global_mean(a).backward()
+        torch.clamp(b, min=-30.0, max=30.0).backward()
+        assert float(D.clamp_global_mean(a).detach()) == float(torch.clamp(b, min=-30.0, max=30.0).detach()) and float(a.grad) == float(b.grad)
+
+
 def test_shard_slice_rejects_uneven():
     from sudo_rm_rf_amd.distributed import shard_slice
     with pytest.raises(ValueError):
