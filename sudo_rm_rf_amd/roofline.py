@@ -136,3 +136,105 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, p
     out.append(pw(SA * N, SA * K, Bt))
     out.append(("overlap_add", f * Bt * (SA * K * L + SA * T), 3.0 * Bt * SA * T))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Training step (forward with saved activations, PIT-SI-SDR, backward, clip, Adam): run_improved_sudormrf.py:146-177
+# ---------------------------------------------------------------------------------------------------------------------------
+def n_params(variant, B, C, U, D, K, N, S, G=1, A=1):
+    """Parameter count of the model (Appendix A of SURVEY.md; checked against the README's #Params there)."""
+    SA = S * A
+    if variant == "groupcomm":
+        n, h, c = B // G, 3 * B // G, C // G
+        tac = (h * n + h + 1) + (h * h + h + 1) + (n * 2 * h + n + 1) + 2 * n
+        ub = (c * n + c) + 2 * c + 1 + D * (5 * c + c + 2 * c) + 2 * c + 1 + (n * c + n)
+        blk = tac + ub
+    else:
+        blk = (C * B + C) + 2 * C + 1 + D * (5 * C + C + 2 * C) + 2 * C + 1 + (B * C + B)
+    return N * A * K + 2 * N + (B * N + B) + U * blk + 1 + (SA * N * B + SA * N) + SA * N * SA * K
+
+
+def train_bytes_per_example(variant, B, C, U, D, K, N, S, T, G=1):
+    """Fusion-minimal HBM bytes of one TRAINING step per example, on the rules of SURVEY.md 8(d) extended to the backward
+    (DESIGN.md 6c): every tensor the forward materialises at a GlobLN barrier is read once more by the backward (the local
+    derivative needs the activation), and every forward pass over a tensor has a mirror pass over its gradient.  So
+        step = 2 x forward + (one extra read of each materialised activation) + what the training forward must keep that the
+               inference forward fuses away (the mask pre-activation [S N, L]: written, read by its ReLU' and by the enc gradient),
+    weights / optimizer state ignored as in 8(d) (<= 0.4 GB per step against >= 80 GB of activations at cfg 4)."""
+    L = frames(T, K, D)
+    fwd = bytes_per_example(variant, B, C, U, D, K, N, S, T, G)
+    xre = 2 if variant == "groupcomm" else 1            # block input (GroupComm: x and u)
+    reread = 4.0 * (N * L + U * (xre * B * L + (4 - 2.0 ** (1 - D)) * C * L) + B * L)
+    mask = 4.0 * (3 * S * N * L)
+    return 2.0 * fwd + reread + mask
+
+
+def train_flops_per_example(variant, B, C, U, D, K, N, S, T, G=1):
+    """Forward + data gradient + weight gradient of every contraction (~3 x the forward's FLOPs)."""
+    return 3.0 * flops_per_example(variant, B, C, U, D, K, N, S, T, G)
+
+
+def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
+    """{profiler family: (algorithmic bytes per step, FLOPs per step)} of srf_forward_train + the loss + srf_backward + the
+    optimizer for the IMPROVED model (csrc/srf_train.hip is the launch sequence this mirrors; launches per step come from the
+    in-library profiler, so per-launch figures = these totals / the launches counted).  Bytes = tensors a kernel family must read
+    + write once per launch, fp32, weights ignored.  GroupComm: None (its thin-shape / TAC families are not modelled)."""
+    if variant != "improved":
+        return None
+    L = frames(T, K, D)
+    f = 4.0 * Bt
+    SN, SK = S * A * N, S * A * K
+    P = n_params(variant, B, C, U, D, K, N, S, G, A)
+    lv = [L >> k for k in range(D)]
+    lev_sum = sum(lv)                                  # C-rows of all pre-norm levels: L (2 - 2^(1-D))
+    fam = {}
+
+    def add(name, nbytes, flops=0.0):
+        b0, f0 = fam.get(name, (0.0, 0.0))
+        fam[name] = (b0 + nbytes, f0 + flops)
+
+    # ---- forward (training): GEMMs on the three-part split kernel, fused pyramid with saved levels, un-fused tail
+    add("encoder", f * (A * T + N * L), 2.0 * Bt * N * A * K * L)
+    add("pw_conv_x3w3<1>", f * L * (N + B), 2.0 * Bt * N * B * L)
+    add("pw_conv_x3w3<0>", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)
+    dw = 2.0 * 5 * Bt * C * lev_sum
+    add("pyramid_moments", U * f * C * L, U * dw)
+    add("pyramid_finalize", U * 8.0 * Bt * C * D * 5)
+    add("pyramid_merge_save", U * f * C * (2 * L + lev_sum), U * (dw + 2.0 * D * Bt * C * L))     # pass 2 + the levels on the side
+    add("pw_conv_x3w3<2>", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L)
+    add("pw_conv_x3w3<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
+    add("mask_apply", f * L * (2 * SN + N), 2.0 * Bt * SN * L)
+    # decoder (stand-alone form): weight transpose, frame GEMM S N -> S K, overlap-add
+    add("pw_conv_x3w<0>", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)
+    add("overlap_add", f * (SK * L + S * A * T), 3.0 * Bt * S * A * T)
+    # ---- loss: one streaming pass over estimates + targets, the gradient pass
+    add("pit_sisdr_stats", f * 2 * S * T, 2.0 * Bt * (4 * S + S * S) * T)
+    add("pit_sisdr_grad", f * 3 * S * T, 4.0 * Bt * S * T)
+    # ---- backward: tail
+    add("frames_gather", f * (S * A * T + SK * L) + f * (A * T + A * K * L))
+    add("pw_wgrad", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)                       # decoder weight
+    add("pw_conv_x3w<0>", f * L * (SK + SN), 2.0 * Bt * SN * SK * L)                 # decoder data gradient (frames -> g_v)
+    add("mask_bwd", f * L * (3 * SN + 2 * N), 3.0 * Bt * SN * L)
+    add("pw_wgrad", f * L * (SN + B), 2.0 * Bt * SN * B * L)                         # mask_net weight
+    add("pw_conv_x3w<0>", f * L * (SN + B), 2.0 * Bt * SN * B * L)                   # mask_net data gradient
+    add("prelu_bwd", f * 3 * B * L, 2.0 * Bt * B * L)
+    # ---- backward: U blocks
+    add("pw_wgrad", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)                   # res_conv weight (prologue re-applied on load)
+    add("pw_conv_x3w<0>", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)             # res_conv data gradient
+    add("gln_bwd_reduce", U * f * C * 2 * (L + lv[-1]), U * 4.0 * Bt * C * (L + lv[-1]))      # final_norm + the deepest level
+    add("gln_bwd_apply", U * f * C * (3 * L + (lev_sum - L)) + U * f * C * 3 * L, U * 16.0 * Bt * C * L)   # final_norm (+ merge sink) + proj norm
+    # per level: the conv backward reads g_out, d_k (its own norm's apply on load), the conv input, the merge part and writes g_in
+    dwb = 4 * L + sum(2 * lv[k] + 3 * lv[k - 1] for k in range(1, D))        # (level 0 has no merge part to add)
+    add("dwconv5_bwd", U * f * C * dwb, U * 2.0 * 15 * Bt * C * lev_sum)
+    add("pw_wgrad", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)                   # proj_1x1 weight
+    add("pw_conv_x3w<0>", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L)         # proj_1x1 data gradient + skip
+    # ---- backward: head
+    add("pw_wgrad", f * L * (B + N), 2.0 * Bt * B * N * L)
+    add("pw_conv_x3w<0>", f * L * (B + N), 2.0 * Bt * B * N * L)
+    add("gln_bwd_reduce", f * N * 2 * L, 4.0 * Bt * N * L)
+    add("gln_bwd_apply", f * N * 4 * L, 8.0 * Bt * N * L)
+    add("pw_wgrad", f * L * (N + A * K), 2.0 * Bt * N * A * K * L)                   # encoder weight
+    # ---- optimizer: sum of squares, then clip coefficient + Adam in one pass (p, g, m, v read; p, m, v written)
+    add("grad_sqnorm", 4.0 * P)
+    add("clip_adam", 28.0 * P, 12.0 * P)
+    return fam

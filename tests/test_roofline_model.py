@@ -41,3 +41,31 @@ def test_launch_model_bytes_are_positive_and_tail_fusion_removes_traffic():
     fused = sum(b for _, b, _ in roofline.launch_model(Bt=32, **CFG2))
     unfused = sum(b for _, b, _ in roofline.launch_model(Bt=32, fuse_tail=False, **CFG2))
     assert 0 < fused < unfused and unfused - fused > 0.7e9          # the masked tensor's write + read (2 x 419 MB) minus the partials
+
+
+def test_training_byte_and_flop_model():
+    """The training step's models: parameter counts = the README's, bytes / FLOPs on the documented rules,
+    and every family of the launch model carries positive bytes."""
+    from sudo_rm_rf_amd import roofline as R
+    d2 = dict(variant="improved", B=256, C=512, U=16, D=5, K=21, N=512, S=2, T=32000)
+    d4 = dict(variant="improved", B=512, C=512, U=36, D=6, K=21, N=2048, S=2, T=32000)
+    d3 = dict(variant="groupcomm", B=256, C=512, U=8, D=5, K=21, N=512, S=2, T=32000, G=16)
+    pk = lambda d: {k: v for k, v in d.items() if k != "T"}
+    assert R.n_params(**pk(d2)) == 5016353 and R.n_params(**pk(d4)) == 23239241 and R.n_params(**pk(d3)) == 507177   # SURVEY.md 8
+    for d in (d2, d4, d3):
+        fwd, trn = R.bytes_per_example(**d), R.train_bytes_per_example(**d)
+        assert 2.0 * fwd < trn < 3.0 * fwd                    # two mirrored passes + the re-reads of the saved activations
+        assert R.train_flops_per_example(**d) == 3.0 * R.flops_per_example(**d)
+    L = R.frames(32000, 21, 5)
+    want = 2 * R.bytes_per_example(**d2) + 4.0 * (512 * L + 16 * (256 * L + (4 - 2.0 ** -4) * 512 * L) + 256 * L) + 4.0 * 3 * 2 * 512 * L
+    assert abs(R.train_bytes_per_example(**d2) - want) < 1.0
+    fam = R.train_family_model(Bt=32, **d2)
+    assert R.train_family_model(Bt=32, **d3) is None
+    for name in ("pw_conv_x3w3<0>", "pw_conv_x3w3<2>", "pw_conv_x3w<0>", "pw_wgrad", "dwconv5_bwd", "gln_bwd_apply", "gln_bwd_reduce",
+                 "pyramid_merge_save", "pyramid_moments", "clip_adam"):
+        assert fam[name][0] > 0, name
+    # the forward GEMMs' bytes are the inference launch model's (same tensors): U x 4 Bt L (B + C) for proj_1x1
+    assert fam["pw_conv_x3w3<0>"][0] == 16 * 4.0 * 32 * L * (256 + 512)
+    # what this kernel set must move is more than the fusion-minimal figure (saved levels, separate norm passes), but < 2 x it
+    ks = sum(b for b, _ in fam.values())
+    assert 1.0 < ks / (32 * R.train_bytes_per_example(**d2)) < 2.0
