@@ -131,7 +131,8 @@ def test_online_remix_matches_the_runner_lines(B, S, T):
 
 
 @pytest.mark.parametrize("name", ["train_tiny_improved", "train_improved_mfma", "train_tiny_groupcomm",
-                                  "train_cfg2_shape", "train_cfg3_shape", "train_cfg4_shape"])
+                                  "train_cfg2_shape", "train_cfg3_shape", "train_cfg4_shape",
+                                  "train_cfg2_bench", "train_cfg4_bench"])
 def test_training_step_matches_reference_golden(name):
     """The runner's step (model.train(); loss = clamp(PIT-SI-SDR(model(mix)[, mixture consistency], clean));
     backward) through the reference's import paths against gradients the reference itself produced
@@ -159,9 +160,36 @@ def test_training_step_matches_reference_golden(name):
     # Round 2, other boxes: the cfg-2 / cfg-4 shape runs landed a PReLU-kink flip in one channel (2.5e-3 on
     # sm.15.spp_dw.3.conv.weight[110], 3.6e-3 on ln.gamma): see check_grads_against_golden's flip budget (1 % of the tensors,
     # none beyond 5 x its bar, whole-gradient L2 error within the bar; measured L2: ~1e-4).
-    big = name.endswith("_shape")
+    # *_bench (round 4): cfg 2 / cfg 4 at the BENCH length T = 32000 (L = 3200 frames: the GEMMs' 256 x 128
+    # tile paths, the full-length SAVE pyramid, the split-K weight gradients `bench.py --train` times), batch 4 / 2.
+    big = name.endswith(("_shape", "_bench"))
     check_grads_against_golden([(k, p.grad.cpu().numpy()) for k, p in model.state_dict(keep_vars=True).items()],
                                z, 2e-3 if big else 2e-4, fp32_yardstick=4.0 if big else 0.0, flip_budget=0.01 if big else 0.0)
+
+
+@pytest.mark.parametrize("name", ["train_improved_mfma_traj", "train_cfg2_shape_traj"])
+def test_training_trajectory_matches_reference_runner_loop(name):
+    """THREE steps of the runner's loop body (run_improved_sudormrf.py:146-177: zero_grad, forward, PIT-SI-SDR, clamp, backward,
+    clip_grad_norm_(5.0), Adam(lr=1e-3)) on three batches, with the fused HIP clip + Adam step, against the trajectory the
+    reference modules themselves produced (tools/make_golden_traj.py): the losses of all steps and the weights after the third
+    (VERDICT r3 missing 4: gradients and the optimizer were pinned separately, their composition over several steps was not)."""
+    import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib
+    from sudo_rm_rf_amd import optim
+    from test_oracle_golden import check_trajectory_against_golden, traj_case
+    cfg, sd, batches, z, c = traj_case(name)
+    model = build(cfg, sd).train()
+    opt = optim.FusedClipAdam(model.parameters(), lr=c["lr"], clip_grad_norm=c["clip_grad_norm"])
+    loss_fn = sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_mtx')
+    losses = []
+    for mix, tgt in batches:
+        opt.zero_grad()
+        l = torch.clamp(loss_fn(model(mix.to(DEV)), tgt.to(DEV)), min=-30., max=+30.)
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    big = "shape" in name
+    check_trajectory_against_golden([(k, p.detach().cpu().numpy()) for k, p in model.state_dict(keep_vars=True).items()], sd, losses,
+                                    z, 2e-2 if big else 2e-3)
 
 
 def test_fast_training_forward_flag():

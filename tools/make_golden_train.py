@@ -35,6 +35,11 @@ CASES = {
     "train_cfg2_shape": (ModelConfig("improved", 256, 512, 16, 5, 21, 512, 2), 2, 8000, 124, 214),   # (seeds with an unclamped loss)
     "train_cfg4_shape": (ModelConfig("improved", 512, 512, 36, 6, 21, 2048, 2), 1, 6400, 105, 205),
     "train_cfg3_shape": (ModelConfig("groupcomm", 256, 512, 8, 5, 21, 512, 2, 1, 16), 2, 8000, 106, 206),
+    # ... and at the BENCH length: T = 32000 = 4 s @ 8 kHz, L = 3200 frames -- the tile paths, the
+    # full-length SAVE pyramid and the split-K weight gradients that `bench.py --train` times -- batch 4
+
+    "train_cfg2_bench": (ModelConfig("improved", 256, 512, 16, 5, 21, 512, 2), 4, 32000, 124, 214),
+    "train_cfg4_bench": (ModelConfig("improved", 512, 512, 36, 6, 21, 2048, 2), 4, 32000, 105, 205),
 }
 SAMPLE = 4096      # gradient entries kept per parameter (strided)
 BIG_SAMPLE = 384   # ... for the BASELINE-shape cases (hundreds of tensors)
@@ -82,7 +87,7 @@ def main():
         # n_least_samples_req, for which it is the identity (SURVEY.md §8c "fp64 oracle recipe").  At these sizes the
         # reference's own fp32 backward is too noisy to referee anything: its PReLU-slope gradients (one scalar = a sum
         # over ~1e6 terms) differ from the fp64 value by up to 1.2e-2 relative.
-        f64 = name.endswith("_shape")
+        f64 = name.endswith(("_shape", "_bench"))
         if f64:
             assert T % cfg.n_least_samples_req == 0
             model = model.double()
@@ -113,7 +118,7 @@ def main():
             g = p.grad.numpy()
             if g32 is not None:
                 arrays["d:" + k] = np.float64(np.abs(g32[k] - g).max() / max(np.abs(g).max(), 1e-300))
-            smp, step = sample(g, BIG_SAMPLE if name.endswith("_shape") else SAMPLE)
+            smp, step = sample(g, BIG_SAMPLE if f64 else SAMPLE)
             arrays["g:" + k] = smp.astype(np.float32)
             arrays["n:" + k] = np.array([step, float(np.abs(g).max()), float(g.astype(np.float64).sum()),
                                          float((g.astype(np.float64) ** 2).sum())])
