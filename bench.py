@@ -345,8 +345,8 @@ def pmc_traffic(kernel_family, workload, train=False):
     must = ""
     if kernel_family.startswith("pw_conv_x3w<"):
         must = ", 2>"                                        # (two-part operands: the last template argument)
-    if kernel_family.startswith("pw_conv_x3w3<"):            # the three-part instantiations: "srf_pw_x3w_kernel<k, e, a, c, 3>"
-        key, must = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3w3<"):-1], ", 3>"
+    if kernel_family.startswith(("pw_conv_x3w3<", "pw_conv_x3w4<")):   # "srf_pw_x3w_kernel<k, e, a, c, 3 | 4>": three bf16 / two fp16 parts
+        key, must = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3w3<"):-1], ", %s>" % kernel_family[11]
     if kernel_family.startswith("pw_conv_x3w<"):             # family "pw_conv_x3w<2>" = every cache-policy instantiation of "srf_pw_x3w_kernel<2, ..."
         key = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3w<"):-1]
     if kernel_family.startswith("pw_conv_bf16x3_p8<"):       # one label per prologue variant = one rocprof kernel name
@@ -551,7 +551,7 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
                 hbm = {"bound": "hbm", "achieved": kd["algorithmic_GBps"], "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": kd["algorithmic_GBps"] / roofline.HBM_PEAK_GBS}
                 if dom.startswith("pw_"):      # a GEMM: the matrix pipe is the other ceiling (3 bf16 MFMAs per product; 6 on the three-part kernel)
-                    peak = roofline.MFMA_BF16_PEAK_TFLOPS / (6 if "x3w3" in dom else 3)
+                    peak = roofline.MFMA_BF16_PEAK_TFLOPS / (6 if "x3w3" in dom else 3)      # (fp16 MFMA peak = bf16's)
                     mfma = {"bound": "mfma", "achieved": kd["TFLOPs"], "peak": peak, "unit": "TFLOP/s", "frac": kd["TFLOPs"] / peak}
                     first, other = (hbm, mfma) if hbm["frac"] >= mfma["frac"] else (mfma, hbm)
                     rl.update(first, other_ceiling=other)
@@ -576,8 +576,10 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
             "value": world * batch * (T / fs) * args.steps / r["seconds"], "unit": "trained-seconds/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (forward GEMMs: three-part split-bf16, 6 MFMAs per product block, 24-bit operands = exact-fp32 class; "
-                     "backward GEMMs: two-part split-bf16, 3 MFMAs; fp32 accumulate)",
+            "dtype": ("f32 (forward GEMMs: three-part split-bf16, 6 MFMAs per product block, 24-bit operands = exact-fp32 class; "
+                      if args.debug_flags & 16384 else
+                      "f32 (forward GEMMs: fp32 operands split into fp16 hi+lo, 22-bit operands, 3 f16 MFMAs per product block = "
+                      "exact-fp32 class by measurement; ") + "backward GEMMs: two-part split-bf16, 3 MFMAs; fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%s training step, batch %d per GPU, T=%d" % (args.workload, batch, T),
                        "global_batch": batch * world, "parallelism": "data-parallel x%d, one gradient all-reduce" % world},

@@ -113,6 +113,7 @@ int srf_profile_get(int i, const char** name, float* ms);
  *   256      leftover GEMM tiles as whole tiles (no quarter tiles) 512       quarter tiles last
  *   1024     TAC forward with one time step per lane               2048      one-tile-per-block 128 x 128 GEMM everywhere
  *                                                                            (also: no 64 x 64 tiles for small launches)
+ *   16384    training forward: three bf16 parts per operand (6 MFMAs, round 3) instead of two fp16 parts (3 MFMAs, round 4)
  *   32768    WITHOUT the fused tail: mask GEMM -> masked tensor -> decoder frame GEMM -> overlap-add as separate launches
  *   bits 12-13, 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating; the GEMM's
  *            only in lab builds: SRF_BUILD_EXPERIMENTS=1 python -m sudo_rm_rf_amd.build -> libsudormrf_hip_lab.so)

@@ -31,9 +31,15 @@
 // tile's first 8 / 16 k-steps as dword buffer stores straight from the MFMA layout: proj_1x1 138 vs 119 us), per-XCD WORK
 // QUEUES with phase seeds (blocks start out of phase on 0-3 quarter tiles, then draw tiles with one atomicAdd each: 125 vs
 // 115 us -- a quarter tile costs ~0.6 of a full tile's time), start-up stagger (114-121 vs 108 us).  Why none of the
-// re-orderings pays: these launches run at the package power cap (1.35 kW of 1.4 kW, shader clock 1.3 GHz), so their
-// time follows the work, not its schedule.
-// The round-2 kernel stays in the library (debug flag 16384) for same-box A/B runs.
+// re-orderings pays -- round 4's finding (profiles/r04_NOTES.md, tools/probes/cu_stream_probe.hip; round 3's "power cap" reading
+// is RETRACTED: with the MFMAs compiled out the launches keep 81-93 % of their time at 2.4 GHz and 1.05 kW): on gfx950 a
+// wavefront's vector-memory instructions do not issue while other wavefronts of its SIMD run MFMAs back to back, so in a block
+// whose eight waves all multiply, loads issue only in the gaps (barriers, LDS waits) and the waves phase-lock; and one CU's L2
+// hits queue behind its own HBM misses.  Round 4 built two kernels around that (loader waves / a SIMD kept free of MFMAs:
+// csrc/experiments/, lab build only) -- bit-identical, not faster (124-170 us against this kernel's 109-118 us on res_conv:
+// the epilogue and the extra barriers cost what the overlap wins).
+// Round 4 also added NP = 4: operands split into two FP16 parts (3 f16 MFMAs per product block, weights pre-scaled by 2^4) --
+// the training forward's default (srf_pwconv.hip: srf_train_f16_split).
 // Prologue / epilogue semantics are those of srf_pw.h (PwArgs).
 #include <type_traits>
 
@@ -58,6 +64,24 @@ __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8
     hi[j] = h;
     lo[j] = (__bf16)(v[j] - (float)h);
   }
+}
+
+// NP 4: the two parts are fp16 (11 + 11 mantissa bits instead of bf16's 8 + 8): hi = fp16(x), lo = fp16(x - hi).
+// The weights are stored times 2^4 (W_F16_WSCALE) so that the lo parts of typical weights (~0.03) stay in fp16's normal range;
+// the epilogue multiplies the accumulators by 2^-4 (exact).  Packets keep the bf16x8 container type (16 bytes).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float W_F16_WSCALE = 16.f;
+__device__ __forceinline__ void w_split8_f16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  f16x8 h8, l8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float vc = __builtin_amdgcn_fmed3f(v[j], -60000.f, 60000.f);     // (fp16 range guard: see srf_pwconv.hip)
+    const _Float16 h = (_Float16)vc;
+    h8[j] = h;
+    l8[j] = (_Float16)(vc - (float)h);
+  }
+  hi = __builtin_bit_cast(bf16x8, h8);
+  lo = __builtin_bit_cast(bf16x8, l8);
 }
 
 #define W_LDS(p) ((__attribute__((address_space(3))) void*)(p))
@@ -312,7 +336,8 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       vb[j] = x0;
     }
     bf16x8 hi, lo;
-    w_split8(vb, hi, lo);
+    if constexpr (NP == 4) w_split8_f16(vb, hi, lo);
+    else w_split8(vb, hi, lo);
     *reinterpret_cast<bf16x8*>(base) = hi;
     *reinterpret_cast<bf16x8*>(base + W_B_IMG) = lo;
   };
@@ -363,21 +388,24 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     }
     constexpr int NT = decltype(full_tag)::value ? 2 : 1;
     // pass-major order: independent accumulators between two MFMAs on the same one (and the summation order of every split-bf16 kernel of the library)
+    auto mf = [](const bf16x8& x, const bf16x8& y, const f32x16& c) __attribute__((always_inline)) {
+      if constexpr (NP == 4)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+      else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+    };
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < NT; ++mi)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+      for (int mi = 0; mi < NT; ++mi) acc[mi][ni] = mf(f.al[mi], f.bh[ni], acc[mi][ni]);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < NT; ++mi)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);
+      for (int mi = 0; mi < NT; ++mi) acc[mi][ni] = mf(f.ah[mi], f.bl[ni], acc[mi][ni]);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < NT; ++mi)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+      for (int mi = 0; mi < NT; ++mi) acc[mi][ni] = mf(f.ah[mi], f.bh[ni], acc[mi][ni]);
   };
   // NP 3: f = {h, l} fragments (sub-step 0), g = {m} fragments (sub-step 1).  Smallest terms first: l*h, h*l | m*m, m*h, h*m, h*h
   auto mma3_a = [&](const Frags& f, auto full_tag) __attribute__((always_inline)) {
@@ -835,6 +863,10 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
             for (int ii = 0; ii < 4; ++ii) {
               float4 o = *reinterpret_cast<const float4*>(strip + (ii * 8 + rsub) * SRF_EPI_PITCH_H + c4);
               const float bs = rbias[mi][ii];
+              if constexpr (NP == 4) {       // (the weights were stored times 2^4)
+                constexpr float inv = 1.f / W_F16_WSCALE;
+                o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+              }
               o.x += bs; o.y += bs; o.z += bs; o.w += bs;
               if constexpr (kHasExt) {
                 const float4 e = rext[mi][ni][ii];
@@ -925,6 +957,8 @@ struct WPackEntry {
 struct WPackTable {
   WPackEntry e[SRF_W_MAX_PACK];
 };
+// F16: fp16 parts of 2^4 w (NP 4) instead of bf16 parts of w
+template <bool F16>
 __global__ __launch_bounds__(256) void srf_x3w_pack_kernel(WPackTable t) {
   WPackEntry e = t.e[blockIdx.y];
   const bool trans = e.Cin < 0;
@@ -939,20 +973,22 @@ __global__ __launch_bounds__(256) void srf_x3w_pack_kernel(WPackTable t) {
     const int kt = (int)(tile % nKt), mt = (int)(tile / nKt);
     const int m = mt * W_BM + row;
     bf16x8 hi, lo;
+    float vv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = kt * W_BK + c * 8 + j;
       const float v = (m < e.Cout) ? (trans ? e.w[(size_t)k * e.Cout + m] : e.w[(size_t)m * e.Cin + k]) : 0.f;
-      const __bf16 h = (__bf16)v;
-      hi[j] = h;
-      lo[j] = (__bf16)(v - (float)h);
+      vv[j] = F16 ? v * W_F16_WSCALE : v;
     }
+    if constexpr (F16) w_split8_f16(vv, hi, lo);
+    else w_split8(vv, hi, lo);
     char* base = e.dst + (size_t)tile * W_WTILE_BYTES + w_swz(row, c);
     *reinterpret_cast<bf16x8*>(base) = hi;
     *reinterpret_cast<bf16x8*>(base + W_A_IMG) = lo;
   }
 }
-int srf_x3w_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {
+static int srf_x3w_pack_launch_any(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st,
+                                   bool f16) {
   for (int base = 0; base < n; base += SRF_W_MAX_PACK) {
     WPackTable t;
     const int cnt = (n - base) < SRF_W_MAX_PACK ? (n - base) : SRF_W_MAX_PACK;
@@ -960,10 +996,18 @@ int srf_x3w_pack_launch(const float* const* w, char* const* dst, const int* Cout
       const int j = base + (i < cnt ? i : 0);
       t.e[i] = WPackEntry{w[j], dst[j], Cout[j], Cin[j]};
     }
-    hipLaunchKernelGGL(srf_x3w_pack_kernel, dim3(64, cnt), dim3(256), 0, st, t);
-    SRF_CHECK_LAUNCH("pack_pw_weights", st);
+    if (f16) hipLaunchKernelGGL(srf_x3w_pack_kernel<true>, dim3(64, cnt), dim3(256), 0, st, t);
+    else hipLaunchKernelGGL(srf_x3w_pack_kernel<false>, dim3(64, cnt), dim3(256), 0, st, t);
+    SRF_CHECK_LAUNCH(f16 ? "pack_pw_weights_f16" : "pack_pw_weights", st);
   }
   return SRF_OK;
+}
+int srf_x3w_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {
+  return srf_x3w_pack_launch_any(w, dst, Cout, Cin, n, st, false);
+}
+// fp16 parts (NP 4): the same image layout and size as the bf16 two-part image
+int srf_x3w_pack_f16_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {
+  return srf_x3w_pack_launch_any(w, dst, Cout, Cin, n, st, true);
 }
 
 // fuse_wd != null: the mask epilogue fused with the decoder's contraction (EPI 4; pro 3, mask epilogue, fuse_M <= 64)
@@ -973,6 +1017,10 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   return srf_pw_x3w_launch_any(a, wpack, pro, nullptr, nullptr, 0, st);
 }
 // three-part operands, six MFMAs per product block (the training forward); wpack3: srf_x3w_pack3_launch's image
+// two fp16 parts, three MFMAs per product block (experiment for the training forward); wpack: srf_x3w_pack_f16_launch's image
+int srf_pw_x3w4_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
+  return srf_pw_x3w_launch_any(a, wpack, pro, nullptr, nullptr, 0, st, 4);
+}
 int srf_pw_x3w3_launch(const PwArgs& a, const char* wpack3, int pro, hipStream_t st) {
   return srf_pw_x3w_launch_any(a, wpack3, pro, nullptr, nullptr, 0, st, 3);
 }
@@ -1104,6 +1152,9 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
         (const void*)&srf_pw_x3w_kernel<3, 2, 0, 13>,
         (const void*)&srf_pw_x3w_kernel<3, 4, 0, 0>, (const void*)&srf_pw_x3w_kernel<3, 4, 0, 4>,
         (const void*)&srf_pw_x3w_kernel<0, 1, 0, 0>,
+        // two fp16 parts (training-forward experiment)
+        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 0, 4>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 5, 4>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 5, 4>, (const void*)&srf_pw_x3w_kernel<3, 0, 0, 5, 4>,
         // three-part operands (training forward)
         (const void*)&srf_pw_x3w_kernel<0, 0, 0, 0, 3>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 5, 3>,
         (const void*)&srf_pw_x3w_kernel<2, 1, 0, 5, 3>, (const void*)&srf_pw_x3w_kernel<3, 0, 0, 5, 3>,
@@ -1212,6 +1263,18 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
   const int cp_flag = (srf_debug_flags() >> 26) & 15;
   static const int kDefaultCp[4] = {0, 5, 5, 5};
   const int cp = cp_flag ? cp_flag - 1 : kDefaultCp[pro < 0 || pro > 3 ? 0 : pro];
+  if (np == 4) {
+#define W_GO4(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, C, 4>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
+    SRF_CHECK_ARG(!mask && !fuse_wd && (pro == 2) == res && !(pro != 2 && res), "srf_pw_conv (fp16 two-part): form not built");
+    if (pro == 0) W_GO4(0, 0, 0);
+    else if (pro == 1) W_GO4(1, 0, 5);
+    else if (pro == 2) W_GO4(2, 1, 5);
+    else W_GO4(3, 0, 5);
+#undef W_GO4
+    static const char* const kLabel4[4] = {"pw_conv_x3w4<0>", "pw_conv_x3w4<1>", "pw_conv_x3w4<2>", "pw_conv_x3w4<3>"};
+    SRF_CHECK_LAUNCH(kLabel4[pro < 0 || pro > 3 ? 3 : pro], st);
+    return SRF_OK;
+  }
   if (np == 3) {
 #define W_GO3(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, C, 3>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
     SRF_CHECK_ARG(!mask && !fuse_wd && (pro == 2) == res && !(pro != 2 && res), "srf_pw_conv (three-part): form not built");

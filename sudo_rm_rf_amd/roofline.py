@@ -193,16 +193,16 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
         b0, f0 = fam.get(name, (0.0, 0.0))
         fam[name] = (b0 + nbytes, f0 + flops)
 
-    # ---- forward (training): GEMMs on the three-part split kernel, fused pyramid with saved levels, un-fused tail
+    # ---- forward (training): GEMMs on the fp16 two-part split kernel (x3w4), fused pyramid with saved levels, un-fused tail
     add("encoder", f * (A * T + N * L), 2.0 * Bt * N * A * K * L)
-    add("pw_conv_x3w3<1>", f * L * (N + B), 2.0 * Bt * N * B * L)
-    add("pw_conv_x3w3<0>", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)
+    add("pw_conv_x3w4<1>", f * L * (N + B), 2.0 * Bt * N * B * L)
+    add("pw_conv_x3w4<0>", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)
     dw = 2.0 * 5 * Bt * C * lev_sum
     add("pyramid_moments", U * f * C * L, U * dw)
     add("pyramid_finalize", U * 8.0 * Bt * C * D * 5)
     add("pyramid_merge_save", U * f * C * (2 * L + lev_sum), U * (dw + 2.0 * D * Bt * C * L))     # pass 2 + the levels on the side
-    add("pw_conv_x3w3<2>", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L)
-    add("pw_conv_x3w3<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
+    add("pw_conv_x3w4<2>", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L)
+    add("pw_conv_x3w4<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
     add("mask_apply", f * L * (2 * SN + N), 2.0 * Bt * SN * L)
     # decoder (stand-alone form): weight transpose, frame GEMM S N -> S K, overlap-add
     add("pw_conv_x3w<0>", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)

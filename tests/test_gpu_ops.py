@@ -258,13 +258,16 @@ def test_pw_conv_narrow_tiles_for_small_launches(Bt, Cin, Cout, L, pro, epi):
 @pytest.mark.parametrize("Bt,Cin,Cout,L", [(16, 256, 512, 3200), (16, 512, 256, 3200), (8, 512, 1024, 3200), (3, 2048, 512, 12800),
                                            (12, 512, 512, 1632)])
 @pytest.mark.parametrize("pro", [0, 1, 2, 3])
-def test_pw_conv_three_part_split(Bt, Cin, Cout, L, pro):
-    """The training forward's GEMM (srf_pw_conv_packed3: three bf16 parts per operand, six MFMAs per product block): the
-    profiler proves the 256 x 128 three-part kernel served the launch; against an fp64 reference its error must be in the
-    exact-fp32 MFMA kernel's class (kernel mode 2 on the same inputs), far below the two-part kernel's; statistics epilogue
-    checked for the forms that have one.  Forms as the training forward uses them: pro 2 with the residual, the others without."""
+@pytest.mark.parametrize("parts", ["fp16x2", "bf16x3"])
+def test_pw_conv_three_part_split(Bt, Cin, Cout, L, pro, parts):
+    """The training forward's GEMM (srf_pw_conv_packed3) in both of its forms -- two fp16 parts per operand, three MFMAs per
+    product block (round 4, the default) and three bf16 parts, six MFMAs (round 3, debug flag 16384): the profiler proves the
+    256 x 128 kernel of that form served the launch; against an fp64 reference its error must be in the exact-fp32 MFMA kernel's
+    class (kernel mode 2 on the same inputs), far below the two-part bf16 kernel's; statistics epilogue checked for the forms
+    that have one.  Forms as the training forward uses them: pro 2 with the residual, the others without."""
     from sudo_rm_rf_amd import ops
     ops.set_kernel_mode(0)
+    ops.set_debug_flags(16384 if parts == "bf16x3" else 0)
     g = torch.Generator(device=DEV).manual_seed(700 + Cin + Cout + L + pro)
     x = torch.randn(Bt, Cin, L, generator=g, device=DEV) * 1.3 + 0.2
     w = torch.randn(Cout, Cin, 1, generator=g, device=DEV) * Cin ** -0.5
@@ -296,7 +299,8 @@ def test_pw_conv_three_part_split(Bt, Cin, Cout, L, pro):
     osums = ops.new_sums(Bt, DEV) if pro == 0 else None
     with ops.kernel_trace(DEV) as tr:
         got = ops.pw_conv3(x, w, bias, packed3, out_sums=osums, **kw)
-    assert tr.names == {"pw_conv_x3w3<%d>" % pro}, tr.names
+    assert tr.names == {"pw_conv_x3w%d<%d>" % (3 if parts == "bf16x3" else 4, pro)}, tr.names
+    ops.set_debug_flags(0)
     try:
         ops.set_kernel_mode(2)
         exact = ops.pw_conv(x, w, bias, **kw)

@@ -61,11 +61,11 @@ def test_training_byte_and_flop_model():
     assert abs(R.train_bytes_per_example(**d2) - want) < 1.0
     fam = R.train_family_model(Bt=32, **d2)
     assert R.train_family_model(Bt=32, **d3) is None
-    for name in ("pw_conv_x3w3<0>", "pw_conv_x3w3<2>", "pw_conv_x3w<0>", "pw_wgrad", "dwconv5_bwd", "gln_bwd_apply", "gln_bwd_reduce",
+    for name in ("pw_conv_x3w4<0>", "pw_conv_x3w4<2>", "pw_conv_x3w<0>", "pw_wgrad", "dwconv5_bwd", "gln_bwd_apply", "gln_bwd_reduce",
                  "pyramid_merge_save", "pyramid_moments", "clip_adam"):
         assert fam[name][0] > 0, name
     # the forward GEMMs' bytes are the inference launch model's (same tensors): U x 4 Bt L (B + C) for proj_1x1
-    assert fam["pw_conv_x3w3<0>"][0] == 16 * 4.0 * 32 * L * (256 + 512)
+    assert fam["pw_conv_x3w4<0>"][0] == 16 * 4.0 * 32 * L * (256 + 512)
     # what this kernel set must move is more than the fusion-minimal figure (saved levels, separate norm passes), but < 2 x it
     ks = sum(b for b, _ in fam.values())
     assert 1.0 < ks / (32 * R.train_bytes_per_example(**d2)) < 2.0
