@@ -22,7 +22,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-ato
 # selected at run time with SRF_GEMM=x3s | x3t), the ablated instantiations of the shipped GEMM (debug flag bits 16..21,
 # SRF_X3W_ABL) and its in-kernel timeline.  The default build -- what ships, what the tests and the bench load -- has none of it.
 EXPERIMENTS = os.environ.get("SRF_BUILD_EXPERIMENTS", "") not in ("", "0")
-EXPERIMENT_SOURCES = ["experiments/srf_pwconv_x3s.hip", "experiments/srf_pwconv_x3t.hip"]
+EXPERIMENT_SOURCES = ["experiments/srf_pwconv_x3s.hip", "experiments/srf_pwconv_x3t.hip", "experiments/srf_pwconv_x3p.hip"]
 if EXPERIMENTS:
     FLAGS = FLAGS + ["-DSRF_EXPERIMENTS=1"]
     LIB = os.path.join(PKG, "libsudormrf_hip_lab.so")       # its own file (load it with SRF_LIB=...): never the product library
@@ -36,6 +36,7 @@ FILE_FLAGS = {
     "srf_pwconv_x3w.hip": ["-fno-slp-vectorize"],
     "experiments/srf_pwconv_x3s.hip": ["-fno-slp-vectorize"],
     "experiments/srf_pwconv_x3t.hip": ["-fno-slp-vectorize"],
+    "experiments/srf_pwconv_x3p.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_w4.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_wgrad.hip": ["-fno-slp-vectorize"],
     "srf_pwconv.hip": ["-fno-slp-vectorize"],

@@ -1,0 +1,446 @@
+// EXPERIMENT (round 4, lab builds only: SRF_BUILD_EXPERIMENTS=1, selected with SRF_GEMM=x3p) -- the 256 x 128 split-bf16 GEMM as
+// TWO CO-RESIDENT BLOCKS PER CU (first form).
+//
+// The shipped kernel (srf_pwconv_x3w.hip) keeps one 512-thread block per CU (144 KB of LDS, ~240 registers): its eight wavefronts
+// convert, wait at the barrier, read fragments and multiply in lock step, so a k-step costs the SUM of those phases (profiles/
+// r04_NOTES.md: 1 536 cycles of MFMA inside ~3 800).  Here a block is half as heavy -- 16-k pipeline steps, three 24-KB stages
+// (A image 16 KB by LDS-DMA, B image 8 KB), <= 128 registers (64 accumulators, ONE fragment set, four 4-register activation sets)
+// -- so that two blocks share a CU, 4 wavefronts per SIMD, and the hardware fills one block's barrier / LDS / conversion gaps
+// with the other block's MFMAs, loads and stores.  Nothing else is clever: no fragment prefetch, no LDS strip in the epilogue
+// (dword buffer stores straight from the MFMA layout: 128-byte row segments), static round-robin tiles, whole tiles only.
+// Same arithmetic as the shipped kernel in the same order (per 16 k: lo*hi, hi*lo, hi*hi; bias, then residual): the outputs are
+// BIT-IDENTICAL; the statistics (fp64 buckets of fp32 partial sums) agree to rounding.
+// Packed weights: srf_x3t_pack_kernel's image (srf_pwconv_x3t.hip) -- per (m-tile, 16-k step) [256 rows][hi k0-7 | hi k8-15 |
+// lo k0-7 | lo k8-15], 64-byte rows, 16-byte chunks XOR-swizzled like the B image.
+// Forms: PRO 0-3 x EPI 0 (bias + statistics) | 1 (bias + residual); the mask / fused-tail GEMM stays with the shipped kernel.
+#include <type_traits>
+
+#include "../srf_pw.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int P_BM = 256, P_BN = 128, P_KT = 16;
+constexpr int P_A_IMG = P_BM * 64;                 // 16 KB
+constexpr int P_B_IMG = P_BN * 64;                 // 8 KB
+constexpr int P_STAGE = P_A_IMG + P_B_IMG;         // 24 KB
+constexpr int P_NSTAGE = 3;
+constexpr int P_MAX_STAT_EXAMPLES = 512;           // 4 KB behind the stages
+constexpr int P_LDS_BYTES = P_NSTAGE * P_STAGE + P_MAX_STAT_EXAMPLES * 8;
+static_assert(2 * P_LDS_BYTES <= 160 * 1024, "two blocks per CU");
+
+__device__ __forceinline__ int p_swz(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
+
+#define P_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ABL (diagnostics): the instantiation that obeys the run-time mask `rabl` (results wrong): 1 = no epilogue, 2 = no MFMAs, 4 = no
+// weight DMA, 8 = no activation loads / conversion / ds_write, 16 = no fragment reads, 32 = no barriers.
+// TL (diagnostics, results stay correct): per-wavefront shader-clock totals {whole kernel, counted waits, barriers, epilogues,
+// steps} as 8 dwords per wavefront to `a.mul` (tools/gemm_timeline_x3s.py with TL_GEMM=x3p).
+template <int PRO, int EPI, int ABL = 0, int TL = 0>
+__global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt, int total,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ bias_r, int rabl_arg) {
+  const int rabl = ABL ? rabl_arg : 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 wavefronts, 64 x 64 each
+  const int Cin = a.Cin, L = a.L;
+  const int nk = Cin / P_KT;                 // multiple of 4, >= 8 (host checks)
+  const int nblk = gridDim.x;
+  const int ntile = (total - (int)blockIdx.x + nblk - 1) / nblk;
+  const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
+  const int x_bytes = a.Bt * Cin * L * 4;
+
+  // GlobLN statistics of every example, once per block (as in the shipped kernel)
+  float2* stat_tab = reinterpret_cast<float2*>(smem + P_NSTAGE * P_STAGE);
+  if constexpr (PRO == 1 || PRO == 2) {
+    for (int b0 = wave * 4; b0 < a.Bt; b0 += 32) {
+      double2 bk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = min(b0 + u, a.Bt - 1);
+        bk[u] = reinterpret_cast<const double2*>(a.nrm.sums)[(size_t)b * SRF_STAT_BUCKETS + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double s = srf_dpp_wave_sum(bk[u].x), q = srf_dpp_wave_sum(bk[u].y);   // totals in lane 63
+        const double m = s * a.inv_count;
+        double v = q * a.inv_count - m * m;
+        v = v < 0.0 ? 0.0 : v;
+        if (lane == 63 && b0 + u < a.Bt) stat_tab[b0 + u] = make_float2((float)m, (float)(1.0 / sqrt(v + 1e-8)));
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- tiles: virtual id v = mt + nMt (lt + nLt b) (the nMt blocks that share an activation tile are neighbours on one XCD)
+  struct TileCur {
+    int v, mt, lt, b;
+  };
+  auto cur_set = [&](TileCur& c, int i) {
+    const int v = srf_xcd_remap(blockIdx.x + i * nblk, total);
+    const int t = v / nMt;
+    c.v = v;
+    c.mt = v - t * nMt;
+    c.b = t / nLt;
+    c.lt = t - c.b * nLt;
+  };
+  // ---- B staging: thread -> time step n = tid & 127, k rows 4 kg .. 4 kg + 3 (kg = tid >> 7, wave-uniform)
+  const int b_n = tid & 127, kg = wave >> 1;
+  const int b_hi = P_A_IMG + p_swz(b_n, kg >> 1) + (kg & 1) * 8;
+  const int b_lo = P_A_IMG + p_swz(b_n, 2 + (kg >> 1)) + (kg & 1) * 8;
+  __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+
+  struct TileP {
+    const char* a_src;   // this wavefront's 2-KB slice of the tile's packed weights, k-step 0 (wave-uniform)
+    int b_vo;            // per-lane byte offset of (example, k row 4 kg, column) inside X; out of range = fetch nothing
+    float mean, rstd;
+  };
+  auto make_tile = [&](const TileCur& c) {
+    TileP t;
+    t.a_src = wpack + (size_t)c.mt * nk * P_A_IMG + wave * 2048;
+    const int col = c.lt * P_BN + b_n;
+    t.b_vo = col < L ? ((c.b * Cin + 4 * kg) * L + col) * 4 : x_bytes;
+    t.mean = 0.f;
+    t.rstd = 1.f;
+    if constexpr (PRO == 1 || PRO == 2) {
+      const float2 mr = stat_tab[c.b];
+      t.mean = mr.x;
+      t.rstd = mr.y;
+    }
+    return t;
+  };
+  struct Regs {
+    float b[4];
+  };
+  auto gload_a = [&](const TileP& t, int kt, int stage) __attribute__((always_inline)) {
+    if (ABL && (rabl & 4)) return;
+    const char* src = t.a_src + (size_t)kt * P_A_IMG + lane * 16;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)P_LDS(smem + stage * P_STAGE + wave * 2048));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src + i * 1024), "s"(dst + i * 1024)
+          : "memory");
+    }
+  };
+  auto gload_b = [&](Regs& r, const TileP& t, int kt) __attribute__((always_inline)) {
+    if (ABL && (rabl & 8)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(r.b[j]));
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * P_KT + j) * L * 4, 0));
+  };
+  auto lds_store = [&](const Regs& r, const TileP& t, int kt, int stage) __attribute__((always_inline)) {
+    if (ABL && (rabl & 8)) return;
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = r.b[j];
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));   // (pins the conversion -- and its wait -- here)
+    bf16x4 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x0 = x[j];
+      if (PRO == 1 || PRO == 2) {
+        const int k = kt * P_KT + 4 * kg + j;
+        const float sc = gamma[k] * t.rstd;
+        x0 = fmaf(x0, sc, beta[k] - t.mean * sc);
+      }
+      if (PRO == 2 || PRO == 3) x0 = srf_prelu(x0, slope);
+      const __bf16 h = (__bf16)x0;
+      ph[j] = h;
+      pl[j] = (__bf16)(x0 - (float)h);
+    }
+    char* base = smem + stage * P_STAGE;
+    *reinterpret_cast<bf16x4*>(base + b_hi) = ph;
+    *reinterpret_cast<bf16x4*>(base + b_lo) = pl;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  const int fr = lane & 31, fc = lane >> 5;
+  int a_off[2], b_off[2];   // hi fragments; the lo fragment of the same row sits at offset ^ 32 (logical chunk + 2)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    a_off[t] = p_swz(wm * 64 + t * 32 + fr, fc);
+    b_off[t] = P_A_IMG + p_swz(wn * 64 + t * 32 + fr, fc);
+  }
+  struct Frags {
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+  };
+  auto read_frags = [&](Frags& f, int stage) __attribute__((always_inline)) {
+    if (ABL && (rabl & 16)) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) asm volatile("" : "=v"(f.ah[t]), "=v"(f.al[t]), "=v"(f.bh[t]), "=v"(f.bl[t]));
+      return;
+    }
+    const char* base = smem + stage * P_STAGE;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f.ah[t] = *reinterpret_cast<const bf16x8*>(base + a_off[t]);
+      f.bh[t] = *reinterpret_cast<const bf16x8*>(base + b_off[t]);
+      f.al[t] = *reinterpret_cast<const bf16x8*>(base + (a_off[t] ^ 32));
+      f.bl[t] = *reinterpret_cast<const bf16x8*>(base + (b_off[t] ^ 32));
+    }
+  };
+  auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+    if (ABL && (rabl & 2)) {
+      asm volatile("" ::"v"(f.ah[0]), "v"(f.al[0]), "v"(f.bh[0]), "v"(f.bl[0]), "v"(f.ah[1]), "v"(f.al[1]), "v"(f.bh[1]), "v"(f.bl[1]));
+      return;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+  };
+
+  // One pipeline step = k-step kt of the current tile (stage s0): convert k-step kt+1 (register set (kt+1) & 3, loaded four steps
+  // ago) into stage s1, start the DMA of k-step kt+2 into stage s2, reload the register set with k-step kt+5, multiply k-step kt.
+  // k-step indices >= nk belong to the NEXT tile.  One barrier per step: before it every wavefront's ds_writes of k-step kt+1
+  // are done and its DMA pieces of k-step kt+1 -- issued a step ago, 10 memory operations ago -- have landed.
+  int s0 = 0;
+  TileP tc, tn;
+  unsigned tl_wait = 0, tl_bar = 0, tl_epi = 0, tl_steps = 0;
+  const unsigned tl_begin = TL ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+  auto pick = [&](int k, int& kk) __attribute__((always_inline)) {
+    const bool nx = k >= nk;   // wave-uniform
+    kk = nx ? k - nk : k;
+    TileP t;
+    t.a_src = nx ? tn.a_src : tc.a_src;
+    t.b_vo = nx ? tn.b_vo : tc.b_vo;
+    t.mean = nx ? tn.mean : tc.mean;
+    t.rstd = nx ? tn.rstd : tc.rstd;
+    return t;
+  };
+  auto step = [&](Regs& set, int kt) __attribute__((always_inline)) {
+    const int s1 = s0 == P_NSTAGE - 1 ? 0 : s0 + 1, s2 = s1 == P_NSTAGE - 1 ? 0 : s1 + 1;
+    int k1, k2, k5;
+    const TileP t1 = pick(kt + 1, k1), t2 = pick(kt + 2, k2), t5 = pick(kt + 5, k5);
+    Frags f;
+    read_frags(f, s0);
+    lds_store(set, t1, k1, s1);
+    gload_a(t2, k2, s2);
+    gload_b(set, t5, k5);
+    mma(f);
+    if constexpr (TL) {
+      const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      const unsigned t2 = (unsigned)__builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tl_wait += t1 - t0;
+      tl_bar += t2 - t1;
+      tl_steps += 1;
+    } else {
+      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      if (!(ABL && (rabl & 32))) __builtin_amdgcn_s_barrier();
+    }
+    s0 = s1;
+  };
+
+  TileCur cur;
+  cur_set(cur, 0);
+  tc = make_tile(cur);
+  TileCur nxc = cur;
+  if (ntile > 1) cur_set(nxc, 1);
+  tn = ntile > 1 ? make_tile(nxc) : tc;   // past the last tile the pipeline re-reads that tile (harmless)
+  Regs r0, r1, r2, r3;
+  gload_a(tc, 0, 0);
+  gload_a(tc, 1, 1);
+  gload_b(r0, tc, 0);
+  gload_b(r1, tc, 1);
+  gload_b(r2, tc, 2);
+  gload_b(r3, tc, 3);
+  lds_store(r0, tc, 0, 0);
+  gload_b(r0, tc, 4);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int i = 0; i < ntile; ++i) {
+    for (int kt = 0; kt < nk; kt += 4) {
+      step(r1, kt);         // converts k-step kt+1 (r1), reloads it with k-step kt+5
+      step(r2, kt + 1);
+      step(r3, kt + 2);
+      step(r0, kt + 3);
+    }
+    // ---- epilogue: straight from the MFMA C layout (register r of block (mi, ni) = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
+    // column lane & 31): one dword buffer store per register = two 128-byte row segments per instruction
+    const unsigned tl_e0 = TL ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+    const int b = cur.b, m0 = cur.mt * P_BM + wm * 64, l0 = cur.lt * P_BN + wn * 64, v = cur.v;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));     // (keeps the offsets below from being hoisted out of the tile loop and spilled)
+    const int lhalf = lane_o >> 5, lcol = lane_o & 31;
+    float s = 0.f, q = 0.f;
+    if (!(ABL && (rabl & 1))) {
+      __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * a.Cout * L, 0, a.Cout * L * 4, 0x00020000);
+      __amdgpu_buffer_rsrc_t rrs = yrs;
+      if constexpr (EPI == 1)
+        rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual) + (size_t)b * a.Cout * L, 0, a.Cout * L * 4, 0x00020000);
+      // units of 8 registers (two 8-row groups of one 32 x 32 block); the residual of unit u + 1 is requested before unit u is
+      // evaluated (16 registers -- a whole block ahead, 32, spills next to the accumulators and the activation sets)
+      float rv[2][8];
+      auto res_issue = [&](int slot, int u) __attribute__((always_inline)) {
+        if constexpr (EPI == 1) {
+          const int mi = u >> 2, ni = (u >> 1) & 1;
+          const int col = l0 + ni * 32 + lcol;
+          const int vo = col < L ? (4 * lhalf * L + col) * 4 : 0x7ffffff0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int row = m0 + mi * 32 + 16 * (u & 1) + (e & 3) + 8 * (e >> 2);      // wave-uniform, < Cout (Cout % 64 == 0)
+            rv[slot][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vo, row * L * 4, 0));
+          }
+        }
+      };
+      res_issue(0, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int mi = u >> 2, ni = (u >> 1) & 1;
+        if (u + 1 < 8) res_issue((u + 1) & 1, u + 1);
+        const int col = l0 + ni * 32 + lcol;
+        const bool okc = col < L;
+        const int vo = okc ? (4 * lhalf * L + col) * 4 : 0x7ffffff0;
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * (u & 1) + gg;
+          const int row8 = m0 + mi * 32 + 8 * g;
+          const float* bp = bias_r + row8;          // 8 consecutive scalars
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            float o = acc[mi][ni][r] + (lhalf ? bp[4 + j] : bp[j]);
+            if constexpr (EPI == 1) o += rv[u & 1][4 * gg + j];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), yrs, vo, (row8 + j) * L * 4, 0);
+            if constexpr (EPI == 0) {
+              const float oz = okc ? o : 0.f;
+              s += oz;
+              q = fmaf(oz, oz, q);
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(acc[mi][0]), "v"(acc[mi][1]));
+    }
+    if (EPI == 0 && a.out_sums) {
+      const double ds = srf_dpp_wave_sum((double)s), dq = srf_dpp_wave_sum((double)q);
+      if (lane == 63) {
+        double* dst = srf_stat_slot(a.out_sums, b, (long)v * 32 + wave);
+        atomicAdd(dst, ds);
+        atomicAdd(dst + 1, dq);
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    if constexpr (TL) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tl_epi += (unsigned)__builtin_amdgcn_s_memtime() - tl_e0;
+    }
+    cur = nxc;
+    tc = tn;
+    if (i + 2 < ntile) {
+      cur_set(nxc, i + 2);
+      tn = make_tile(nxc);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus DMA of the pipeline tail must not outlive the block's LDS
+  if constexpr (TL) {
+    unsigned* out = reinterpret_cast<unsigned*>(const_cast<float*>(a.mul)) + ((size_t)blockIdx.x * 8 + wave) * 8;
+    if (lane == 0) {
+      out[0] = (unsigned)__builtin_amdgcn_s_memtime() - tl_begin;
+      out[1] = tl_bar;
+      out[2] = tl_wait;
+      out[3] = tl_epi;
+      out[4] = tl_steps;
+    }
+  }
+}
+
+bool srf_x3p_supported(const PwArgs& a, int pro) {
+  if (a.Cin % 64 || a.Cin < 128 || a.Cout % 64 || a.L % 4) return false;   // (whole 64-row wavefront tiles: no row guards)
+  if ((pro == 1 || pro == 2) && a.Bt > P_MAX_STAT_EXAMPLES) return false;
+  if (a.epi_mask & 1) return false;                  // (the mask epilogue stays with the shipped kernel)
+  if (a.residual && a.out_sums) return false;
+  return true;
+}
+
+int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
+  const int nMt = (a.Cout + P_BM - 1) / P_BM, nLt = (a.L + P_BN - 1) / P_BN;
+  const long total = (long)a.Bt * nMt * nLt;
+  SRF_CHECK_ARG(total < (1L << 30), "srf_pw_conv: too many tiles");
+  SRF_CHECK_ARG(srf_x3p_supported(a, pro), "srf_pw_conv: shape not served by the paired 256 x 128 kernel");
+  const long ok = srf_device_cached(6, [](void*) -> long {
+    bool good = true;
+    const void* fns[] = {(const void*)&srf_pw_x3p_kernel<0, 0>, (const void*)&srf_pw_x3p_kernel<1, 0>,
+                         (const void*)&srf_pw_x3p_kernel<2, 0>, (const void*)&srf_pw_x3p_kernel<3, 0>,
+                         (const void*)&srf_pw_x3p_kernel<0, 1>, (const void*)&srf_pw_x3p_kernel<1, 1>,
+                         (const void*)&srf_pw_x3p_kernel<2, 1>, (const void*)&srf_pw_x3p_kernel<3, 1>,
+                         (const void*)&srf_pw_x3p_kernel<0, 0, 1>, (const void*)&srf_pw_x3p_kernel<2, 1, 1>,
+                         (const void*)&srf_pw_x3p_kernel<0, 0, 0, 1>, (const void*)&srf_pw_x3p_kernel<2, 1, 0, 1>};
+    for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES) == hipSuccess;
+    return good ? 1 : 0;
+  }, nullptr);
+  SRF_CHECK_ARG(ok == 1, "srf_pw_conv: cannot reserve %d bytes of LDS", P_LDS_BYTES);
+  long nb = 2L * srf_device_cus();
+  if (const char* e = getenv("SRF_X3P_BLOCKS")) nb = atol(e) > 0 ? atol(e) : nb;
+  nb -= nb % 8;
+  if (nb > total) nb = total;
+  dim3 grid((unsigned)nb), block(512);
+  const bool res = a.residual != nullptr;
+  const int abl = getenv("SRF_X3W_ABL") ? atoi(getenv("SRF_X3W_ABL")) : 0;
+#define P_GO(...) hipLaunchKernelGGL((srf_pw_x3p_kernel<__VA_ARGS__>), grid, block, P_LDS_BYTES, st, a, wpack, nMt, nLt, (int)total, a.nrm.gamma, a.nrm.beta, a.bias, abl)
+  const bool tl = getenv("SRF_X3S_TL") && atoi(getenv("SRF_X3S_TL")) && a.mul;
+  if (tl && pro == 0 && !res) {
+    P_GO(0, 0, 0, 1);
+  } else if (tl && pro == 2 && res) {
+    P_GO(2, 1, 0, 1);
+  } else if (abl && pro == 0 && !res) {
+    P_GO(0, 0, 1);
+  } else if (abl && pro == 2 && res) {
+    P_GO(2, 1, 1);
+  } else if (!res) {
+    switch (pro) {
+      case 0: P_GO(0, 0); break;
+      case 1: P_GO(1, 0); break;
+      case 2: P_GO(2, 0); break;
+      default: P_GO(3, 0); break;
+    }
+  } else {
+    switch (pro) {
+      case 0: P_GO(0, 1); break;
+      case 1: P_GO(1, 1); break;
+      case 2: P_GO(2, 1); break;
+      default: P_GO(3, 1); break;
+    }
+  }
+#undef P_GO
+  static const char* const kLabel[4] = {"pw_conv_x3w<0>", "pw_conv_x3w<1>", "pw_conv_x3w<2>", "pw_conv_x3w<3>"};
+  SRF_CHECK_LAUNCH(kLabel[pro < 0 || pro > 3 ? 3 : pro], st);
+  return SRF_OK;
+}

@@ -213,7 +213,7 @@ bool srf_x3w_shape_supported(int Cin, int Cout, int L);
 size_t srf_x3w_packed_bytes(int Cout, int Cin);
 int srf_x3w_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
 #ifdef SRF_EXPERIMENTS
-// Round-4 GEMM experiments (csrc/experiments/, SRF_BUILD_EXPERIMENTS=1 builds only; selected with SRF_GEMM=x3s | x3t; both
+// Round-4 GEMM experiments (csrc/experiments/, SRF_BUILD_EXPERIMENTS=1 builds only; selected with SRF_GEMM=x3s | x3t | x3p; all
 // bit-identical to the shipped kernel): wavefronts split by role / one SIMD reserved for memory work.  In such a build a packed
 // weight buffer holds TWO images: [x3w image | x3t image].
 int srf_pw_x3s_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
@@ -222,6 +222,8 @@ int srf_pw_x3t_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
 bool srf_x3t_supported(int Bt, int Cin, int pro);
 size_t srf_x3t_packed_bytes(int Cout, int Cin);
 int srf_x3t_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
+int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);   // two co-resident blocks per CU (x3t's image)
+bool srf_x3p_supported(const PwArgs& a, int pro);
 #endif
 static int srf_pw_256_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
 #ifdef SRF_EXPERIMENTS
@@ -230,6 +232,8 @@ static int srf_pw_256_launch(const PwArgs& a, const char* wpack, int pro, hipStr
   if (sel && sel[0] == 'x' && sel[2] == 't' && srf_x3t_supported(a.Bt, a.Cin, pro) &&
       (long)a.Bt * ((a.Cout + 255) / 256) * ((a.L + 191) / 192) >= srf_device_cus())
     return srf_pw_x3t_launch(a, wpack + srf_x3w_packed_bytes(a.Cout, a.Cin), pro, st);
+  if (sel && sel[0] == 'x' && sel[2] == 'p' && srf_x3p_supported(a, pro))
+    return srf_pw_x3p_launch(a, wpack + srf_x3w_packed_bytes(a.Cout, a.Cin), pro, st);
 #endif
   return srf_pw_x3w_launch(a, wpack, pro, st);
 }

@@ -28,6 +28,7 @@ struct WgArgs {
   int M, N, L, Bt;
   int kc_len, nKc, P;  // time-chunk length (multiple of 32), chunks per example, partials
   int nMt, nNt;
+  int xcd_map;         // block -> (tile, partial) mapping that puts ALL output tiles of a partial on one XCD (P % 8 == 0)
 };
 
 __device__ __forceinline__ void wg_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
@@ -47,7 +48,20 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_kernel(WgArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int ntiles = a.nMt * a.nNt;
-  const int tile = blockIdx.x % ntiles, p = blockIdx.x / ntiles;
+  // Every output tile of partial p streams the SAME (example, time-chunk) pieces: G rows are shared by the nNt tiles of an
+  // m-tile, X rows by the nMt tiles of an n-tile.  Blocks go to XCDs round-robin by blockIdx, so the round-3 mapping
+  // (tile = blockIdx % ntiles; with 8 tiles: tile t lives on XCD t) made every XCD read its rows through its own L2 -- the
+  // operands crossed the fabric (nNt M + nMt N) / (M + N) times: 2.7 x for 256 x 512.  Round 4: XCD x
+  // owns the partials p = x (mod 8), its co-resident blocks walk the tiles of one partial together, and the re-reads hit L2.
+  int tile, p;
+  if (a.xcd_map) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % ntiles;
+    p = (j / ntiles) * 8 + xcd;
+  } else {
+    tile = blockIdx.x % ntiles;
+    p = blockIdx.x / ntiles;
+  }
   const int m0 = (tile % a.nMt) * WG_BM, n0 = (tile / a.nMt) * WG_BN;
   const int L = a.L, M = a.M, N = a.N;
   const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
@@ -358,6 +372,7 @@ static int wg_pick_partials(int ntiles, int nchunks) {
   int P = (2 * 256 + ntiles - 1) / ntiles;   // one resident wave of blocks (2 per CU): fewer, longer partials
   if (P > nchunks) P = nchunks;
   if (P > 128) P = 128;
+  if (P >= 8) P &= ~7;                       // a multiple of the XCD count (the kernel's xcd_map)
   if (P < 1) P = 1;
   return P;
 }
@@ -369,6 +384,7 @@ static void wg_geometry(int M, int N, int L, int Bt, WgArgs* a) {
   if (a->kc_len > L) a->kc_len = (L + 31) / 32 * 32;
   a->nKc = (L + a->kc_len - 1) / a->kc_len;
   a->P = wg_pick_partials(a->nMt * a->nNt, Bt * a->nKc);
+  a->xcd_map = (a->P % 8 == 0 && !(srf_debug_flags() & 4096)) ? 1 : 0;
 }
 
 extern "C" size_t srf_pw_wgrad_scratch_bytes(int Bt, int Cout, int Cin, int L) {

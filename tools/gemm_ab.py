@@ -2,7 +2,7 @@
 """Same-process interleaved A/B of the 256 x 128 split-bf16 GEMM variants on the model's launch shapes (cfg 2, cfg 4, cfg 5):
 rounds of N launches per variant, variants interleaved, median / min us per launch, outputs compared bit for bit.
 
-    python tools/gemm_ab.py [name=debug_flags[:abl[:gemm]] ...]    default: x3w=0 x3t=0:0:x3t   (abl / gemm: lab builds only -- SRF_BUILD_EXPERIMENTS=1, SRF_LIB=.../libsudormrf_hip_lab.so)
+    python tools/gemm_ab.py [name=debug_flags[:abl[:gemm[:blocks]]] ...]    default: x3w=0 x3t=0:0:x3t   (abl / gemm: lab builds only -- SRF_BUILD_EXPERIMENTS=1, SRF_LIB=.../libsudormrf_hip_lab.so)
     GEMM_SHAPES=res_conv,proj_1x1 GEMM_ROUNDS=7 GEMM_ITERS=20"""
 import json
 import os
@@ -25,6 +25,9 @@ SHAPES = {  # name: (Bt, Cin, Cout, L, prologue, epilogue)
     "cfg4_bottleneck": (32, 2048, 512, 3200, 1, "sums"),
     "cfg5_res_conv": (16, 512, 512, 12800, 2, "residual"),
     "cfg5_mask": (16, 512, 8192, 12800, 3, "mask"),
+    # tile counts that are whole multiples of 256 and 512 (no leftover round: steady-state comparison of kernel forms)
+    "proj_4096": (32, 256, 512, 4096, 0, "sums"),
+    "res_conv_4096": (32, 512, 256, 4096, 2, "residual"),
 }
 
 
@@ -35,10 +38,11 @@ def main():
     class _Flags:   # debug flags + the SRF_X3W_ABL environment switch of the experimental instantiations
         @staticmethod
         def set(spec):
-            f, abl, gemm = (spec.split(":") + ["", ""])[:3]
+            f, abl, gemm, blocks = (spec.split(":") + ["", "", ""])[:4]
             ops.set_debug_flags(int(f))
             os.environ["SRF_X3W_ABL"] = abl or "0"
             os.environ["SRF_GEMM"] = gemm           # "x3s": the role-split kernel (srf_pwconv_x3s.hip)
+            os.environ["SRF_X3P_BLOCKS"] = blocks or "0"     # x3p: persistent blocks (default 2 per CU)
 
     only = os.environ.get("GEMM_SHAPES")
     rounds, iters = int(os.environ.get("GEMM_ROUNDS", "5")), int(os.environ.get("GEMM_ITERS", "10"))
@@ -65,13 +69,21 @@ def main():
         kw["packed"] = ops.pack_pw_weight(w)
         ref, times = None, {n: [] for n, _ in variants}
         same = {}
+        ref_sums = None
         for n, f in variants:
             _Flags.set(f)
+            if "out_sums" in kw:
+                kw["out_sums"] = ops.new_sums(Bt, DEV)
             y = ops.pw_conv(x, w, bias, **kw)
             torch.cuda.synchronize()
             if ref is None:
                 ref = y
             same[n] = bool(torch.equal(y, ref))
+            if "out_sums" in kw:        # the statistics epilogue: bucket totals against the first variant's (fp32 partial sums: ~1e-6)
+                tot = kw["out_sums"].sum(dim=1)
+                if ref_sums is None:
+                    ref_sums = tot
+                same[n] = same[n] and bool(torch.allclose(tot, ref_sums, rtol=1e-5, atol=1e-3))
             del y
         for _ in range(rounds):
             for n, f in variants:

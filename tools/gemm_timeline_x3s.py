@@ -31,7 +31,8 @@ for name, (Bt, Cin, Cout, L, pro, res) in SHAPES.items():
         norm = ops._norm(sums, gamma, beta, slope)
     resid = torch.randn(Bt, Cout, L, generator=g, device=DEV) if res else None
     osums = None if res else ops.new_sums(Bt, DEV)
-    trace = torch.zeros(256 * 12 * 8, dtype=torch.int32, device=DEV)
+    NB, NW = (512, 8) if GEMM == "x3p" else (256, 12)
+    trace = torch.zeros(NB * NW * 8, dtype=torch.int32, device=DEV)
 
     def run():
         rc = lib.srf_pw_conv_packed(_lib.ptr(x), _lib.ptr(w), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(y), Bt, Cin, Cout, L,
@@ -51,9 +52,10 @@ for name, (Bt, Cin, Cout, L, pro, res) in SHAPES.items():
         e1.record()
         torch.cuda.synchronize()
         us[tl] = e0.elapsed_time(e1) * 100
-    t = trace.cpu().numpy().view(np.uint32).reshape(256, 12, 8).astype(np.float64)
+    t = trace.cpu().numpy().view(np.uint32).reshape(NB, NW, 8).astype(np.float64)
     print("== %s: %.1f us plain, %.1f us instrumented" % (name, us["0"], us["1"]))
     roles = ((("multiply", [0, 1, 2, 3, 4, 5, 6, 7]), ("stage X ", [8, 9]), ("DMA     ", [10, 11])) if GEMM == "x3s" else
+             (("all     ", [0, 1, 2, 3, 4, 5, 6, 7]),) if GEMM == "x3p" else
              (("multiply", [0, 1, 2, 4, 5, 6]), ("loaders ", [3, 7])))
     for role, sl in roles:
         r = t[:, sl, :].reshape(-1, 8)

@@ -77,6 +77,7 @@ def main():
     cnt = C.c_int(0)
     _lib.check(lib.srf_profile_end(stream, C.byref(cnt)), "srf_profile_end")
     per = {}
+    seq = {}
     nm, ms = C.c_char_p(), C.c_float()
     for i in range(cnt.value):
         lib.srf_profile_get(i, C.byref(nm), C.byref(ms))
@@ -85,6 +86,15 @@ def main():
         e = per.setdefault(nm.value.decode(), [0.0, 0])
         e[0] += ms.value
         e[1] += 1
+        seq.setdefault(nm.value.decode(), []).append(ms.value * 1e3)
+    # TRAIN_SEQ="family:period,...": the family's launches in order, averaged by position within a period (e.g. the five
+    # depthwise-backward launches of a U-ConvBlock: "dwconv5_bwd:5") -- to stderr
+    for item in filter(None, os.environ.get("TRAIN_SEQ", "").split(",")):
+        fam, period = item.split(":")
+        v, period = seq.get(fam, []), int(period)
+        pos = [[x for j, x in enumerate(v) if j % period == k] for k in range(period)]
+        print("%s (%d launches) us by position: %s" % (fam, len(v), "  ".join("%.1f" % (sum(q) / max(len(q), 1)) for q in pos)),
+              file=sys.stderr)
     plan = model._engine().last_plan
     saved, scratch = plan.train_sizes()
     out = {"workload": "%s training step, batch %d, T=%d" % (name, batch, T), "ms_per_step": dt * 1e3,
