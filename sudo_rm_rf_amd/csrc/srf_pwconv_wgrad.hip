@@ -333,18 +333,40 @@ __global__ __launch_bounds__(256) void srf_wgrad_reduce_kernel(const float* __re
 
 // The weight AND the bias partials of one wgrad in one launch (round 3: the separate bias reduction was a 12-us launch for
 // 256-512 sums): threads [0, rows * cols_out) fold dW as srf_wgrad_reduce_kernel does, the next `rows` threads the bias.
+// (round 4: four consecutive columns per thread -- float4 loads of the partials, four independent chains -- when the row
+// lengths allow it; V = 1 is the scalar form.  cfg 2: 21 -> see profiles/r04_NOTES.md)
+template <int V>
 __global__ __launch_bounds__(256) void srf_wgrad_reduce2_kernel(const float* __restrict__ part, float* __restrict__ out, int rows,
                                                                 int cols, int cols_out, int ld_out,
                                                                 const float* __restrict__ bias_part, float* __restrict__ bias_out,
                                                                 int P, float beta) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long nw = (long)rows * cols_out;
+  const int cv = cols_out / V;
+  const long nw = (long)rows * cv;
   if (i < nw) {
-    const int m = (int)(i / cols_out), n = (int)(i - (long)m * cols_out);
+    const int m = (int)(i / cv), n = (int)(i - (long)m * cv) * V;
     const size_t src = (size_t)m * cols + n, stride = (size_t)rows * cols, dst = (size_t)m * ld_out + n;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(size_t)p * stride + src];
-    out[dst] = beta != 0.f ? fmaf(beta, out[dst], s) : s;
+    if constexpr (V == 4) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+      for (int p = 0; p < P; ++p) {
+        const float4 t = *reinterpret_cast<const float4*>(part + (size_t)p * stride + src);
+        s.x += t.x;
+        s.y += t.y;
+        s.z += t.z;
+        s.w += t.w;
+      }
+      float4* o = reinterpret_cast<float4*>(out + dst);
+      if (beta != 0.f) {
+        const float4 c = *o;
+        s = make_float4(fmaf(beta, c.x, s.x), fmaf(beta, c.y, s.y), fmaf(beta, c.z, s.z), fmaf(beta, c.w, s.w));
+      }
+      *o = s;
+    } else {
+      float s = 0.f;
+      for (int p = 0; p < P; ++p) s += part[(size_t)p * stride + src];
+      out[dst] = beta != 0.f ? fmaf(beta, out[dst], s) : s;
+    }
   } else if (i < nw + rows) {
     const int m = (int)(i - nw);
     float s = 0.f;
@@ -463,9 +485,14 @@ extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* i
   }
   int rc;
   if (dbias && !(a.P >= 64 && (long)Cout * dw_cols * 4 <= 65536)) {   // (large outputs: no partial split, one launch for both)
-    const long n = (long)Cout * dw_cols + Cout;
-    hipLaunchKernelGGL(srf_wgrad_reduce2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin, dw_cols,
-                       dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
+    const bool v4 = (Cin % 4 == 0) && (dw_cols % 4 == 0) && (dw_ld % 4 == 0) && srf_aligned16(a.part) && srf_aligned16(dw);
+    const long n = (long)Cout * (dw_cols / (v4 ? 4 : 1)) + Cout;
+    if (v4)
+      hipLaunchKernelGGL(srf_wgrad_reduce2_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin,
+                         dw_cols, dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
+    else
+      hipLaunchKernelGGL(srf_wgrad_reduce2_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin,
+                         dw_cols, dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
   } else {
     rc = wg_reduce_launch(a.part, dw, Cout, Cin, dw_cols, dw_ld, a.P, accumulate, st);
     if (rc) return rc;
