@@ -417,6 +417,9 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
   SRF_CHECK_HIP(hipMemsetAsync(zeros, 0, sizeof(float) * zmax, st));
   // the blocks' norm / conv backwards get one scratch slice per call (statistic buckets zeroed here, once) and leave their
   // parameter-gradient reductions to one batched flush after the block loop
+  // (the WHOLE arena, 75 MB at cfg 2 / 170 MB at cfg 4 = 0.1 % of a step, not just the fp64 buckets at the head of each norm slice
+  // -- the chunked fallback kernels (debug flags 1<<29 / 1<<30, rows beyond the row kernels' limits) accumulate
+  // their row partials with atomicAdd and rely on zeroed slices)
   SRF_CHECK_HIP(hipMemsetAsync(sc + s.arena, 0, s.arena_bytes, st));
   srf_defer_clear();
   struct DeferOff {
