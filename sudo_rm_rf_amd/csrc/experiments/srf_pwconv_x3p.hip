@@ -40,8 +40,13 @@ __device__ __forceinline__ int p_swz(int r, int c) { return r * 64 + ((c ^ ((r >
 template <int PRO, int EPI, int ABL = 0, int TL = 0>
 __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt, int total,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const float* __restrict__ bias_r, int rabl_arg) {
+                                                            const float* __restrict__ bias_r, int rabl_arg, int stagger) {
   const int rabl = ABL ? rabl_arg : 0;
+  // Two blocks share a CU and run tiles of equal length: left alone they reach their epilogues together.  The blocks of the
+  // grid's second half (the ones the dispatcher places as second residents) start `stagger` x ~8 K cycles late, so that one
+  // block's epilogue (stores, residual loads) falls into the other's k-loop.
+  if (blockIdx.x >= (gridDim.x >> 1))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -414,7 +419,8 @@ int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   dim3 grid((unsigned)nb), block(512);
   const bool res = a.residual != nullptr;
   const int abl = getenv("SRF_X3W_ABL") ? atoi(getenv("SRF_X3W_ABL")) : 0;
-#define P_GO(...) hipLaunchKernelGGL((srf_pw_x3p_kernel<__VA_ARGS__>), grid, block, P_LDS_BYTES, st, a, wpack, nMt, nLt, (int)total, a.nrm.gamma, a.nrm.beta, a.bias, abl)
+  const int stagger = getenv("SRF_X3P_STAGGER") ? atoi(getenv("SRF_X3P_STAGGER")) : 0;
+#define P_GO(...) hipLaunchKernelGGL((srf_pw_x3p_kernel<__VA_ARGS__>), grid, block, P_LDS_BYTES, st, a, wpack, nMt, nLt, (int)total, a.nrm.gamma, a.nrm.beta, a.bias, abl, stagger)
   const bool tl = getenv("SRF_X3S_TL") && atoi(getenv("SRF_X3S_TL")) && a.mul;
   if (tl && pro == 0 && !res) {
     P_GO(0, 0, 0, 1);

@@ -319,6 +319,32 @@ def test_pw_conv_three_part_split(Bt, Cin, Cout, L, pro, parts):
         assert torch.allclose(tot, ref, rtol=1e-5, atol=1e-6 * got[0].numel())
 
 
+def test_pw_conv_fp16_split_clamps_instead_of_overflowing():
+    """The training forward's default GEMM splits operands into fp16 parts: values beyond fp16's range are clamped to +-6e4
+    (finite, wrong by the clamp only) -- never inf / NaN; debug flag 16384 (three bf16 parts) has no such limit and stays
+    exact.  (No model of ours comes within 100 x of that magnitude; this pins the documented behaviour.)"""
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+    Bt, Cin, Cout, L = 8, 256, 256, 3200
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(Bt, Cin, L, generator=g, device=DEV)
+    x[0, 5, 17] = 3.0e5
+    x[1, 9, 100] = -2.5e5
+    w = torch.randn(Cout, Cin, 1, generator=g, device=DEV) * Cin ** -0.5
+    bias = torch.zeros(Cout, device=DEV)
+    want = torch.einsum("mk,bkl->bml", w[:, :, 0].double(), x.double())
+    got = ops.pw_conv3(x, w, bias, ops.pack3_pw_weight(w))
+    assert torch.isfinite(got).all()
+    clamped = torch.einsum("mk,bkl->bml", w[:, :, 0].double(), x.double().clamp(-6.0e4, 6.0e4))
+    assert float((got.double() - clamped).abs().max()) <= 1e-5 * float(clamped.abs().max())
+    try:
+        ops.set_debug_flags(16384)
+        exact = ops.pw_conv3(x, w, bias, ops.pack3_pw_weight(w))
+    finally:
+        ops.set_debug_flags(0)
+    assert float((exact.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
 # (Bt, Cin, Cout, L, prologue, epilogue): the GEMMs of BASELINE cfg 4 / cfg 5 AT BENCH BATCH that no golden reaches
 # (VERDICT r2 weak 1): bottleneck K = 2048 / 4096 (64 / 128 k-tiles), proj_1x1 / res_conv at 512 -> 512 (two M tiles,
 # statistics epilogue / residual epilogue), cfg 5's mask GEMM (Cout = S N = 8192: 32 M tiles, ReLU x encoder epilogue)

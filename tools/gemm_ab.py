@@ -38,7 +38,8 @@ def main():
     class _Flags:   # debug flags + the SRF_X3W_ABL environment switch of the experimental instantiations
         @staticmethod
         def set(spec):
-            f, abl, gemm, blocks = (spec.split(":") + ["", "", ""])[:4]
+            f, abl, gemm, blocks, stagger = (spec.split(":") + ["", "", "", ""])[:5]
+            os.environ["SRF_X3P_STAGGER"] = stagger or "0"   # x3p: start-up delay of the grid's second half (units of ~8 K cycles)
             ops.set_debug_flags(int(f))
             os.environ["SRF_X3W_ABL"] = abl or "0"
             os.environ["SRF_GEMM"] = gemm           # "x3s": the role-split kernel (srf_pwconv_x3s.hip)
