@@ -325,7 +325,7 @@ def test_pw_conv_fp16_split_clamps_instead_of_overflowing():
     exact.  (No model of ours comes within 100 x of that magnitude; this pins the documented behaviour.)"""
     from sudo_rm_rf_amd import ops
     ops.set_kernel_mode(0)
-    Bt, Cin, Cout, L = 8, 256, 256, 3200
+    Bt, Cin, Cout, L = 16, 256, 256, 3200          # 400 tiles: served by the 256 x 128 kernel (asserted below)
     g = torch.Generator(device=DEV).manual_seed(3)
     x = torch.randn(Bt, Cin, L, generator=g, device=DEV)
     x[0, 5, 17] = 3.0e5
@@ -333,7 +333,10 @@ def test_pw_conv_fp16_split_clamps_instead_of_overflowing():
     w = torch.randn(Cout, Cin, 1, generator=g, device=DEV) * Cin ** -0.5
     bias = torch.zeros(Cout, device=DEV)
     want = torch.einsum("mk,bkl->bml", w[:, :, 0].double(), x.double())
-    got = ops.pw_conv3(x, w, bias, ops.pack3_pw_weight(w))
+    packed = ops.pack3_pw_weight(w)
+    with ops.kernel_trace(DEV) as tr:
+        got = ops.pw_conv3(x, w, bias, packed)
+    assert tr.names == {"pw_conv_x3w4<0>"}, tr.names
     assert torch.isfinite(got).all()
     clamped = torch.einsum("mk,bkl->bml", w[:, :, 0].double(), x.double().clamp(-6.0e4, 6.0e4))
     assert float((got.double() - clamped).abs().max()) <= 1e-5 * float(clamped.abs().max())
