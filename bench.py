@@ -349,6 +349,8 @@ def pmc_traffic(kernel_family, workload, train=False):
         key, must = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3w3<"):-1], ", %s>" % kernel_family[11]
     if kernel_family.startswith("pw_conv_x3w<"):             # family "pw_conv_x3w<2>" = every cache-policy instantiation of "srf_pw_x3w_kernel<2, ..."
         key = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3w<"):-1]
+    if kernel_family.startswith("pw_conv_x3p<"):             # the paired-block form: "srf_pw_x3p_kernel<k, e, 0, 0>"
+        key = "srf_pw_x3p_kernel<%s," % kernel_family[len("pw_conv_x3p<"):-1]
     if kernel_family.startswith("pw_conv_bf16x3_p8<"):       # one label per prologue variant = one rocprof kernel name
         key = "srf_pw_bf16x3_p8_kernel<%s," % kernel_family[len("pw_conv_bf16x3_p8<"):-1]
     fetch, write = {}, {}
@@ -807,7 +809,7 @@ def main():
             # Two ceilings for a 1x1-conv GEMM: the matrix pipe (fp32-equivalent FLOPs; the split-precision kernels issue 3
             # bf16 MFMAs per product block, so their peak is the bf16 dense peak / 3) and HBM (algorithmic bytes).  The
             # BINDING one -- the larger time floor -- is reported as the roofline, the other beside it.
-            split = dom.startswith("pw_conv_bf16x3") or dom.startswith("pw_conv_x3w")
+            split = dom.startswith(("pw_conv_bf16x3", "pw_conv_x3w", "pw_conv_x3p"))
             peak = roofline.MFMA_BF16_PEAK_TFLOPS / 3 if split else roofline.MFMA_F32_PEAK_TFLOPS
             mfma = {"bound": "mfma", "achieved": kd["TFLOPs"], "peak": peak, "unit": "TFLOP/s", "frac": kd["TFLOPs"] / peak,
                     "note": ("algorithmic fp32 FLOPs (2*Cin*Cout per output); peak = bf16 dense MFMA peak / 3 because "

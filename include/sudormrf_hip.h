@@ -113,9 +113,12 @@ int srf_profile_get(int i, const char** name, float* ms);
  *   256      leftover GEMM tiles as whole tiles (no quarter tiles) 512       quarter tiles last
  *   1024     TAC forward with one time step per lane               2048      one-tile-per-block 128 x 128 GEMM everywhere
  *                                                                            (also: no 64 x 64 tiles for small launches)
+ *   4096     weight-gradient GEMM: round 3's block -> (tile, partial) mapping (every XCD re-reads its rows through its own L2)
+ *   8192     swap the two forms of the 256 x 128 GEMM: srf_forward / srf_separate run the one-block-per-CU kernel (srf_pwconv_x3w.hip),
+ *            every other caller the paired-block kernel (srf_pwconv_x3p.hip) -- default: the paired form inside the forward only
  *   16384    training forward: three bf16 parts per operand (6 MFMAs, round 3) instead of two fp16 parts (3 MFMAs, round 4)
  *   32768    WITHOUT the fused tail: mask GEMM -> masked tensor -> decoder frame GEMM -> overlap-add as separate launches
- *   bits 12-13, 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating; the GEMM's
+ *   bits 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating; the GEMM's
  *            only in lab builds: SRF_BUILD_EXPERIMENTS=1 python -m sudo_rm_rf_amd.build -> libsudormrf_hip_lab.so)
  *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
  *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)

@@ -12,17 +12,17 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libsudormrf_hip.so")
-SOURCES = ["srf_api.hip", "srf_encoder.hip", "srf_elementwise.hip", "srf_dwconv.hip", "srf_pyramid.hip", "srf_pyramid_reg.hip", "srf_pwconv.hip", "srf_pwconv_bf16x3.hip", "srf_pwconv_x3w.hip", "srf_pwconv_w4.hip", "srf_pwconv_small.hip",
+SOURCES = ["srf_api.hip", "srf_encoder.hip", "srf_elementwise.hip", "srf_dwconv.hip", "srf_pyramid.hip", "srf_pyramid_reg.hip", "srf_pwconv.hip", "srf_pwconv_bf16x3.hip", "srf_pwconv_x3w.hip", "srf_pwconv_x3p.hip", "srf_pwconv_w4.hip", "srf_pwconv_small.hip",
            "srf_tac.hip", "srf_loss.hip", "srf_pwconv_wgrad.hip", "srf_backward.hip", "srf_train.hip", "srf_augment.hip", "srf_optim.hip", "srf_feeder.hip"]
 HEADERS = [os.path.join(CSRC, "srf_common.h"), os.path.join(CSRC, "srf_pw.h"), os.path.join(CSRC, "srf_plan.h"), os.path.join(CSRC, "srf_pyr.h"),
            os.path.join(os.path.dirname(PKG), "include", "sudormrf_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 # SRF_BUILD_EXPERIMENTS=1: a LAB build -- adds the GEMM experiments of csrc/experiments/ (role-split / one-SIMD-for-memory kernels,
-# selected at run time with SRF_GEMM=x3s | x3t), the ablated instantiations of the shipped GEMM (debug flag bits 16..21,
+# selected at run time with SRF_GEMM=x3s | x3t | x3w), the ablated instantiations of the shipped GEMM (debug flag bits 16..21,
 # SRF_X3W_ABL) and its in-kernel timeline.  The default build -- what ships, what the tests and the bench load -- has none of it.
 EXPERIMENTS = os.environ.get("SRF_BUILD_EXPERIMENTS", "") not in ("", "0")
-EXPERIMENT_SOURCES = ["experiments/srf_pwconv_x3s.hip", "experiments/srf_pwconv_x3t.hip", "experiments/srf_pwconv_x3p.hip"]
+EXPERIMENT_SOURCES = ["experiments/srf_pwconv_x3s.hip", "experiments/srf_pwconv_x3t.hip"]
 if EXPERIMENTS:
     FLAGS = FLAGS + ["-DSRF_EXPERIMENTS=1"]
     LIB = os.path.join(PKG, "libsudormrf_hip_lab.so")       # its own file (load it with SRF_LIB=...): never the product library
@@ -36,7 +36,7 @@ FILE_FLAGS = {
     "srf_pwconv_x3w.hip": ["-fno-slp-vectorize"],
     "experiments/srf_pwconv_x3s.hip": ["-fno-slp-vectorize"],
     "experiments/srf_pwconv_x3t.hip": ["-fno-slp-vectorize"],
-    "experiments/srf_pwconv_x3p.hip": ["-fno-slp-vectorize"],
+    "srf_pwconv_x3p.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_w4.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_wgrad.hip": ["-fno-slp-vectorize"],
     "srf_pwconv.hip": ["-fno-slp-vectorize"],

@@ -361,7 +361,22 @@ extern "C" int srf_separate(const srf_plan* p, const float* const* P, int num_pa
   return srf_forward_impl(p, P, num_params, wav, out, workspace, workspace_bytes, stats, mixture_consistency, stream);
 }
 
+static int srf_forward_body(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
+                            void* workspace, size_t workspace_bytes, const float* wav_stats, int mixture_consistency,
+                            void* stream);
+void srf_pw_prefer_paired(bool on);   // srf_pwconv.hip: the paired-block form of the 256 x 128 GEMM for this thread's launches
 static int srf_forward_impl(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
+                            void* workspace, size_t workspace_bytes, const float* wav_stats, int mixture_consistency,
+                            void* stream) {
+  // The inference forward is what the engine runs as two sub-batches on two streams: its GEMMs take the half-CU blocks of
+  // srf_pwconv_x3p.hip so that the other stream's kernels can co-reside (srf_pwconv.hip, srf_pw_256_launch).
+  struct Paired {
+    Paired() { srf_pw_prefer_paired(true); }
+    ~Paired() { srf_pw_prefer_paired(false); }
+  } paired_for_this_call;
+  return srf_forward_body(p, P, num_params, wav, out, workspace, workspace_bytes, wav_stats, mixture_consistency, stream);
+}
+static int srf_forward_body(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
                             void* workspace, size_t workspace_bytes, const float* wav_stats, int mixture_consistency,
                             void* stream) {
   SRF_CHECK_ARG(p && P && wav && out && workspace, "srf_forward: null pointer");
@@ -391,7 +406,7 @@ static int srf_forward_impl(const srf_plan* p, const float* const* P, int num_pa
 
   rc = srf_zero_launch(stats, p->stats_bytes, st);
   if (rc) return rc;
-  // split + lay out every 1x1 weight for the 256 x 128 split-precision GEMM (srf_pwconv_x3v.hip), one launch per forward
+  // split + lay out every 1x1 weight for the 256 x 128 split-precision GEMMs (srf_pwconv_x3w.hip / _x3p.hip), one launch per form and forward
   // (kernel mode 0 only; debug flag 8 = without: the 128 x 128 kernels that split W on the fly)
   const bool use_pack = srf_kernel_mode() == 0 && !(srf_debug_flags() & 8) && !p->pk_param.empty();
   if (use_pack) {

@@ -222,19 +222,33 @@ int srf_pw_x3t_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
 bool srf_x3t_supported(int Bt, int Cin, int pro);
 size_t srf_x3t_packed_bytes(int Cout, int Cin);
 int srf_x3t_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
-int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);   // two co-resident blocks per CU (x3t's image)
-bool srf_x3p_supported(const PwArgs& a, int pro);
 #endif
+// Round 4: the paired-block form of the 256 x 128 kernel (srf_pwconv_x3p.hip: two co-resident blocks per CU; bit-identical
+// outputs).  In isolation it ties with the one-block kernel on proj_1x1 / bottleneck and loses on res_conv (127 vs 113 us) and
+// in the single-stream training step (+3.5 % / +4.5 % at cfg 2 / cfg 4); INSIDE srf_forward, whose caller runs two sub-batches
+// on two streams, its half-CU blocks let the other stream's kernels co-reside (cfg 2: 6.74 -> 6.36-6.48 ms).  So srf_forward
+// asks for it (srf_pw_prefer_paired, thread-local, scoped to the call) and every other caller -- srf_pw_conv_packed on its
+// own, the backward's data-gradient GEMMs -- keeps the one-block kernel.  Debug flag 8192 swaps the two choices (A/B, tests).
+// A packed weight buffer holds TWO images: [x3w image | x3p image] (lab builds: + the x3t image).
+int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
+bool srf_x3p_supported(const PwArgs& a, int pro);
+size_t srf_x3p_packed_bytes(int Cout, int Cin);
+int srf_x3p_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
+static thread_local int g_pw_prefer_paired = 0;
+void srf_pw_prefer_paired(bool on) { g_pw_prefer_paired = on ? 1 : 0; }      // (srf_forward: around its launches)
+static bool srf_pw_paired_wanted() { return g_pw_prefer_paired != 0; }
 static int srf_pw_256_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
+  const char* wpack_p = wpack + srf_x3w_packed_bytes(a.Cout, a.Cin);
 #ifdef SRF_EXPERIMENTS
   const char* sel = getenv("SRF_GEMM");
   if (sel && sel[0] == 'x' && sel[2] == 's' && srf_x3s_supported(a.Bt, pro)) return srf_pw_x3s_launch(a, wpack, pro, st);
   if (sel && sel[0] == 'x' && sel[2] == 't' && srf_x3t_supported(a.Bt, a.Cin, pro) &&
       (long)a.Bt * ((a.Cout + 255) / 256) * ((a.L + 191) / 192) >= srf_device_cus())
-    return srf_pw_x3t_launch(a, wpack + srf_x3w_packed_bytes(a.Cout, a.Cin), pro, st);
-  if (sel && sel[0] == 'x' && sel[2] == 'p' && srf_x3p_supported(a, pro))
-    return srf_pw_x3p_launch(a, wpack + srf_x3w_packed_bytes(a.Cout, a.Cin), pro, st);
+    return srf_pw_x3t_launch(a, wpack_p + srf_x3p_packed_bytes(a.Cout, a.Cin), pro, st);
+  if (sel && sel[0] == 'x' && sel[2] == 'w') return srf_pw_x3w_launch(a, wpack, pro, st);
 #endif
+  const bool paired = srf_pw_paired_wanted() != ((srf_debug_flags() & 8192) != 0);
+  if (paired && srf_x3p_supported(a, pro)) return srf_pw_x3p_launch(a, wpack_p, pro, st);
   return srf_pw_x3w_launch(a, wpack, pro, st);
 }
 int srf_pw_small_launch(const PwArgs& a, hipStream_t st);
@@ -408,18 +422,22 @@ int srf_pw_conv_preadd(const float* x, const float* q, const srf_norm* qnorm, fl
 extern "C" size_t srf_packed_pw_weight_bytes(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0 || !srf_x3w_shape_supported(Cin, Cout, 4)) return 0;
 #ifdef SRF_EXPERIMENTS
-  return srf_x3w_packed_bytes(Cout, Cin) + srf_x3t_packed_bytes(Cout, Cin);
+  return srf_x3w_packed_bytes(Cout, Cin) + srf_x3p_packed_bytes(Cout, Cin) + srf_x3t_packed_bytes(Cout, Cin);
 #else
-  return srf_x3w_packed_bytes(Cout, Cin);
+  return srf_x3w_packed_bytes(Cout, Cin) + srf_x3p_packed_bytes(Cout, Cin);
 #endif
 }
 static int srf_pack_both(const float* const* w, void* const* packed, const int* Cout, const int* Cin_signed, int n, hipStream_t st) {
   int rc = srf_x3w_pack_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin_signed, n, st);
-#ifdef SRF_EXPERIMENTS
   if (rc) return rc;
-  std::vector<char*> second(n);     // (experiment builds: the x3t image of every entry behind its x3w image)
+  std::vector<char*> second(n);     // the x3p image of every entry behind its x3w image
   for (int i = 0; i < n; ++i)
     second[i] = reinterpret_cast<char*>(packed[i]) + srf_x3w_packed_bytes(Cout[i], Cin_signed[i] < 0 ? -Cin_signed[i] : Cin_signed[i]);
+  rc = srf_x3p_pack_launch(w, second.data(), Cout, Cin_signed, n, st);
+#ifdef SRF_EXPERIMENTS
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i)       // (experiment builds: the x3t image behind that)
+    second[i] += srf_x3p_packed_bytes(Cout[i], Cin_signed[i] < 0 ? -Cin_signed[i] : Cin_signed[i]);
   rc = srf_x3t_pack_launch(w, second.data(), Cout, Cin_signed, n, st);
 #endif
   return rc;

@@ -1,21 +1,27 @@
-// EXPERIMENT (round 4, lab builds only: SRF_BUILD_EXPERIMENTS=1, selected with SRF_GEMM=x3p) -- the 256 x 128 split-bf16 GEMM as
-// TWO CO-RESIDENT BLOCKS PER CU (first form).
+// K2 (fast path, round 4) -- the 256 x 128 split-bf16 GEMM as TWO CO-RESIDENT BLOCKS PER CU (first form).
 //
-// The shipped kernel (srf_pwconv_x3w.hip) keeps one 512-thread block per CU (144 KB of LDS, ~240 registers): its eight wavefronts
-// convert, wait at the barrier, read fragments and multiply in lock step, so a k-step costs the SUM of those phases (profiles/
-// r04_NOTES.md: 1 536 cycles of MFMA inside ~3 800).  Here a block is half as heavy -- 16-k pipeline steps, three 24-KB stages
-// (A image 16 KB by LDS-DMA, B image 8 KB), <= 128 registers (64 accumulators, ONE fragment set, four 4-register activation sets)
-// -- so that two blocks share a CU, 4 wavefronts per SIMD, and the hardware fills one block's barrier / LDS / conversion gaps
-// with the other block's MFMAs, loads and stores.  Nothing else is clever: no fragment prefetch, no LDS strip in the epilogue
-// (dword buffer stores straight from the MFMA layout: 128-byte row segments), static round-robin tiles, whole tiles only.
-// Same arithmetic as the shipped kernel in the same order (per 16 k: lo*hi, hi*lo, hi*hi; bias, then residual): the outputs are
-// BIT-IDENTICAL; the statistics (fp64 buckets of fp32 partial sums) agree to rounding.
-// Packed weights: srf_x3t_pack_kernel's image (srf_pwconv_x3t.hip) -- per (m-tile, 16-k step) [256 rows][hi k0-7 | hi k8-15 |
-// lo k0-7 | lo k8-15], 64-byte rows, 16-byte chunks XOR-swizzled like the B image.
-// Forms: PRO 0-3 x EPI 0 (bias + statistics) | 1 (bias + residual); the mask / fused-tail GEMM stays with the shipped kernel.
+// srf_pwconv_x3w.hip keeps one 512-thread block per CU (144 KB of LDS, ~240 registers).  Here a block is half as heavy -- 16-k
+// pipeline steps, three 24-KB stages (A image 16 KB by LDS-DMA, B image 8 KB), <= 128 registers (64 accumulators, ONE fragment
+// set, four 4-register activation sets = loads four steps ahead) -- so that two blocks share a CU, 4 wavefronts per SIMD.  In
+// isolation that is a tie with the one-block kernel (profiles/r04_NOTES.md: a SIMD either issues vector-memory instructions or
+// feeds the matrix pipe, so more wavefronts add contenders, not overlap; one such block per CU: 130 us, two: 107-114, x3w:
+// 106-118).  What it buys is INSIDE THE FORWARD: the engine runs a batch as two sub-batches on two streams (DESIGN.md "Two
+// streams per forward"), and a GEMM block that owns half a CU instead of all of it lets the other stream's pyramid kernels
+// (VALU- and HBM-bound, no LDS) co-reside with it: cfg 2 6.74 -> 6.36-6.45 ms on the same box, where the one-block kernel
+// gains nothing from the split (profiles/r04_gemm_x3p_in_forward_ab.txt).
+// Nothing else is clever: no fragment prefetch, no LDS strip in the epilogue (dword buffer stores straight from the MFMA layout:
+// 128-byte row segments), static round-robin tiles, whole tiles only.
+// Same arithmetic as srf_pwconv_x3w.hip in the same order (per 16 k: lo*hi, hi*lo, hi*hi; bias, then residual): the outputs are
+// BIT-IDENTICAL to it; the statistics (fp64 buckets of fp32 partial sums) agree to rounding.
+// Packed weights (srf_x3p_pack_kernel): per (m-tile, 16-k step) [256 rows][hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15], 64-byte
+// rows, 16-byte chunks XOR-swizzled like the B image: a stage's A image is one contiguous 16-KB DMA and both operands' fragments
+// are conflict-free ds_read_b128.
+// Forms: PRO 0-3 x EPI 0 (bias + statistics) | 1 (bias + residual) -- proj_1x1, res_conv, bottleneck and the backward's
+// data-gradient GEMMs; Cout % 64 == 0.  The mask / fused-tail GEMM, the fp16-part training forward and every other shape stay
+// with srf_pwconv_x3w.hip.  Reference sites: improved_sudormrf.py:256-259, :174, :196, :220.
 #include <type_traits>
 
-#include "../srf_pw.h"
+#include "srf_pw.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -33,9 +39,63 @@ __device__ __forceinline__ int p_swz(int r, int c) { return r * 64 + ((c ^ ((r >
 
 #define P_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
-// ABL (diagnostics): the instantiation that obeys the run-time mask `rabl` (results wrong): 1 = no epilogue, 2 = no MFMAs, 4 = no
+// ---- packed weights ------------------------------------------------------------------------------------------------------
+struct PPackEntry {
+  const float* w;
+  char* dst;
+  int Cout, Cin;     // Cin < 0: w is [|Cin|][Cout] and the image is that of its transpose (the backward's data-gradient GEMMs)
+};
+constexpr int SRF_P_MAX_PACK = 48;
+struct PPackTable {
+  PPackEntry e[SRF_P_MAX_PACK];
+};
+__global__ __launch_bounds__(256) void srf_x3p_pack_kernel(PPackTable t) {
+  PPackEntry e = t.e[blockIdx.y];
+  const bool trans = e.Cin < 0;
+  e.Cin = trans ? -e.Cin : e.Cin;
+  const int nKt = e.Cin / P_KT;
+  const int nMt = (e.Cout + P_BM - 1) / P_BM;
+  const long total = (long)nMt * nKt * P_BM * 2;   // one thread per (row, 8-k packet): both parts
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int c = (int)(id & 1);
+    const int row = (int)((id >> 1) % P_BM);
+    const long tile = (id >> 1) / P_BM;
+    const int kt = (int)(tile % nKt), mt = (int)(tile / nKt);
+    const int m = mt * P_BM + row;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kt * P_KT + c * 8 + j;
+      const float v = (m < e.Cout) ? (trans ? e.w[(size_t)k * e.Cout + m] : e.w[(size_t)m * e.Cin + k]) : 0.f;
+      const __bf16 h = (__bf16)v;
+      hi[j] = h;
+      lo[j] = (__bf16)(v - (float)h);
+    }
+    char* base = e.dst + (size_t)tile * P_A_IMG;
+    *reinterpret_cast<bf16x8*>(base + p_swz(row, c)) = hi;
+    *reinterpret_cast<bf16x8*>(base + p_swz(row, 2 + c)) = lo;
+  }
+}
+size_t srf_x3p_packed_bytes(int Cout, int Cin) {
+  return (size_t)((Cout + P_BM - 1) / P_BM) * (size_t)(Cin / P_KT) * (size_t)P_A_IMG;
+}
+int srf_x3p_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {
+  for (int base = 0; base < n; base += SRF_P_MAX_PACK) {
+    PPackTable t;
+    const int cnt = (n - base) < SRF_P_MAX_PACK ? (n - base) : SRF_P_MAX_PACK;
+    for (int i = 0; i < SRF_P_MAX_PACK; ++i) {
+      const int j = base + (i < cnt ? i : 0);
+      t.e[i] = PPackEntry{w[j], dst[j], Cout[j], Cin[j]};
+    }
+    hipLaunchKernelGGL(srf_x3p_pack_kernel, dim3(64, cnt), dim3(256), 0, st, t);
+    SRF_CHECK_LAUNCH("pack_pw_weights", st);
+  }
+  return SRF_OK;
+}
+
+// ABL (diagnostics, lab builds only): the instantiation that obeys the run-time mask `rabl` (results wrong): 1 = no epilogue, 2 = no MFMAs, 4 = no
 // weight DMA, 8 = no activation loads / conversion / ds_write, 16 = no fragment reads, 32 = no barriers.
-// TL (diagnostics, results stay correct): per-wavefront shader-clock totals {whole kernel, counted waits, barriers, epilogues,
+// TL (diagnostics, lab builds only; results stay correct): per-wavefront shader-clock totals {whole kernel, counted waits, barriers, epilogues,
 // steps} as 8 dwords per wavefront to `a.mul` (tools/gemm_timeline_x3s.py with TL_GEMM=x3p).
 template <int PRO, int EPI, int ABL = 0, int TL = 0>
 __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt, int total,
@@ -298,7 +358,7 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
     asm volatile("" : "+v"(lane_o));     // (keeps the offsets below from being hoisted out of the tile loop and spilled)
     const int lhalf = lane_o >> 5, lcol = lane_o & 31;
     float s = 0.f, q = 0.f;
-    if (!(ABL && (rabl & 1))) {
+    if (!(ABL && (rabl & 1)) && m0 < a.Cout) {      // (Cout % 64 == 0: a wavefront's 64 rows are in range together or not at all)
       __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * a.Cout * L, 0, a.Cout * L * 4, 0x00020000);
       __amdgpu_buffer_rsrc_t rrs = yrs;
       if constexpr (EPI == 1)
@@ -345,7 +405,7 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
           }
         }
       }
-    } else {
+    } else if (ABL) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(acc[mi][0]), "v"(acc[mi][1]));
     }
@@ -406,21 +466,28 @@ int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
                          (const void*)&srf_pw_x3p_kernel<2, 0>, (const void*)&srf_pw_x3p_kernel<3, 0>,
                          (const void*)&srf_pw_x3p_kernel<0, 1>, (const void*)&srf_pw_x3p_kernel<1, 1>,
                          (const void*)&srf_pw_x3p_kernel<2, 1>, (const void*)&srf_pw_x3p_kernel<3, 1>,
+#ifdef SRF_EXPERIMENTS
                          (const void*)&srf_pw_x3p_kernel<0, 0, 1>, (const void*)&srf_pw_x3p_kernel<2, 1, 1>,
-                         (const void*)&srf_pw_x3p_kernel<0, 0, 0, 1>, (const void*)&srf_pw_x3p_kernel<2, 1, 0, 1>};
+                         (const void*)&srf_pw_x3p_kernel<0, 0, 0, 1>, (const void*)&srf_pw_x3p_kernel<2, 1, 0, 1>,
+#endif
+    };
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
   SRF_CHECK_ARG(ok == 1, "srf_pw_conv: cannot reserve %d bytes of LDS", P_LDS_BYTES);
-  long nb = 2L * srf_device_cus();
+  long nb = 2L * srf_device_cus();      // two resident blocks per CU
+  int abl = 0, stagger = 0;
+#ifdef SRF_EXPERIMENTS                   // lab builds: block count, ablation mask, start-up stagger, in-kernel timeline
   if (const char* e = getenv("SRF_X3P_BLOCKS")) nb = atol(e) > 0 ? atol(e) : nb;
+  abl = getenv("SRF_X3W_ABL") ? atoi(getenv("SRF_X3W_ABL")) : 0;
+  stagger = getenv("SRF_X3P_STAGGER") ? atoi(getenv("SRF_X3P_STAGGER")) : 0;
+#endif
   nb -= nb % 8;
   if (nb > total) nb = total;
   dim3 grid((unsigned)nb), block(512);
   const bool res = a.residual != nullptr;
-  const int abl = getenv("SRF_X3W_ABL") ? atoi(getenv("SRF_X3W_ABL")) : 0;
-  const int stagger = getenv("SRF_X3P_STAGGER") ? atoi(getenv("SRF_X3P_STAGGER")) : 0;
 #define P_GO(...) hipLaunchKernelGGL((srf_pw_x3p_kernel<__VA_ARGS__>), grid, block, P_LDS_BYTES, st, a, wpack, nMt, nLt, (int)total, a.nrm.gamma, a.nrm.beta, a.bias, abl, stagger)
+#ifdef SRF_EXPERIMENTS
   const bool tl = getenv("SRF_X3S_TL") && atoi(getenv("SRF_X3S_TL")) && a.mul;
   if (tl && pro == 0 && !res) {
     P_GO(0, 0, 0, 1);
@@ -430,7 +497,9 @@ int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
     P_GO(0, 0, 1);
   } else if (abl && pro == 2 && res) {
     P_GO(2, 1, 1);
-  } else if (!res) {
+  } else
+#endif
+  if (!res) {
     switch (pro) {
       case 0: P_GO(0, 0); break;
       case 1: P_GO(1, 0); break;
@@ -446,7 +515,7 @@ int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
     }
   }
 #undef P_GO
-  static const char* const kLabel[4] = {"pw_conv_x3w<0>", "pw_conv_x3w<1>", "pw_conv_x3w<2>", "pw_conv_x3w<3>"};
+  static const char* const kLabel[4] = {"pw_conv_x3p<0>", "pw_conv_x3p<1>", "pw_conv_x3p<2>", "pw_conv_x3p<3>"};
   SRF_CHECK_LAUNCH(kLabel[pro < 0 || pro > 3 ? 3 : pro], st);
   return SRF_OK;
 }

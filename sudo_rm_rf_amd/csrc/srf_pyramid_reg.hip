@@ -434,7 +434,11 @@ bool srf_pyramid_reg_supported(int L, int D) {
 // moments / finalize / merge launches are driven by srf_pyramid() in srf_pyramid.hip
 int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st) {
   const int CH = a.D <= 5 ? 16 : 32;
-  a.abl = (srf_debug_flags() >> 12) & 3;
+#ifdef SRF_EXPERIMENTS
+  a.abl = getenv("SRF_PYR_ABL") ? atoi(getenv("SRF_PYR_ABL")) & 3 : 0;   // (lab builds: pass-1 ablations, results wrong)
+#else
+  a.abl = 0;
+#endif
   const int nchunks = a.L / CH;
   a.tiles = (nchunks + 59) / 60;
   a.own = (nchunks + a.tiles - 1) / a.tiles;

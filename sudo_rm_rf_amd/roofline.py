@@ -205,7 +205,7 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
     add("pw_conv_x3w4<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
     add("mask_apply", f * L * (2 * SN + N), 2.0 * Bt * SN * L)
     # decoder (stand-alone form): weight transpose, frame GEMM S N -> S K, overlap-add
-    add("pw_conv_x3w<0>", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)
+    add("pw_conv_bf16x3_p8<0>", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)            # (K = S N, 42 rows: the 128 x 128 kernel)
     add("overlap_add", f * (SK * L + S * A * T), 3.0 * Bt * S * A * T)
     # ---- loss: one streaming pass over estimates + targets, the gradient pass
     add("pit_sisdr_stats", f * 2 * S * T, 2.0 * Bt * (4 * S + S * S) * T)
@@ -213,7 +213,7 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
     # ---- backward: tail
     add("frames_gather", f * (S * A * T + SK * L) + f * (A * T + A * K * L))
     add("pw_wgrad", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)                       # decoder weight
-    add("pw_conv_x3w<0>", f * L * (SK + SN), 2.0 * Bt * SN * SK * L)                 # decoder data gradient (frames -> g_v)
+    add("pw_conv_mfma", f * L * (SK + SN), 2.0 * Bt * SN * SK * L)                   # decoder data gradient (frames -> g_v; K = 42 padded: generic MFMA kernel)
     add("mask_bwd", f * L * (3 * SN + 2 * N), 3.0 * Bt * SN * L)
     add("pw_wgrad", f * L * (SN + B), 2.0 * Bt * SN * B * L)                         # mask_net weight
     add("pw_conv_x3w<0>", f * L * (SN + B), 2.0 * Bt * SN * B * L)                   # mask_net data gradient
@@ -230,7 +230,7 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
     add("pw_conv_x3w<0>", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L)         # proj_1x1 data gradient + skip
     # ---- backward: head
     add("pw_wgrad", f * L * (B + N), 2.0 * Bt * B * N * L)
-    add("pw_conv_x3w<0>", f * L * (B + N), 2.0 * Bt * B * N * L)
+    add("pw_conv_x3w<0>", f * L * (B + N), 2.0 * Bt * B * N * L)                     # bottleneck data gradient
     add("gln_bwd_reduce", f * N * 2 * L, 4.0 * Bt * N * L)
     add("gln_bwd_apply", f * N * 4 * L, 8.0 * Bt * N * L)
     add("pw_wgrad", f * L * (N + A * K), 2.0 * Bt * N * A * K * L)                   # encoder weight

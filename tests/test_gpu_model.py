@@ -104,8 +104,8 @@ def test_unfused_pyramid_agrees(manifest, name):
 
 
 # (case, bench batch, kernel families the single-stream forward MUST have been dispatched to)
-_X3W = {"pw_conv_x3w<0>", "pw_conv_x3w<1>", "pw_conv_x3w<2>", "pw_mask_decode"}
-_BENCH_BATCH = [("cfg2_improved_u16", 32, _X3W), ("cfg3_groupcomm_u8", 32, {"pw_conv_x3w<1>", "pw_mask_decode", "pw_conv_small"}),
+_X3W = {"pw_conv_x3p<0>", "pw_conv_x3p<1>", "pw_conv_x3p<2>", "pw_mask_decode"}      # (x3p: the paired-block 256 x 128 kernel)
+_BENCH_BATCH = [("cfg2_improved_u16", 32, _X3W), ("cfg3_groupcomm_u8", 32, {"pw_conv_x3p<1>", "pw_mask_decode", "pw_conv_small"}),
                 ("cfg4_improved_u36_n2048", 32, _X3W), ("cfg5_improved_u36_n4096", 16, _X3W)]
 
 
@@ -144,10 +144,10 @@ def test_bench_batch_examples_match_reference_golden(manifest, case, batch, fami
         count = {n: sum(1 for k, _ in tr.launches if k == n) for n in tr.names}
         U = cfg.num_blocks
         if cfg.variant == "improved":     # bottleneck, U x proj_1x1, U x res_conv, mask + decoder -- ALL on the 256 x 128 kernel
-            assert (count["pw_conv_x3w<1>"], count["pw_conv_x3w<0>"], count["pw_conv_x3w<2>"], count["pw_mask_decode"]) == \
+            assert (count["pw_conv_x3p<1>"], count["pw_conv_x3p<0>"], count["pw_conv_x3p<2>"], count["pw_mask_decode"]) == \
                 (1, U, U, 1), count
         else:                             # GroupComm: bottleneck + mask on it, the per-group convs on the thin-shape kernel
-            assert (count["pw_conv_x3w<1>"], count["pw_mask_decode"], count["pw_conv_small"]) == (1, 1, 2 * U), count
+            assert (count["pw_conv_x3p<1>"], count["pw_mask_decode"], count["pw_conv_small"]) == (1, 1, 2 * U), count
         # (the fused tail contracts the masked values with the decoder inside the mask GEMM: no GEMM is left on the 128 x 128
         # kernels and the masked tensor is never stored)
         assert sum(v for k, v in count.items() if k.startswith("pw_conv_bf16x3") or k == "pw_conv_mfma") == 0, count

@@ -198,6 +198,12 @@ def test_pw_conv_persistent_variants(Bt, Cin, Cout, L, pro):
     packed = ops.pack_pw_weight(w)
     assert packed is not None
     outs["packed 256x128"] = ops.pw_conv(x, w, bias, residual=res, packed=packed, **kw)
+    try:
+        ops.set_debug_flags(8192)        # (round 4) the paired-block form, what srf_forward runs: two co-resident blocks per CU
+        outs["packed 256x128, two blocks per CU"] = ops.pw_conv(x, w, bias, residual=res, packed=packed, **kw)
+    finally:
+        ops.set_debug_flags(0)
+    assert torch.equal(outs["packed 256x128"], outs["packed 256x128, two blocks per CU"])
     for name, got in outs.items():
         check(got, want, 1e-4, "persistent pw_conv pro=%d (%s)" % (pro, name))
     assert torch.equal(outs["dispatched"], outs["pointer loads"])
@@ -415,13 +421,28 @@ def test_pw_conv_x3w_at_cfg4_cfg5_shapes(Bt, Cin, Cout, L, pro, epi):
         assert ((tot[:, 1] - (gd * gd).sum(1)).abs() <= 4e-6 * (gd * gd).sum(1) + 1e-9).all()
         del gd
         kw["out_sums"] = ops.new_sums(Bt, DEV)
+    if epi != "mask":
+        # (round 4) the PAIRED-BLOCK form of the kernel -- what srf_forward runs for every form but the mask epilogue; stand-alone
+        # calls get it with debug flag 8192 -- is bit-identical and its statistics agree to rounding
+        try:
+            ops.set_debug_flags(8192)
+            with ops.kernel_trace(DEV) as tr1:
+                one = ops.pw_conv(x, w, bias, packed=packed, **kw)
+        finally:
+            ops.set_debug_flags(0)
+        assert tr1.names == {"pw_conv_x3p<%d>" % pro}, tr1.names
+        assert torch.equal(got, one)
+        if sums is not None:
+            assert torch.allclose(kw["out_sums"].sum(1), sums.sum(1), rtol=1e-6, atol=1e-6 * got[0].numel())
+            kw["out_sums"] = ops.new_sums(Bt, DEV)
+        del one
     try:
         ops.set_debug_flags(4)                                   # without the 256 x 128 kernel
         with ops.kernel_trace(DEV) as tr2:
             ref = ops.pw_conv(x, w, bias, packed=packed, **kw)
     finally:
         ops.set_debug_flags(0)
-    assert not any(n.startswith("pw_conv_x3w") for n in tr2.names), tr2.names
+    assert not any(n.startswith(("pw_conv_x3w", "pw_conv_x3p")) for n in tr2.names), tr2.names
     assert torch.equal(got, ref)
 
 
