@@ -233,7 +233,8 @@ int srf_x3t_pack_launch(const float* const* w, char* const* dst, const int* Cout
 int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
 bool srf_x3p_supported(const PwArgs& a, int pro);
 size_t srf_x3p_packed_bytes(int Cout, int Cin);
-int srf_x3p_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
+int srf_x3w_pack2_launch(const float* const* w, char* const* dst, char* const* dst16, const int* Cout, const int* Cin, int n,
+                         hipStream_t st);
 static thread_local int g_pw_prefer_paired = 0;
 void srf_pw_prefer_paired(bool on) { g_pw_prefer_paired = on ? 1 : 0; }      // (srf_forward: around its launches)
 static bool srf_pw_paired_wanted() { return g_pw_prefer_paired != 0; }
@@ -428,12 +429,10 @@ extern "C" size_t srf_packed_pw_weight_bytes(int Cout, int Cin) {
 #endif
 }
 static int srf_pack_both(const float* const* w, void* const* packed, const int* Cout, const int* Cin_signed, int n, hipStream_t st) {
-  int rc = srf_x3w_pack_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin_signed, n, st);
-  if (rc) return rc;
-  std::vector<char*> second(n);     // the x3p image of every entry behind its x3w image
+  std::vector<char*> second(n);     // the x3p image of every entry behind its x3w image (one launch writes both)
   for (int i = 0; i < n; ++i)
     second[i] = reinterpret_cast<char*>(packed[i]) + srf_x3w_packed_bytes(Cout[i], Cin_signed[i] < 0 ? -Cin_signed[i] : Cin_signed[i]);
-  rc = srf_x3p_pack_launch(w, second.data(), Cout, Cin_signed, n, st);
+  int rc = srf_x3w_pack2_launch(w, reinterpret_cast<char* const*>(packed), second.data(), Cout, Cin_signed, n, st);
 #ifdef SRF_EXPERIMENTS
   if (rc) return rc;
   for (int i = 0; i < n; ++i)       // (experiment builds: the x3t image behind that)

@@ -9,11 +9,13 @@
 // streams per forward"), and a GEMM block that owns half a CU instead of all of it lets the other stream's pyramid kernels
 // (VALU- and HBM-bound, no LDS) co-reside with it: cfg 2 6.74 -> 6.36-6.45 ms on the same box, where the one-block kernel
 // gains nothing from the split (profiles/r04_gemm_x3p_in_forward_ab.txt).
-// Nothing else is clever: no fragment prefetch, no LDS strip in the epilogue (dword buffer stores straight from the MFMA layout:
-// 128-byte row segments), static round-robin tiles, whole tiles only.
+// Nothing else is clever: no fragment prefetch, static round-robin tiles, whole tiles only; the epilogue goes through
+// wave-private LDS strips (float4 stores / residual loads: a quarter of the vector-memory instructions of storing straight from
+// the MFMA layout, which measured 6.49 against 6.375 ms per cfg-2 forward and 22.26 against 21.78 ms at cfg 4, same box --
+// profiles/r04_gemm_x3p_in_forward_ab.txt).
 // Same arithmetic as srf_pwconv_x3w.hip in the same order (per 16 k: lo*hi, hi*lo, hi*hi; bias, then residual): the outputs are
 // BIT-IDENTICAL to it; the statistics (fp64 buckets of fp32 partial sums) agree to rounding.
-// Packed weights (srf_x3p_pack_kernel): per (m-tile, 16-k step) [256 rows][hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15], 64-byte
+// Packed weights (second image of srf_x3w_pack_kernel): per (m-tile, 16-k step) [256 rows][hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15], 64-byte
 // rows, 16-byte chunks XOR-swizzled like the B image: a stage's A image is one contiguous 16-KB DMA and both operands' fragments
 // are conflict-free ds_read_b128.
 // Forms: PRO 0-3 x EPI 0 (bias + statistics) | 1 (bias + residual) -- proj_1x1, res_conv, bottleneck and the backward's
@@ -39,58 +41,10 @@ __device__ __forceinline__ int p_swz(int r, int c) { return r * 64 + ((c ^ ((r >
 
 #define P_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
-// ---- packed weights ------------------------------------------------------------------------------------------------------
-struct PPackEntry {
-  const float* w;
-  char* dst;
-  int Cout, Cin;     // Cin < 0: w is [|Cin|][Cout] and the image is that of its transpose (the backward's data-gradient GEMMs)
-};
-constexpr int SRF_P_MAX_PACK = 48;
-struct PPackTable {
-  PPackEntry e[SRF_P_MAX_PACK];
-};
-__global__ __launch_bounds__(256) void srf_x3p_pack_kernel(PPackTable t) {
-  PPackEntry e = t.e[blockIdx.y];
-  const bool trans = e.Cin < 0;
-  e.Cin = trans ? -e.Cin : e.Cin;
-  const int nKt = e.Cin / P_KT;
-  const int nMt = (e.Cout + P_BM - 1) / P_BM;
-  const long total = (long)nMt * nKt * P_BM * 2;   // one thread per (row, 8-k packet): both parts
-  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
-    const int c = (int)(id & 1);
-    const int row = (int)((id >> 1) % P_BM);
-    const long tile = (id >> 1) / P_BM;
-    const int kt = (int)(tile % nKt), mt = (int)(tile / nKt);
-    const int m = mt * P_BM + row;
-    bf16x8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = kt * P_KT + c * 8 + j;
-      const float v = (m < e.Cout) ? (trans ? e.w[(size_t)k * e.Cout + m] : e.w[(size_t)m * e.Cin + k]) : 0.f;
-      const __bf16 h = (__bf16)v;
-      hi[j] = h;
-      lo[j] = (__bf16)(v - (float)h);
-    }
-    char* base = e.dst + (size_t)tile * P_A_IMG;
-    *reinterpret_cast<bf16x8*>(base + p_swz(row, c)) = hi;
-    *reinterpret_cast<bf16x8*>(base + p_swz(row, 2 + c)) = lo;
-  }
-}
+// ---- packed weights: the image is written by srf_x3w_pack_kernel (srf_pwconv_x3w.hip, WPackEntry::dst16) in the launch that
+// writes the one-block kernel's image -- same bf16 parts, laid out per 16-k step ---------------------------------------------
 size_t srf_x3p_packed_bytes(int Cout, int Cin) {
   return (size_t)((Cout + P_BM - 1) / P_BM) * (size_t)(Cin / P_KT) * (size_t)P_A_IMG;
-}
-int srf_x3p_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {
-  for (int base = 0; base < n; base += SRF_P_MAX_PACK) {
-    PPackTable t;
-    const int cnt = (n - base) < SRF_P_MAX_PACK ? (n - base) : SRF_P_MAX_PACK;
-    for (int i = 0; i < SRF_P_MAX_PACK; ++i) {
-      const int j = base + (i < cnt ? i : 0);
-      t.e[i] = PPackEntry{w[j], dst[j], Cout[j], Cin[j]};
-    }
-    hipLaunchKernelGGL(srf_x3p_pack_kernel, dim3(64, cnt), dim3(256), 0, st, t);
-    SRF_CHECK_LAUNCH("pack_pw_weights", st);
-  }
-  return SRF_OK;
 }
 
 // ABL (diagnostics, lab builds only): the instantiation that obeys the run-time mask `rabl` (results wrong): 1 = no epilogue, 2 = no MFMAs, 4 = no
@@ -350,8 +304,7 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
       step(r3, kt + 2);
       step(r0, kt + 3);
     }
-    // ---- epilogue: straight from the MFMA C layout (register r of block (mi, ni) = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
-    // column lane & 31): one dword buffer store per register = two 128-byte row segments per instruction
+    // ---- epilogue
     const unsigned tl_e0 = TL ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
     const int b = cur.b, m0 = cur.mt * P_BM + wm * 64, l0 = cur.lt * P_BN + wn * 64, v = cur.v;
     int lane_o = lane;
@@ -363,47 +316,79 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
       __amdgpu_buffer_rsrc_t rrs = yrs;
       if constexpr (EPI == 1)
         rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual) + (size_t)b * a.Cout * L, 0, a.Cout * L * 4, 0x00020000);
-      // units of 8 registers (two 8-row groups of one 32 x 32 block); the residual of unit u + 1 is requested before unit u is
-      // evaluated (16 registers -- a whole block ahead, 32, spills next to the accumulators and the activation sets)
-      float rv[2][8];
+      // Through a wave-private LDS strip in the stage the tile's last k-step has just freed (16 rows x 32 columns at a time,
+      // pitch 36 floats): the accumulators go in by MFMA layout (register r of a 32 x 32 block = row (r & 3) + 8 (r >> 2) +
+      // 4 (lane >> 5), column lane & 31) and come out as float4 along time, so that the residual loads and the stores are
+      // 16-byte accesses -- 16 + 16 vector-memory instructions per wavefront and tile instead of 64 + 64 dword ones (a
+      // wavefront's vector-memory instructions are what competes with its SIMD's MFMAs; LDS instructions do not).
+      // Unit u = (mi, ni, half): the residual / bias of unit u + 1 is requested before unit u is evaluated.
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const int free_stage = s0 == 0 ? P_NSTAGE - 1 : s0 - 1;
+      float* strip = reinterpret_cast<float*>(smem + free_stage * P_STAGE) + wave * (16 * SRF_EPI_PITCH_H);
+      const int c4 = (lane_o & 7) * 4, rsub = lane_o >> 3;
+      float4 rv[2][2];
+      float bv[2][2];
+      auto unit_off = [&](int u, int it, int& row, bool& ok) __attribute__((always_inline)) {
+        const int mi = u >> 2, ni = (u >> 1) & 1, h = u & 1;
+        row = m0 + mi * 32 + 16 * h + it * 8 + rsub;
+        const int col = l0 + ni * 32 + c4;
+        ok = col < L;                                  // (L % 4 == 0: a float4 is in range as a whole)
+        return ok ? (row * L + col) * 4 : 0x7ffffff0;
+      };
       auto res_issue = [&](int slot, int u) __attribute__((always_inline)) {
-        if constexpr (EPI == 1) {
-          const int mi = u >> 2, ni = (u >> 1) & 1;
-          const int col = l0 + ni * 32 + lcol;
-          const int vo = col < L ? (4 * lhalf * L + col) * 4 : 0x7ffffff0;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int row = m0 + mi * 32 + 16 * (u & 1) + (e & 3) + 8 * (e >> 2);      // wave-uniform, < Cout (Cout % 64 == 0)
-            rv[slot][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vo, row * L * 4, 0));
+        for (int it = 0; it < 2; ++it) {
+          int row;
+          bool ok;
+          const int off = unit_off(u, it, row, ok);
+          bv[slot][it] = a.bias[row];
+          if constexpr (EPI == 1) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rrs, off, 0, 0);
+            rv[slot][it] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
           }
         }
       };
       res_issue(0, 0);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int mi = u >> 2, ni = (u >> 1) & 1;
+        const int mi = u >> 2, ni = (u >> 1) & 1, h = u & 1;
         if (u + 1 < 8) res_issue((u + 1) & 1, u + 1);
-        const int col = l0 + ni * 32 + lcol;
-        const bool okc = col < L;
-        const int vo = okc ? (4 * lhalf * L + col) * 4 : 0x7ffffff0;
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-          const int g = 2 * (u & 1) + gg;
-          const int row8 = m0 + mi * 32 + 8 * g;
-          const float* bp = bias_r + row8;          // 8 consecutive scalars
+        for (int e = 0; e < 8; ++e)
+          strip[((e & 3) + 8 * (e >> 2) + 4 * lhalf) * SRF_EPI_PITCH_H + lcol] = acc[mi][ni][8 * h + e];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * g + j;
-            float o = acc[mi][ni][r] + (lhalf ? bp[4 + j] : bp[j]);
-            if constexpr (EPI == 1) o += rv[u & 1][4 * gg + j];
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), yrs, vo, (row8 + j) * L * 4, 0);
-            if constexpr (EPI == 0) {
-              const float oz = okc ? o : 0.f;
-              s += oz;
-              q = fmaf(oz, oz, q);
+        for (int it = 0; it < 2; ++it) {
+          int row;
+          bool ok;
+          const int off = unit_off(u, it, row, ok);
+          float4 o = *reinterpret_cast<const float4*>(strip + (it * 8 + rsub) * SRF_EPI_PITCH_H + c4);
+          const float bs = bv[u & 1][it];
+          o.x += bs;
+          o.y += bs;
+          o.z += bs;
+          o.w += bs;
+          if constexpr (EPI == 1) {
+            const float4 e4 = rv[u & 1][it];
+            o.x += e4.x;
+            o.y += e4.y;
+            o.z += e4.z;
+            o.w += e4.w;
+          }
+          const u32x4 ov = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+          __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, off, 0, 0);
+          if constexpr (EPI == 0) {
+            if (ok) {
+              s += (o.x + o.y) + (o.z + o.w);
+              q = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, fmaf(o.w, o.w, q))));
             }
           }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     } else if (ABL) {
 #pragma unroll
@@ -427,6 +412,9 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       tl_epi += (unsigned)__builtin_amdgcn_s_memtime() - tl_e0;
     }
+    // every wavefront's strip reads are done before the next step's DMA overwrites that stage
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     cur = nxc;
     tc = tn;
     if (i + 2 < ntile) {

@@ -952,6 +952,8 @@ constexpr int SRF_W_MAX_PACK = 96;
 struct WPackEntry {
   const float* w;
   char* dst;
+  char* dst16;     // optional second image of the same parts for the paired-block kernel (srf_pwconv_x3p.hip): per (m-tile, 16-k
+                   // step) [256 rows][hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15], same swizzle -- written by the same launch
   int Cout, Cin;   // Cin < 0: w is stored TRANSPOSED ([|Cin|][Cout]) -- the backward's data-gradient GEMMs use W^T
 };
 struct WPackTable {
@@ -985,16 +987,21 @@ __global__ __launch_bounds__(256) void srf_x3w_pack_kernel(WPackTable t) {
     char* base = e.dst + (size_t)tile * W_WTILE_BYTES + w_swz(row, c);
     *reinterpret_cast<bf16x8*>(base) = hi;
     *reinterpret_cast<bf16x8*>(base + W_A_IMG) = lo;
+    if (!F16 && e.dst16) {      // 16-k step 2 kt + (c >> 1) of the m-tile, 8-k packet c & 1
+      char* b16 = e.dst16 + ((size_t)mt * (2 * nKt) + 2 * kt + (c >> 1)) * (size_t)(W_BM * 64);
+      *reinterpret_cast<bf16x8*>(b16 + w_swz(row, c & 1)) = hi;
+      *reinterpret_cast<bf16x8*>(b16 + w_swz(row, 2 + (c & 1))) = lo;
+    }
   }
 }
 static int srf_x3w_pack_launch_any(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st,
-                                   bool f16) {
+                                   bool f16, char* const* dst16 = nullptr) {
   for (int base = 0; base < n; base += SRF_W_MAX_PACK) {
     WPackTable t;
     const int cnt = (n - base) < SRF_W_MAX_PACK ? (n - base) : SRF_W_MAX_PACK;
     for (int i = 0; i < SRF_W_MAX_PACK; ++i) {
       const int j = base + (i < cnt ? i : 0);
-      t.e[i] = WPackEntry{w[j], dst[j], Cout[j], Cin[j]};
+      t.e[i] = WPackEntry{w[j], dst[j], dst16 ? dst16[j] : nullptr, Cout[j], Cin[j]};
     }
     if (f16) hipLaunchKernelGGL(srf_x3w_pack_kernel<true>, dim3(64, cnt), dim3(256), 0, st, t);
     else hipLaunchKernelGGL(srf_x3w_pack_kernel<false>, dim3(64, cnt), dim3(256), 0, st, t);
@@ -1004,6 +1011,11 @@ static int srf_x3w_pack_launch_any(const float* const* w, char* const* dst, cons
 }
 int srf_x3w_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {
   return srf_x3w_pack_launch_any(w, dst, Cout, Cin, n, st, false);
+}
+// both images of every entry in ONE launch: dst (this kernel's) and dst16 (the paired-block kernel's)
+int srf_x3w_pack2_launch(const float* const* w, char* const* dst, char* const* dst16, const int* Cout, const int* Cin, int n,
+                         hipStream_t st) {
+  return srf_x3w_pack_launch_any(w, dst, Cout, Cin, n, st, false, dst16);
 }
 // fp16 parts (NP 4): the same image layout and size as the bf16 two-part image
 int srf_x3w_pack_f16_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {

@@ -87,8 +87,8 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, p
     out = [("zero_fill", 16.0 * 64 * Bg * (1 + U * (D + 2 + (1 if variant == "groupcomm" else 0))), 0.0)]   # GlobLN statistic slots
     convs = [(N, B)] + [(nB, nC), (nC, nB)] * U + [(B, SA * N)]
     pk = [(ci, co) for ci, co in convs if _packable(ci, co)]
-    if kernel_mode == 0 and packed and pk:      # one launch per forward: fp32 weights -> bf16 hi|lo tile images
-        out.append(("pack_pw_weights", sum(8.0 * ci * co for ci, co in pk), 0.0))
+    if kernel_mode == 0 and packed and pk:      # one launch per forward: fp32 weights -> bf16 hi|lo tile images (two layouts:
+        out.append(("pack_pw_weights", sum(12.0 * ci * co for ci, co in pk), 0.0))      # the one-block and the paired-block GEMM's)
     out.append(("encoder", f * Bt * (A * T + N * L), 2.0 * Bt * N * A * K * L))
 
     def pw(cin, cout, bt, extra_in=0):
