@@ -350,6 +350,229 @@ static bool srf_tac_lanes_launch(const TacArgs& a, int n, int Bt, hipStream_t st
   }
 }
 
+// =============================================================================================================================
+// MFMA form (round 4) for n = 16, H = 48, G = 16 -- the shape of BASELINE's GroupComm configuration (cfg 3).
+// The lane-per-(time step, group) kernel above is VALU-bound (134 us per launch at cfg 3: ~2 300 VALU instructions per wavefront
+// and 8 columns).  Here the three Linear layers are small GEMMs on the matrix pipe: a wavefront owns 32 time steps of one example
+// and walks the 16 groups,
+//   z_g  [48 x 32] = Wi [48 x 16] x_g [16 x 32]                     2 M-blocks x 1 k-step
+//   q    [48 x 32] = Wm [48 x 48] zbar [48 x 32],  r = Wo[:, H:] q    (2 + 1) M-blocks x 3 k-steps, once per tile
+//   o_g  [16 x 32] = Wo[:, :H] [16 x 48] z_g [48 x 32] + r            1 M-block x 3 k-steps       (second sweep: z_g recomputed)
+// with fp32 operands split into TWO FP16 PARTS (hi = fp16(v), lo = fp16(v - hi): 22 mantissa bits, the training forward's scheme,
+// srf_pwconv_x3w.hip NP = 4) and three v_mfma_f32_32x32x16_f16 per product block, fp32 accumulate -- the fp32 VALU kernel's
+// accuracy class (test_tac's bar is unchanged).  Weights are stored times 2^4 so that their lo parts stay normal in fp16; the
+// biases ride in as the MFMAs' C operand at the matching scale and PReLU commutes with the positive scale, so every rescale is
+// one exact multiply at the end of a chain.  What the MFMA hands back (C layout: lane = column, registers = rows (r & 3) +
+// 8 (r >> 2) + 4 (lane >> 5)) becomes the next GEMM's B operand (lane = column, 8 consecutive k) with four
+// v_permlane32_swap_b32 per 8 rows -- no LDS round trip.  The A fragments of Wm / Wo live in LDS (24 KB, built once per block),
+// Wi's in registers.  One 32-column tile per wavefront, four per block: the hardware balances 3 200 tiles.
+typedef _Float16 tac_f16x8 __attribute__((ext_vector_type(8)));
+typedef float tac_f32x16 __attribute__((ext_vector_type(16)));
+constexpr float TAC_WS = 16.f;
+
+__device__ __forceinline__ void tac_split8(const float (&v)[8], tac_f16x8& hi, tac_f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 h = (_Float16)v[j];
+    hi[j] = h;
+    lo[j] = (_Float16)(v[j] - (float)h);
+  }
+}
+// c + A B with A = ah + al, B = bh + bl (lo * lo dropped), smallest terms first
+__device__ __forceinline__ tac_f32x16 tac_mma3(const tac_f16x8& ah, const tac_f16x8& al, const tac_f16x8& bh, const tac_f16x8& bl,
+                                               tac_f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+// 8 C-layout registers c[0..7] of one 16-row group (c[0..3]: rows e | 4 + e of the lower 8, c[4..7]: of the upper 8, by lane
+// half) -> this lane's B-operand values: 8 consecutive rows 8 (lane >> 5) + 0..7 of its column
+__device__ __forceinline__ void tac_c_to_b(const float (&c)[8], float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[e]), __float_as_uint(c[4 + e]), false, false);
+    v[e] = __uint_as_float(r[0]);
+    v[4 + e] = __uint_as_float(r[1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_per_row, int total_tiles) {
+  constexpr int NN = 16, HH = 48, G = 16;
+  __shared__ tac_f16x8 s_frag[24][64];     // A fragments {hi, lo}: Wm (2 M-blocks x 3 k-steps), Wo[:, H:] (3), Wo[:, :H] (3)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform for the compiler: buffer descriptors in SGPRs)
+  const int t = lane & 31, h = lane >> 5;
+  const int L = a.L;
+  // ---- A fragments: element (lane, e) = W[row = 32 blk + (lane & 31)][k = 16 s + 8 (lane >> 5) + e] x 2^4, zero beyond the matrix
+  for (int id = tid; id < 12 * 64; id += 256) {
+    const int f = id >> 6, ln = id & 63, row32 = ln & 31, kh = ln >> 5;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float w = 0.f;
+      if (f < 6) {                       // Wm [48][48]: f = blk * 3 + s
+        const int blk = f / 3, sidx = f - blk * 3, j = blk * 32 + row32, k = 16 * sidx + 8 * kh + e;
+        if (j < HH) w = a.wm[j * HH + k];
+      } else {                           // Wo [16][96]: f - 6 = half * 3 + s, half 0 = the q columns (H ..), 1 = the z columns
+        const int half = (f - 6) / 3, sidx = (f - 6) - half * 3, k = 16 * sidx + 8 * kh + e;
+        if (row32 < NN) w = a.wo[row32 * 2 * HH + (half == 0 ? HH : 0) + k];
+      }
+      v[e] = w * TAC_WS;
+    }
+    tac_f16x8 hi, lo;
+    tac_split8(v, hi, lo);
+    s_frag[2 * f][ln] = hi;
+    s_frag[2 * f + 1][ln] = lo;
+  }
+  tac_f16x8 wi_h[2], wi_l[2];            // Wi [48][16]: 2 M-blocks, one k-step
+  tac_f32x16 bi16[2];                    // 2^4 bi in the C layout (the first MFMA's C operand)
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    float v[8];
+    const int j = blk * 32 + t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = j < HH ? a.wi[j * NN + 8 * h + e] * TAC_WS : 0.f;
+    tac_split8(v, wi_h[blk], wi_l[blk]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      bi16[blk][r] = row < HH ? a.bi[row] * TAC_WS : 0.f;
+    }
+  }
+  __syncthreads();
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= total_tiles) return;       // (after the barrier; wave-uniform)
+  const int b = tile / tiles_per_row, l0 = (tile - b * tiles_per_row) * 32;
+  const int col = l0 + t;
+  const bool valid = col < L;
+  const float ai = a.ai[0], am = a.am[0], ao = a.ao[0];
+  __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * G * NN * L, 0, G * NN * L * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(a.q + (size_t)b * G * NN * L, 0, G * NN * L * 4, 0x00020000);
+  const int x_vo = valid ? (8 * h * L + col) * 4 : 0x7ffffff0;     // (out of range: the load returns 0, the store is dropped)
+  const int q_vo = valid ? (4 * h * L + col) * 4 : 0x7ffffff0;
+
+  // x_g's B fragment: 8 dword loads (rows 8 h + e of group g at this lane's column), requested one group ahead
+  struct XRaw {
+    float v[8];
+  };
+  auto issue_x = [&](int g, XRaw& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, x_vo, (g * NN + e) * L * 4, 0));
+  };
+  // 2^4 PReLU(Wi x + bi) of group g in the C layout: zA rows 0..31, zB rows 32..47 (registers 0..7)
+  auto z_of = [&](const tac_f16x8& xh, const tac_f16x8& xl, tac_f32x16& zA, tac_f32x16& zB) __attribute__((always_inline)) {
+    zA = tac_mma3(wi_h[0], wi_l[0], xh, xl, bi16[0]);
+    zB = tac_mma3(wi_h[1], wi_l[1], xh, xl, bi16[1]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zA[r] = srf_prelu(zA[r], ai);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) zB[r] = srf_prelu(zB[r], ai);
+  };
+  // the three k-steps' B fragments of a [48 x 32] C-layout pair (A: rows 0..31, B: rows 32..47), values times `scale`
+  auto frags_of = [&](const tac_f32x16& cA, const tac_f32x16& cB, float scale, tac_f16x8 (&fh)[3], tac_f16x8 (&fl)[3])
+      __attribute__((always_inline)) {
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx) {
+      float c8[8], v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c8[e] = (sidx < 2 ? cA[8 * sidx + e] : cB[e]) * scale;
+      tac_c_to_b(c8, v);
+      tac_split8(v, fh[sidx], fl[sidx]);
+    }
+  };
+
+  // ---- sweep 1: zsum = sum_g 2^4 z_g
+  tac_f32x16 zsA, zsB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zsA[r] = zsB[r] = 0.f;
+  XRaw xa, xb;
+  issue_x(0, xa);
+  auto sweep1 = [&](XRaw& cur, XRaw& nxt, int g) __attribute__((always_inline)) {
+    issue_x(g + 1 < G ? g + 1 : 0, nxt);             // (the last one requests group 0 again: sweep 2 starts with it)
+    tac_f16x8 xh, xl;
+    tac_split8(cur.v, xh, xl);
+    tac_f32x16 zA, zB;
+    z_of(xh, xl, zA, zB);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zsA[r] += zA[r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) zsB[r] += zB[r];
+  };
+  for (int g = 0; g < G; g += 2) {
+    sweep1(xa, xb, g);
+    sweep1(xb, xa, g + 1);
+  }
+  // ---- q = PReLU(Wm zbar + bm), r = Wo[:, H:] q + bo.  B fragments of 2^4 zbar = zsum / G; Wm is stored times 2^4: the
+  // accumulators hold 2^8 (Wm zbar + bm)
+  tac_f32x16 r256;
+  {
+    tac_f16x8 fh[3], fl[3];
+    frags_of(zsA, zsB, 1.f / (float)G, fh, fl);
+    tac_f32x16 qA, qB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      qA[r] = a.bm[row] * (TAC_WS * TAC_WS);
+      qB[r] = row < HH - 32 ? a.bm[32 + row] * (TAC_WS * TAC_WS) : 0.f;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx) {
+      qA = tac_mma3(s_frag[2 * sidx][lane], s_frag[2 * sidx + 1][lane], fh[sidx], fl[sidx], qA);
+      qB = tac_mma3(s_frag[2 * (3 + sidx)][lane], s_frag[2 * (3 + sidx) + 1][lane], fh[sidx], fl[sidx], qB);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      qA[r] = srf_prelu(qA[r], am);
+      qB[r] = srf_prelu(qB[r], am);
+    }
+    frags_of(qA, qB, 1.f / TAC_WS, fh, fl);          // 2^4 q
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      r256[r] = row < NN ? a.bo[row] * (TAC_WS * TAC_WS) : 0.f;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx)
+      r256 = tac_mma3(s_frag[2 * (6 + sidx)][lane], s_frag[2 * (6 + sidx) + 1][lane], fh[sidx], fl[sidx], r256);
+  }
+  // ---- sweep 2: o_g = PReLU(Wo[:, :H] z_g + r + bo)
+  auto sweep2 = [&](XRaw& cur, XRaw& nxt, int g) __attribute__((always_inline)) {
+    if (g + 1 < G) issue_x(g + 1, nxt);
+    tac_f16x8 xh, xl;
+    tac_split8(cur.v, xh, xl);
+    tac_f32x16 zA, zB;
+    z_of(xh, xl, zA, zB);
+    tac_f16x8 fh[3], fl[3];
+    frags_of(zA, zB, 1.f, fh, fl);                   // 2^4 z_g
+    tac_f32x16 o = r256;
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx)
+      o = tac_mma3(s_frag[2 * (9 + sidx)][lane], s_frag[2 * (9 + sidx) + 1][lane], fh[sidx], fl[sidx], o);
+    float ss = 0.f, sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                    // rows (r & 3) + 8 (r >> 2) + 4 h = 0 .. 15
+      const float v = srf_prelu(o[r] * (1.f / (TAC_WS * TAC_WS)), ao);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), qrs, q_vo, (g * NN + (r & 3) + 8 * (r >> 2)) * L * 4, 0);
+      const float vz = valid ? v : 0.f;
+      ss += vz;
+      sq = fmaf(vz, vz, sq);
+    }
+    if (a.out_sums) {      // (64 fp32 partials of 8 values each, summed in fp32 like the VALU kernel's lane sums, then fp64 buckets)
+      const float fs = srf_dpp_wave_sum(ss), fq = srf_dpp_wave_sum(sq);
+      if (lane == 63) {
+        double* dst = srf_stat_slot(a.out_sums, (long)b * G + g, tile);
+        atomicAdd(dst, (double)fs);
+        atomicAdd(dst + 1, (double)fq);
+      }
+    }
+  };
+  for (int g = 0; g < G; g += 2) {
+    sweep2(xa, xb, g);
+    sweep2(xb, xa, g + 1);
+  }
+}
+
 extern "C" int srf_tac(const float* x, float* q, const float* const* params, int Bt, int G, int n, int H,
                        int L, double* out_sums, void* stream) {
   SRF_CHECK_ARG(x && q && params, "srf_tac: null pointer");
@@ -373,6 +596,17 @@ extern "C" int srf_tac(const float* x, float* q, const float* const* params, int
   a.L = L;
   dim3 grid((L + 127) / 128, Bt), block(128);
   hipStream_t st = (hipStream_t)stream;
+  // debug flags 1 << 22 / 24 / 25 / 26, 1024: the VALU kernels (the MFMA form serves n = 16, G = 16; 1 << 22 = just not the MFMA form)
+  if (srf_kernel_mode() == 0 && n == 16 && G == 16 && !(srf_debug_flags() & ((1 << 22) | (1 << 24) | (1 << 25) | (1 << 26) | 1024)) &&
+      (long)G * n * L * 4 < (1L << 31)) {
+    const int tiles_per_row = (L + 31) / 32;
+    const long total = (long)Bt * tiles_per_row;
+    if (total < (1L << 30)) {
+      hipLaunchKernelGGL(srf_tac_mfma_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, a, tiles_per_row, (int)total);
+      SRF_CHECK_LAUNCH("tac_mfma", st);
+      return SRF_OK;
+    }
+  }
   if (srf_kernel_mode() != 1 && !(srf_debug_flags() & (1 << 24)) && srf_tac_lanes_launch(a, n, Bt, st)) {
     SRF_CHECK_LAUNCH("tac", st);
     return SRF_OK;
