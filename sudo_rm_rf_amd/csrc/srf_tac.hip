@@ -404,21 +404,33 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform for the compiler: buffer descriptors in SGPRs)
   const int t = lane & 31, h = lane >> 5;
   const int L = a.L;
-  // ---- A fragments: element (lane, e) = W[row = 32 blk + (lane & 31)][k = 16 s + 8 (lane >> 5) + e] x 2^4, zero beyond the matrix
+  // ---- A fragments: element (lane, e) = W[row = 32 blk + (lane & 31)][k = 16 s + 8 (lane >> 5) + e] x 2^4, zero beyond the
+  // matrix.  8 consecutive k = two float4 loads (rows are 192 / 384 bytes long: 16-byte aligned when the tensor is)
+  __shared__ float s_bias[HH + HH + NN];   // bi | bm | bo
+  for (int e = tid; e < HH + HH + NN; e += 256) s_bias[e] = e < HH ? a.bi[e] : (e < 2 * HH ? a.bm[e - HH] : a.bo[e - 2 * HH]);
+  auto row8 = [&](const float* p, bool ok, float (&v)[8]) __attribute__((always_inline)) {
+    float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo4;
+    if (ok) {
+      if ((((size_t)p) & 15) == 0) {
+        lo4 = reinterpret_cast<const float4*>(p)[0];
+        hi4 = reinterpret_cast<const float4*>(p)[1];
+      } else {
+        lo4 = make_float4(p[0], p[1], p[2], p[3]);
+        hi4 = make_float4(p[4], p[5], p[6], p[7]);
+      }
+    }
+    v[0] = lo4.x * TAC_WS; v[1] = lo4.y * TAC_WS; v[2] = lo4.z * TAC_WS; v[3] = lo4.w * TAC_WS;
+    v[4] = hi4.x * TAC_WS; v[5] = hi4.y * TAC_WS; v[6] = hi4.z * TAC_WS; v[7] = hi4.w * TAC_WS;
+  };
   for (int id = tid; id < 12 * 64; id += 256) {
     const int f = id >> 6, ln = id & 63, row32 = ln & 31, kh = ln >> 5;
     float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float w = 0.f;
-      if (f < 6) {                       // Wm [48][48]: f = blk * 3 + s
-        const int blk = f / 3, sidx = f - blk * 3, j = blk * 32 + row32, k = 16 * sidx + 8 * kh + e;
-        if (j < HH) w = a.wm[j * HH + k];
-      } else {                           // Wo [16][96]: f - 6 = half * 3 + s, half 0 = the q columns (H ..), 1 = the z columns
-        const int half = (f - 6) / 3, sidx = (f - 6) - half * 3, k = 16 * sidx + 8 * kh + e;
-        if (row32 < NN) w = a.wo[row32 * 2 * HH + (half == 0 ? HH : 0) + k];
-      }
-      v[e] = w * TAC_WS;
+    if (f < 6) {                         // Wm [48][48]: f = blk * 3 + s
+      const int blk = f / 3, sidx = f - blk * 3, j = blk * 32 + row32;
+      row8(a.wm + (j < HH ? j : 0) * HH + 16 * sidx + 8 * kh, j < HH, v);
+    } else {                             // Wo [16][96]: f - 6 = half * 3 + s, half 0 = the q columns (H ..), 1 = the z columns
+      const int half = (f - 6) / 3, sidx = (f - 6) - half * 3;
+      row8(a.wo + (row32 < NN ? row32 : 0) * 2 * HH + (half == 0 ? HH : 0) + 16 * sidx + 8 * kh, row32 < NN, v);
     }
     tac_f16x8 hi, lo;
     tac_split8(v, hi, lo);
@@ -426,27 +438,30 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
     s_frag[2 * f + 1][ln] = lo;
   }
   tac_f16x8 wi_h[2], wi_l[2];            // Wi [48][16]: 2 M-blocks, one k-step
-  tac_f32x16 bi16[2];                    // 2^4 bi in the C layout (the first MFMA's C operand)
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
     float v[8];
     const int j = blk * 32 + t;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = j < HH ? a.wi[j * NN + 8 * h + e] * TAC_WS : 0.f;
+    row8(a.wi + (j < HH ? j : 0) * NN + 8 * h, j < HH, v);
     tac_split8(v, wi_h[blk], wi_l[blk]);
+  }
+  __syncthreads();
+  tac_f32x16 bi16[2];                    // 2^4 bi in the C layout (the first MFMA's C operand)
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      bi16[blk][r] = row < HH ? a.bi[row] * TAC_WS : 0.f;
+      bi16[blk][r] = row < HH ? s_bias[row] * TAC_WS : 0.f;
     }
-  }
-  __syncthreads();
+  const float ai = a.ai[0], am = a.am[0], ao = a.ao[0];
+  // ONE tile per wavefront (a loop over tiles keeps ~80 more registers alive across iterations: 296 instead of 216, one
+  // wavefront per SIMD instead of two, 134 instead of 105 us)
   const int tile = blockIdx.x * 4 + wave;
   if (tile >= total_tiles) return;       // (after the barrier; wave-uniform)
   const int b = tile / tiles_per_row, l0 = (tile - b * tiles_per_row) * 32;
   const int col = l0 + t;
   const bool valid = col < L;
-  const float ai = a.ai[0], am = a.am[0], ao = a.ao[0];
   __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * G * NN * L, 0, G * NN * L * 4, 0x00020000);
   __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(a.q + (size_t)b * G * NN * L, 0, G * NN * L * 4, 0x00020000);
   const int x_vo = valid ? (8 * h * L + col) * 4 : 0x7ffffff0;     // (out of range: the load returns 0, the store is dropped)
@@ -459,6 +474,11 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
   auto issue_x = [&](int g, XRaw& r) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) r.v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, x_vo, (g * NN + e) * L * 4, 0));
+  };
+  // (fp16 range guard, as in the training forward's GEMM: the residual stream of every model we have stays below 1e3)
+  auto clamp8 = [&](float (&v)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -60000.f, 60000.f);
   };
   // 2^4 PReLU(Wi x + bi) of group g in the C layout: zA rows 0..31, zB rows 32..47 (registers 0..7)
   auto z_of = [&](const tac_f16x8& xh, const tac_f16x8& xl, tac_f32x16& zA, tac_f32x16& zB) __attribute__((always_inline)) {
@@ -491,6 +511,7 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
   auto sweep1 = [&](XRaw& cur, XRaw& nxt, int g) __attribute__((always_inline)) {
     issue_x(g + 1 < G ? g + 1 : 0, nxt);             // (the last one requests group 0 again: sweep 2 starts with it)
     tac_f16x8 xh, xl;
+    clamp8(cur.v);
     tac_split8(cur.v, xh, xl);
     tac_f32x16 zA, zB;
     z_of(xh, xl, zA, zB);
@@ -513,8 +534,8 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      qA[r] = a.bm[row] * (TAC_WS * TAC_WS);
-      qB[r] = row < HH - 32 ? a.bm[32 + row] * (TAC_WS * TAC_WS) : 0.f;
+      qA[r] = s_bias[HH + row] * (TAC_WS * TAC_WS);
+      qB[r] = row < HH - 32 ? s_bias[HH + 32 + row] * (TAC_WS * TAC_WS) : 0.f;
     }
 #pragma unroll
     for (int sidx = 0; sidx < 3; ++sidx) {
@@ -530,7 +551,7 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      r256[r] = row < NN ? a.bo[row] * (TAC_WS * TAC_WS) : 0.f;
+      r256[r] = row < NN ? s_bias[2 * HH + row] * (TAC_WS * TAC_WS) : 0.f;
     }
 #pragma unroll
     for (int sidx = 0; sidx < 3; ++sidx)
@@ -540,6 +561,7 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
   auto sweep2 = [&](XRaw& cur, XRaw& nxt, int g) __attribute__((always_inline)) {
     if (g + 1 < G) issue_x(g + 1, nxt);
     tac_f16x8 xh, xl;
+    clamp8(cur.v);
     tac_split8(cur.v, xh, xl);
     tac_f32x16 zA, zB;
     z_of(xh, xl, zA, zB);
@@ -602,7 +624,8 @@ extern "C" int srf_tac(const float* x, float* q, const float* const* params, int
     const int tiles_per_row = (L + 31) / 32;
     const long total = (long)Bt * tiles_per_row;
     if (total < (1L << 30)) {
-      hipLaunchKernelGGL(srf_tac_mfma_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, a, tiles_per_row, (int)total);
+      const long blocks = (total + 3) / 4;
+      hipLaunchKernelGGL(srf_tac_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_per_row, (int)total);
       SRF_CHECK_LAUNCH("tac_mfma", st);
       return SRF_OK;
     }
