@@ -6,6 +6,12 @@
 //   mask ReLU * encoder output      improved_sudormrf.py:296-298
 //   conv_transpose1d / conv1d frame gathers for the decoder / encoder weight gradients  :247-251,272-279
 #include "srf_common.h"
+
+// The streamed operands of the row kernels below (gradients, saved activations: each read once per kernel) as non-temporal loads
+// (round 4; -DSRF_BWD_NT=false for the A/B build)
+#ifndef SRF_BWD_NT
+#define SRF_BWD_NT true
+#endif
 #include <algorithm>
 #include <vector>
 
@@ -242,13 +248,13 @@ __global__ __launch_bounds__(256) void srf_gln_bwd_reduce_v4_kernel(GlnBwdArgs a
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int fc = min(f0 + u * 64 + lane, L4 - 1);   // clamped: loads unconditional
-      gv[u] = go[fc];
-      xv[u] = xr[fc];
+      gv[u] = srf_ld4<SRF_BWD_NT>(reinterpret_cast<const float*>(go + fc));
+      xv[u] = srf_ld4<SRF_BWD_NT>(reinterpret_cast<const float*>(xr + fc));
     }
     if (go2) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float4 t = go2[min(f0 + u * 64 + lane, L4 - 1)];
+        const float4 t = srf_ld4<SRF_BWD_NT>(reinterpret_cast<const float*>(go2 + min(f0 + u * 64 + lane, L4 - 1)));
         gv[u].x += t.x;
         gv[u].y += t.y;
         gv[u].z += t.z;
@@ -299,8 +305,8 @@ __global__ __launch_bounds__(256) void srf_gln_bwd_apply_v4_kernel(GlnBwdArgs a,
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int fc = min(u * 64 + lane, L4 - 1);
-    gv[u] = go[fc];
-    xv[u] = xr[fc];
+    gv[u] = srf_ld4<SRF_BWD_NT>(reinterpret_cast<const float*>(go + fc));
+    xv[u] = srf_ld4<SRF_BWD_NT>(reinterpret_cast<const float*>(xr + fc));
   }
   float mean, rstd;
   srf_finalize_stats(a.nrm.sums, g, a.inv_count, mean, rstd);
@@ -314,8 +320,8 @@ __global__ __launch_bounds__(256) void srf_gln_bwd_apply_v4_kernel(GlnBwdArgs a,
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int fc = min(f0 + u * 64 + lane, L4 - 1);
-        gv[u] = go[fc];
-        xv[u] = xr[fc];
+        gv[u] = srf_ld4<SRF_BWD_NT>(reinterpret_cast<const float*>(go + fc));
+        xv[u] = srf_ld4<SRF_BWD_NT>(reinterpret_cast<const float*>(xr + fc));
       }
     }
     if (go2) {
@@ -906,19 +912,19 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_row_kernel(DwBwdArgs a, l
     const bool valid = f < L4;
     const int i0 = f * 4;
     // ---- all loads of the trip first
-    const float4 xv = *reinterpret_cast<const float4*>(xr + (valid ? i0 : 0));
+    const float4 xv = srf_ld4<SRF_BWD_NT>(xr + (valid ? i0 : 0));
     float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (FUSE && gadd) ga = *reinterpret_cast<const float4*>(gadd + (valid ? i0 : 0));
+    if (FUSE && gadd) ga = srf_ld4<SRF_BWD_NT>(gadd + (valid ? i0 : 0));
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 g2 = make_float2(0.f, 0.f);
     float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 d2 = make_float2(0.f, 0.f);
     if (S == 1) {
-      g4 = *reinterpret_cast<const float4*>(gd + (valid ? i0 : 0));
-      if (APPLY) d4 = *reinterpret_cast<const float4*>(ax + (valid ? i0 : 0));
+      g4 = srf_ld4<SRF_BWD_NT>(gd + (valid ? i0 : 0));
+      if (APPLY) d4 = srf_ld4<SRF_BWD_NT>(ax + (valid ? i0 : 0));
     } else {
-      g2 = *reinterpret_cast<const float2*>(gd + (valid ? (i0 >> 1) : 0));   // Lout = Lin/2: both outputs exist
-      if (APPLY) d2 = *reinterpret_cast<const float2*>(ax + (valid ? (i0 >> 1) : 0));
+      g2 = srf_ld2<SRF_BWD_NT>(gd + (valid ? (i0 >> 1) : 0));   // Lout = Lin/2: both outputs exist
+      if (APPLY) d2 = srf_ld2<SRF_BWD_NT>(ax + (valid ? (i0 >> 1) : 0));
     }
     // edge lanes: the two positions left of lane 0 / right of lane 63 (i0 % 4 == 0: in range together or not at all)
     const int hi = lane == 0 ? i0 - 2 : i0 + 4;

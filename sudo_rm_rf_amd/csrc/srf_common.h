@@ -220,6 +220,29 @@ __device__ __forceinline__ void srf_finalize_stats_dpp(const double* sums, long 
 // min(x, a x) when a > 1, i.e. the median of {x, a x, +inf} resp. {x, a x, -inf}; the third operand depends on the
 // (wave-uniform, loop-invariant) slope only.  The compare + select form costs three VALU instructions per element
 // and showed up in every kernel that applies the activation on load (res_conv GEMM -4 %, pyramid pass 1 -7 %).
+// Non-temporal (streaming) loads for tensors a kernel reads exactly once: they do not displace what the NEXT kernel will read.
+// NT = false: the plain load (same code path for A/B).
+template <bool NT>
+__device__ __forceinline__ float4 srf_ld4(const float* p) {
+  if constexpr (NT) {
+    typedef float srf_f4v __attribute__((ext_vector_type(4)));
+    const srf_f4v t = __builtin_nontemporal_load(reinterpret_cast<const srf_f4v*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ float2 srf_ld2(const float* p) {
+  if constexpr (NT) {
+    typedef float srf_f2v __attribute__((ext_vector_type(2)));
+    const srf_f2v t = __builtin_nontemporal_load(reinterpret_cast<const srf_f2v*>(p));
+    return make_float2(t[0], t[1]);
+  } else {
+    return *reinterpret_cast<const float2*>(p);
+  }
+}
+
 __device__ __forceinline__ float srf_prelu(float x, float a) {
   return __builtin_amdgcn_fmed3f(x, a * x, a <= 1.f ? __builtin_inff() : -__builtin_inff());
 }

@@ -51,7 +51,9 @@ size_t srf_x3p_packed_bytes(int Cout, int Cin) {
 // weight DMA, 8 = no activation loads / conversion / ds_write, 16 = no fragment reads, 32 = no barriers.
 // TL (diagnostics, lab builds only; results stay correct): per-wavefront shader-clock totals {whole kernel, counted waits, barriers, epilogues,
 // steps} as 8 dwords per wavefront to `a.mul` (tools/gemm_timeline_x3s.py with TL_GEMM=x3p).
-template <int PRO, int EPI, int ABL = 0, int TL = 0>
+// CP (cache policy, as in srf_pwconv_x3w.hip): bit 0 = non-temporal output stores, bit 2 = non-temporal activation loads -- for the
+// forms whose streamed tensors would otherwise displace the weight image every CU re-reads from L2 for every tile.
+template <int PRO, int EPI, int ABL = 0, int TL = 0, int CP = 0>
 __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt, int total,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ bias_r, int rabl_arg, int stagger) {
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * P_KT + j) * L * 4, 0));
+      r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * P_KT + j) * L * 4, (CP & 4) ? 2 : 0));
   };
   auto lds_store = [&](const Regs& r, const TileP& t, int kt, int stage) __attribute__((always_inline)) {
     if (ABL && (rabl & 8)) return;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
             o.w += e4.w;
           }
           const u32x4 ov = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-          __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, off, 0, (CP & 1) ? 2 : 0);
           if constexpr (EPI == 0) {
             if (ok) {
               s += (o.x + o.y) + (o.z + o.w);
@@ -454,6 +456,7 @@ int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
                          (const void*)&srf_pw_x3p_kernel<2, 0>, (const void*)&srf_pw_x3p_kernel<3, 0>,
                          (const void*)&srf_pw_x3p_kernel<0, 1>, (const void*)&srf_pw_x3p_kernel<1, 1>,
                          (const void*)&srf_pw_x3p_kernel<2, 1>, (const void*)&srf_pw_x3p_kernel<3, 1>,
+                         (const void*)&srf_pw_x3p_kernel<1, 0, 0, 0, 4>, (const void*)&srf_pw_x3p_kernel<2, 1, 0, 0, 4>,
 #ifdef SRF_EXPERIMENTS
                          (const void*)&srf_pw_x3p_kernel<0, 0, 1>, (const void*)&srf_pw_x3p_kernel<2, 1, 1>,
                          (const void*)&srf_pw_x3p_kernel<0, 0, 0, 1>, (const void*)&srf_pw_x3p_kernel<2, 1, 0, 1>,
@@ -487,7 +490,11 @@ int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
     P_GO(2, 1, 1);
   } else
 #endif
-  if (!res) {
+  if (pro == 1 && !res && !(srf_debug_flags() & 2)) {
+    P_GO(1, 0, 0, 0, 4);          // bottleneck
+  } else if (pro == 2 && res && !(srf_debug_flags() & 2)) {
+    P_GO(2, 1, 0, 0, 4);          // res_conv (debug flag 2: the plain cache policy)
+  } else if (!res) {
     switch (pro) {
       case 0: P_GO(0, 0); break;
       case 1: P_GO(1, 0); break;
