@@ -39,7 +39,7 @@ pmc() {    # name, index, counters (comma separated), bench args...
   find "$OUT/pmc_${name}_$i" -name "*.csv" -size +30M -delete
 }
 if [[ $PARTS == *r* ]]; then
-  for w in cfg2_improved_u16 cfg4_improved_u36_n2048 cfg5_improved_u36_n4096; do prof $w --workload $w; done
+  for w in cfg2_improved_u16 cfg3_groupcomm_u8 cfg4_improved_u36_n2048 cfg5_improved_u36_n4096; do prof $w --workload $w; done
   for w in cfg2_improved_u16 cfg4_improved_u36_n2048; do prof train_$w --train --workload $w; done
 fi
 if [[ $PARTS == *p* ]]; then
