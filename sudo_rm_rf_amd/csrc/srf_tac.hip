@@ -619,7 +619,7 @@ extern "C" int srf_tac(const float* x, float* q, const float* const* params, int
   dim3 grid((L + 127) / 128, Bt), block(128);
   hipStream_t st = (hipStream_t)stream;
   // debug flags 1 << 22 / 24 / 25 / 26, 1024: the VALU kernels (the MFMA form serves n = 16, G = 16; 1 << 22 = just not the MFMA form)
-  if (srf_kernel_mode() == 0 && n == 16 && G == 16 && !(srf_debug_flags() & ((1 << 22) | (1 << 24) | (1 << 25) | (1 << 26) | 1024)) &&
+  if (srf_kernel_mode() != 1 && n == 16 && G == 16 && !(srf_debug_flags() & ((1 << 22) | (1 << 24) | (1 << 25) | (1 << 26) | 1024)) &&
       (long)G * n * L * 4 < (1L << 31)) {
     const int tiles_per_row = (L + 31) / 32;
     const long total = (long)Bt * tiles_per_row;
@@ -856,6 +856,447 @@ __global__ __launch_bounds__(256) void srf_tac_bwd_lanes_kernel(TacBwdArgs a, co
   }
 }
 
+// =============================================================================================================================
+// MFMA form of the backward (round 4) for n = 16, H = 48, G = 16: same tile ownership and layout tricks as srf_tac_mfma_kernel.
+// Per 32-column tile and wavefront:
+//   sweep 1 (groups): z_g (fp16 parts, as the forward) -> Z, zsum            | once: zbar -> ZB, pq, q -> Q, r
+//   sweep 2 (groups): z_g again, po_g = Wo[:, :H] z_g + r -> g_po -> GPO, gs | once: GS, g_pq = PReLU'(pq) Wo[:, H:]^T gs -> GPQ,
+//                                                                            |       g_zbar = Wm^T g_pq / G
+//   sweep 3 (groups): pz_g again, g_z = Wo[:, :H]^T g_po + g_zbar, g_pz = PReLU'(pz) g_z -> GPZ, g_x = Wi^T g_pz -> gx
+// The forward recomputation uses the forward kernel's fp16 hi + lo parts (identical z); every GRADIENT operand (g_po, gs, g_pq,
+// g_pz and the transposed weights) is split into two BF16 parts (16 mantissa bits, fp32's exponent range -- gradients can be far
+// below fp16's 6e-5) like the rest of the backward's GEMMs.  g_po is re-read in sweep 3 straight in the B layout from GPO, which
+// this wavefront wrote in sweep 2 (device-scope loads behind a vmcnt(0): other lanes' stores).
+typedef __bf16 tac_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void tac_split8_bf(const float (&v)[8], tac_bf16x8& hi, tac_bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+__device__ __forceinline__ tac_f32x16 tac_mma3_bf(const tac_bf16x8& ah, const tac_bf16x8& al, const tac_bf16x8& bh,
+                                                  const tac_bf16x8& bl, tac_f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+
+__global__ __launch_bounds__(256, 2) void srf_tac_bwd_mfma_kernel(TacBwdArgs a, const float* __restrict__ wi,
+                                                               const float* __restrict__ bi, const float* __restrict__ wo,
+                                                               const float* __restrict__ bo, int tiles_per_row, int total_tiles) {
+  constexpr int NN = 16, HH = 48, G = 16;
+  // A fragments {hi, lo}, 1 KB each.  fp16 (x 2^4): 0..5 Wm (blk * 3 + s), 6..8 Wo[:, H:] (s), 9..11 Wo[:, :H] (s).
+  // bf16: 12..13 Wo[:, H:]^T (blk), 14..19 Wm^T (blk * 3 + s), 20..21 Wo[:, :H]^T (blk), 22..24 Wi^T (s).
+  __shared__ tac_f16x8 s_frag[50][64];
+  __shared__ float s_bias[HH + HH + NN];   // bi | bm | bo
+  __shared__ float s_red[4][3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = lane & 31, h = lane >> 5;
+  const int L = a.L;
+  for (int e = tid; e < HH + HH + NN; e += 256) s_bias[e] = e < HH ? bi[e] : (e < 2 * HH ? a.bm[e - HH] : bo[e - 2 * HH]);
+  for (int id = tid; id < 25 * 64; id += 256) {
+    const int f = id >> 6, ln = id & 63, row32 = ln & 31, kh = ln >> 5;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float w = 0.f;
+      if (f < 6) {
+        const int blk = f / 3, sidx = f - blk * 3, j = blk * 32 + row32, k = 16 * sidx + 8 * kh + e;
+        if (j < HH) w = a.wm[j * HH + k];
+      } else if (f < 12) {
+        const int half = (f - 6) / 3, sidx = (f - 6) - half * 3, k = 16 * sidx + 8 * kh + e;
+        if (row32 < NN) w = wo[row32 * 2 * HH + (half == 0 ? HH : 0) + k];
+      } else if (f < 14) {               // Wo[:, H:]^T [48][16]
+        const int j = (f - 12) * 32 + row32, k = 8 * kh + e;
+        if (j < HH) w = wo[k * 2 * HH + HH + j];
+      } else if (f < 20) {               // Wm^T [48][48]
+        const int blk = (f - 14) / 3, sidx = (f - 14) - blk * 3, j = blk * 32 + row32, k = 16 * sidx + 8 * kh + e;
+        if (j < HH) w = a.wm[k * HH + j];
+      } else if (f < 22) {               // Wo[:, :H]^T [48][16]
+        const int j = (f - 20) * 32 + row32, k = 8 * kh + e;
+        if (j < HH) w = wo[k * 2 * HH + j];
+      } else {                           // Wi^T [16][48]
+        const int sidx = f - 22, k = 16 * sidx + 8 * kh + e;
+        if (row32 < NN) w = wi[k * NN + row32];
+      }
+      v[e] = f < 12 ? w * TAC_WS : w;
+    }
+    if (f < 12) {
+      tac_f16x8 hi, lo;
+      tac_split8(v, hi, lo);
+      s_frag[2 * f][ln] = hi;
+      s_frag[2 * f + 1][ln] = lo;
+    } else {
+      tac_bf16x8 hi, lo;
+      tac_split8_bf(v, hi, lo);
+      s_frag[2 * f][ln] = __builtin_bit_cast(tac_f16x8, hi);
+      s_frag[2 * f + 1][ln] = __builtin_bit_cast(tac_f16x8, lo);
+    }
+  }
+  tac_f16x8 wi_h[2], wi_l[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    float v[8];
+    const int j = blk * 32 + t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = j < HH ? wi[j * NN + 8 * h + e] * TAC_WS : 0.f;
+    tac_split8(v, wi_h[blk], wi_l[blk]);
+  }
+  __syncthreads();
+  tac_f32x16 bi16[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      bi16[blk][r] = row < HH ? s_bias[row] * TAC_WS : 0.f;
+    }
+  const float ai = a.ai[0], am = a.am[0], ao = a.ao[0];
+  float d_ai = 0.f, d_am = 0.f, d_ao = 0.f;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile < total_tiles) {              // (wave-uniform; the block reduction below needs every wavefront)
+    const int b = tile / tiles_per_row, l0 = (tile - b * tiles_per_row) * 32;
+    const int col = l0 + t;
+    const bool valid = col < L;
+    const float vmask = valid ? 1.f : 0.f;
+    auto rsrc = [&](const float* base, size_t per_example_rows) __attribute__((always_inline)) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + (size_t)b * per_example_rows * L, 0,
+                                               (int)(per_example_rows * L * 4), 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t xrs = rsrc(a.x, G * NN), gors = rsrc(a.go, G * NN), gxrs = rsrc(a.gx, G * NN);
+    __amdgpu_buffer_rsrc_t zrs = rsrc(a.Z, G * HH), gpzrs = rsrc(a.GPZ, G * HH), gpors = rsrc(a.GPO, G * NN);
+    __amdgpu_buffer_rsrc_t gsrs = rsrc(a.GS, NN), qrs = rsrc(a.Q, HH), gpqrs = rsrc(a.GPQ, HH), zbrs = rsrc(a.ZB, HH);
+    const int b_vo = valid ? (8 * h * L + col) * 4 : 0x7ffffff0;     // B layout: rows 8 h + e
+    const int c_vo = valid ? (4 * h * L + col) * 4 : 0x7ffffff0;     // C layout: rows (r & 3) + 8 (r >> 2) + 4 h
+
+    struct Raw8 {
+      float v[8];
+    };
+    // 8 rows (row0 + 8 h + e) of this lane's column: a B fragment's values
+    auto load_b8 = [&](__amdgpu_buffer_rsrc_t rs, int row0, Raw8& r, int aux) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (aux) r.v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, b_vo, (row0 + e) * L * 4, 17));
+        else r.v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, b_vo, (row0 + e) * L * 4, 0));
+      }
+    };
+    // C-layout registers c[0 .. n) (16-row groups) <-> rows row0 + (r & 3) + 8 (r >> 2) + 4 h
+    auto store_c = [&](__amdgpu_buffer_rsrc_t rs, int row0, const float* c, int n) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (r < n) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c[r]), rs, c_vo, (row0 + (r & 3) + 8 * (r >> 2)) * L * 4, 0);
+    };
+    auto clamp8 = [&](float (&v)[8]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -60000.f, 60000.f);
+    };
+    // 2^4 (Wi x + bi) of a group in the C layout (pre-activation): zA rows 0..31, zB rows 32..47 (registers 0..7)
+    auto pz_of = [&](Raw8& xr, tac_f32x16& zA, tac_f32x16& zB) __attribute__((always_inline)) {
+      tac_f16x8 xh, xl;
+      clamp8(xr.v);
+      tac_split8(xr.v, xh, xl);
+      zA = tac_mma3(wi_h[0], wi_l[0], xh, xl, bi16[0]);
+      zB = tac_mma3(wi_h[1], wi_l[1], xh, xl, bi16[1]);
+    };
+    auto frags16 = [&](const tac_f32x16& cA, const tac_f32x16& cB, float scale, tac_f16x8 (&fh)[3], tac_f16x8 (&fl)[3])
+        __attribute__((always_inline)) {
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) {
+        float c8[8], v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c8[e] = (sidx < 2 ? cA[8 * sidx + e] : cB[e]) * scale;
+        tac_c_to_b(c8, v);
+        tac_split8(v, fh[sidx], fl[sidx]);
+      }
+    };
+    auto frags_bf = [&](const tac_f32x16& cA, const tac_f32x16& cB, tac_bf16x8 (&fh)[3], tac_bf16x8 (&fl)[3])
+        __attribute__((always_inline)) {
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) {
+        float c8[8], v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c8[e] = sidx < 2 ? cA[8 * sidx + e] : cB[e];
+        tac_c_to_b(c8, v);
+        tac_split8_bf(v, fh[sidx], fl[sidx]);
+      }
+    };
+    auto fragA16 = [&](int f, tac_f16x8& hi, tac_f16x8& lo) __attribute__((always_inline)) {
+      hi = s_frag[2 * f][lane];
+      lo = s_frag[2 * f + 1][lane];
+    };
+    auto fragAbf = [&](int f, tac_bf16x8& hi, tac_bf16x8& lo) __attribute__((always_inline)) {
+      hi = __builtin_bit_cast(tac_bf16x8, s_frag[2 * f][lane]);
+      lo = __builtin_bit_cast(tac_bf16x8, s_frag[2 * f + 1][lane]);
+    };
+
+    // ================= sweep 1: z_g -> Z, zsum
+    tac_f32x16 zsA, zsB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zsA[r] = zsB[r] = 0.f;
+    Raw8 xa, xb;
+    load_b8(xrs, 0, xa, 0);
+    auto sweep1 = [&](Raw8& cur, Raw8& nxt, int g) __attribute__((always_inline)) {
+      load_b8(xrs, (g + 1 < G ? g + 1 : 0) * NN, nxt, 0);
+      tac_f32x16 zA, zB;
+      pz_of(cur, zA, zB);
+      float zs[24];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        zA[r] = srf_prelu(zA[r], ai);
+        zsA[r] += zA[r];
+        zs[r] = zA[r] * (1.f / TAC_WS);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        zB[r] = srf_prelu(zB[r], ai);
+        zsB[r] += zB[r];
+        zs[16 + r] = zB[r] * (1.f / TAC_WS);
+      }
+      store_c(zrs, g * HH, zs, 16);
+      store_c(zrs, g * HH + 32, zs + 16, 8);
+    };
+    for (int g = 0; g < G; g += 2) {
+      sweep1(xa, xb, g);
+      sweep1(xb, xa, g + 1);
+    }
+    // ================= zbar -> ZB; pq, q -> Q; r = Wo[:, H:] q + bo
+    tac_f32x16 r256;
+    {
+      tac_f32x16 pqA, pqB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        zsA[r] *= 1.f / (float)G;          // 2^4 zbar
+        zsB[r] *= 1.f / (float)G;
+      }
+      float zb[24];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zb[r] = zsA[r] * (1.f / TAC_WS);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) zb[16 + r] = zsB[r] * (1.f / TAC_WS);
+      store_c(zbrs, 0, zb, 16);
+      store_c(zbrs, 32, zb + 16, 8);
+      tac_f16x8 fh[3], fl[3];
+      frags16(zsA, zsB, 1.f, fh, fl);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        pqA[r] = s_bias[HH + row] * (TAC_WS * TAC_WS);
+        pqB[r] = row < HH - 32 ? s_bias[HH + 32 + row] * (TAC_WS * TAC_WS) : 0.f;
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) {
+        tac_f16x8 ah, al;
+        fragA16(sidx, ah, al);
+        pqA = tac_mma3(ah, al, fh[sidx], fl[sidx], pqA);
+        fragA16(3 + sidx, ah, al);
+        pqB = tac_mma3(ah, al, fh[sidx], fl[sidx], pqB);
+      }
+      tac_f32x16 qA, qB;
+      float qs[24], pqs[24];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pqA[r] *= 1.f / (TAC_WS * TAC_WS);
+        pqB[r] *= 1.f / (TAC_WS * TAC_WS);
+        qA[r] = srf_prelu(pqA[r], am);
+        qB[r] = srf_prelu(pqB[r], am);
+        qs[r] = qA[r];
+        pqs[r] = pqA[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        qs[16 + r] = qB[r];
+        pqs[16 + r] = pqB[r];
+      }
+      store_c(qrs, 0, qs, 16);
+      store_c(qrs, 32, qs + 16, 8);
+      // pq is needed again behind sweep 2 (PReLU'): parked in GPQ's own slots -- each lane re-reads exactly what it wrote, and
+      // overwrites it with g_pq afterwards -- instead of 24 registers across the sweep
+      store_c(gpqrs, 0, pqs, 16);
+      store_c(gpqrs, 32, pqs + 16, 8);
+      frags16(qA, qB, TAC_WS, fh, fl);           // 2^4 q
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        r256[r] = row < NN ? s_bias[2 * HH + row] * (TAC_WS * TAC_WS) : 0.f;
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) {
+        tac_f16x8 ah, al;
+        fragA16(6 + sidx, ah, al);
+        r256 = tac_mma3(ah, al, fh[sidx], fl[sidx], r256);
+      }
+    }
+    // ================= sweep 2: po_g -> g_po -> GPO, gs
+    float gs[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) gs[r] = 0.f;
+    auto sweep2 = [&](Raw8& cur, Raw8& nxt, int g) __attribute__((always_inline)) {
+      load_b8(xrs, (g + 1 < G ? g + 1 : 0) * NN, nxt, 0);
+      float gov[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        gov[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gors, c_vo, (g * NN + (r & 3) + 8 * (r >> 2)) * L * 4, 0));
+      tac_f32x16 zA, zB;
+      pz_of(cur, zA, zB);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zA[r] = srf_prelu(zA[r], ai);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) zB[r] = srf_prelu(zB[r], ai);
+      tac_f16x8 fh[3], fl[3];
+      frags16(zA, zB, 1.f, fh, fl);
+      tac_f32x16 o = r256;
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) {
+        tac_f16x8 ah, al;
+        fragA16(9 + sidx, ah, al);
+        o = tac_mma3(ah, al, fh[sidx], fl[sidx], o);
+      }
+      float gpo[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float pv = o[r] * (1.f / (TAC_WS * TAC_WS));
+        const float gv = gov[r];                 // (out-of-range columns loaded 0)
+        gpo[r] = pv >= 0.f ? gv : gv * ao;
+        d_ao = pv < 0.f ? fmaf(gv, pv, d_ao) : d_ao;
+        gs[r] += gpo[r];
+      }
+      store_c(gpors, g * NN, gpo, 8);
+    };
+    for (int g = 0; g < G; g += 2) {
+      sweep2(xa, xb, g);
+      sweep2(xb, xa, g + 1);
+    }
+    // ================= GS; g_pq = PReLU'(pq) (Wo[:, H:]^T gs) -> GPQ; g_zbar / G = Wm^T g_pq / G
+    tac_f32x16 gzbA, gzbB;
+    {
+      store_c(gsrs, 0, gs, 8);
+      tac_bf16x8 gh, gl;
+      {
+        float v[8];
+        tac_c_to_b(gs, v);
+        tac_split8_bf(v, gh, gl);
+      }
+      tac_f32x16 gqA, gqB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gqA[r] = gqB[r] = 0.f;
+      tac_bf16x8 ah, al;
+      fragAbf(12, ah, al);
+      gqA = tac_mma3_bf(ah, al, gh, gl, gqA);
+      fragAbf(13, ah, al);
+      gqB = tac_mma3_bf(ah, al, gh, gl, gqB);
+      float gpq[24], pqv[24];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 24; ++r)
+        pqv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            gpqrs, c_vo, ((r < 16 ? 0 : 32) + (r & 3) + 8 * ((r & 15) >> 2)) * L * 4, 17));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float gq = gqA[r], pv = pqv[r];
+        gqA[r] = pv >= 0.f ? gq : gq * am;
+        d_am = pv < 0.f ? fmaf(gq * vmask, pv, d_am) : d_am;
+        gpq[r] = gqA[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float gq = gqB[r], pv = pqv[16 + r];
+        gqB[r] = pv >= 0.f ? gq : gq * am;
+        d_am = pv < 0.f ? fmaf(gq * vmask, pv, d_am) : d_am;
+        gpq[16 + r] = gqB[r];
+      }
+      store_c(gpqrs, 0, gpq, 16);
+      store_c(gpqrs, 32, gpq + 16, 8);
+      tac_bf16x8 fh[3], fl[3];
+      frags_bf(gqA, gqB, fh, fl);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gzbA[r] = gzbB[r] = 0.f;
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) {
+        fragAbf(14 + sidx, ah, al);
+        gzbA = tac_mma3_bf(ah, al, fh[sidx], fl[sidx], gzbA);
+        fragAbf(17 + sidx, ah, al);
+        gzbB = tac_mma3_bf(ah, al, fh[sidx], fl[sidx], gzbB);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        gzbA[r] *= 1.f / (float)G;
+        gzbB[r] *= 1.f / (float)G;
+      }
+    }
+    // ================= sweep 3: g_z = Wo[:, :H]^T g_po + g_zbar / G, g_pz -> GPZ, g_x = Wi^T g_pz
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's GPO stores have left before other lanes read them
+    auto sweep3 = [&](Raw8& cur, Raw8& nxt, int g) __attribute__((always_inline)) {
+      if (g + 1 < G) load_b8(xrs, (g + 1) * NN, nxt, 0);
+      Raw8 gp;
+      load_b8(gpors, g * NN, gp, 1);                    // g_po of the group in the B layout (device-scope loads)
+      tac_f32x16 pzA, pzB;
+      pz_of(cur, pzA, pzB);                             // 2^4 pz
+      tac_bf16x8 gh, gl;
+      tac_split8_bf(gp.v, gh, gl);
+      tac_f32x16 gzA = gzbA, gzB = gzbB;
+      tac_bf16x8 ah, al;
+      fragAbf(20, ah, al);
+      gzA = tac_mma3_bf(ah, al, gh, gl, gzA);
+      fragAbf(21, ah, al);
+      gzB = tac_mma3_bf(ah, al, gh, gl, gzB);
+      float gpz[24];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = pzA[r] * (1.f / TAC_WS), gz = gzA[r];
+        gzA[r] = pv >= 0.f ? gz : gz * ai;
+        d_ai = pv < 0.f ? fmaf(gz * vmask, pv, d_ai) : d_ai;
+        gpz[r] = gzA[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float pv = pzB[r] * (1.f / TAC_WS), gz = gzB[r];
+        gzB[r] = pv >= 0.f ? gz : gz * ai;
+        d_ai = pv < 0.f ? fmaf(gz * vmask, pv, d_ai) : d_ai;
+        gpz[16 + r] = gzB[r];
+      }
+      store_c(gpzrs, g * HH, gpz, 16);
+      store_c(gpzrs, g * HH + 32, gpz + 16, 8);
+      tac_bf16x8 fh[3], fl[3];
+      frags_bf(gzA, gzB, fh, fl);
+      tac_f32x16 gx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) {
+        fragAbf(22 + sidx, ah, al);
+        gx = tac_mma3_bf(ah, al, fh[sidx], fl[sidx], gx);
+      }
+      float gxv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) gxv[r] = gx[r];
+      store_c(gxrs, g * NN, gxv, 8);
+    };
+    load_b8(xrs, 0, xa, 0);
+    for (int g = 0; g < G; g += 2) {
+      sweep3(xa, xb, g);
+      sweep3(xb, xa, g + 1);
+    }
+  }
+  // ---- slope gradients: wavefront sums, block sum, one atomic per block and slope
+  d_ai = srf_dpp_wave_sum(d_ai);
+  d_am = srf_dpp_wave_sum(d_am);
+  d_ao = srf_dpp_wave_sum(d_ao);
+  if (lane == 63) {
+    s_red[wave][0] = d_ai;
+    s_red[wave][1] = d_am;
+    s_red[wave][2] = d_ao;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const float tsum = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    if (tsum != 0.f) atomicAdd(a.dslope + tid, tsum);
+  }
+}
+
 template <int NN>
 static bool srf_tac_bwd_g(const TacBwdArgs& a, const float* const* P, int Bt, hipStream_t st) {
 #define SRF_TAC_BWD_GO(GG)                                                                                  \
@@ -928,7 +1369,16 @@ extern "C" int srf_tac_bwd(const float* x, const float* go, const float* const* 
   a.G = G;
   a.L = L;
   SRF_CHECK_HIP(hipMemsetAsync(a.dslope, 0, 3 * sizeof(float), st));
-  bool ok = false;
+  bool ok = false, mfma = false;
+  // debug flag 1 << 22: the VALU kernel (the MFMA form serves n = 16, G = 16)
+  if (srf_kernel_mode() != 1 && n == 16 && G == 16 && !(srf_debug_flags() & (1 << 22)) && (long)G * H * L * 4 < (1L << 31) &&
+      (long)Bt * ((L + 31) / 32) < (1L << 30)) {
+    const int tiles_per_row = (L + 31) / 32;
+    const long total = (long)Bt * tiles_per_row;
+    hipLaunchKernelGGL(srf_tac_bwd_mfma_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, a, params[0], params[1],
+                       params[6], params[7], tiles_per_row, (int)total);
+    ok = mfma = true;
+  } else
   switch (n) {
     case 2: ok = srf_tac_bwd_g<2>(a, params, Bt, st); break;
     case 4: ok = srf_tac_bwd_g<4>(a, params, Bt, st); break;
@@ -940,7 +1390,11 @@ extern "C" int srf_tac_bwd(const float* x, const float* go, const float* const* 
     srf_set_error("srf_tac_bwd: n=%d, G=%d unsupported (n in 2,4,8,16; G in 2,4,8,16)", n, G);
     return SRF_EINVAL;
   }
-  SRF_CHECK_LAUNCH("tac_bwd", st);
+  if (mfma) {
+    SRF_CHECK_LAUNCH("tac_bwd_mfma", st);
+  } else {
+    SRF_CHECK_LAUNCH("tac_bwd", st);
+  }
   int rc;
   // weight / bias gradients: four reductions over (batch, group, time) as weight-gradient GEMMs
   rc = srf_pw_wgrad(a.GPZ, x, nullptr, (int)BG, n, H, L, grads[0], grads[1], 1, wg, stream);              // dWi, dbi
