@@ -118,8 +118,9 @@ int srf_profile_get(int i, const char** name, float* ms);
  *            every other caller the paired-block kernel (srf_pwconv_x3p.hip) -- default: the paired form inside the forward only
  *   16384    training forward: three bf16 parts per operand (6 MFMAs, round 3) instead of two fp16 parts (3 MFMAs, round 4)
  *   32768    WITHOUT the fused tail: mask GEMM -> masked tensor -> decoder frame GEMM -> overlap-add as separate launches
- *   bits 16-23  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating; the GEMM's
+ *   bits 16-21  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating; the GEMM's
  *            only in lab builds: SRF_BUILD_EXPERIMENTS=1 python -m sudo_rm_rf_amd.build -> libsudormrf_hip_lab.so)
+ *   1<<22    TAC forward / backward on the VALU kernels instead of the MFMA forms (n = 16, G = 16)
  *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
  *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)
  *   1<<29 / 1<<30  chunked depthwise-backward / scalar GlobLN-backward kernels and no backward fusion
