@@ -323,8 +323,8 @@ def power_pass(run, seconds=2.0):
 
 def pmc_traffic(kernel_family, workload, train=False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE are collected in their own runs of this same command -- tools/gpu_profiles.sh, summarised by
-    tools/collect_profiles3.py -- and stored under profiles/; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
+    WRITE_SIZE are collected in their own runs of this same command -- tools/gpu_profiles_r4.sh, summarised by
+    tools/collect_profiles4.py -- and stored under profiles/; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     for gfx950)."""
     short = {"cfg2_improved_u16": "cfg2_bs32", "cfg4_improved_u36_n2048": "cfg4_u36_n2048_bs32",
              "cfg5_improved_u36_n4096": "cfg5_u36_n4096_8s16k_bs16"}.get(workload)
