@@ -186,7 +186,12 @@ int srf_pw_conv(const float* x, const float* w, const float* bias, float* y,
  * into bf16 hi/lo and laid out tile-by-tile ONCE (srf_forward does it at the start of every forward for
  * all its 1x1 convolutions, in one launch).  srf_packed_pw_weight_bytes() = 0 when the shape does not
  * qualify (needs Cin % 64 == 0, Cout >= 192); srf_pw_conv_packed() with w_packed = NULL (or a
- * non-qualifying shape / mode) is exactly srf_pw_conv().  packed buffers: 16-B aligned device memory. */
+ * non-qualifying shape / mode) is exactly srf_pw_conv().  packed buffers: 16-B aligned device memory.
+ * Round 4: a packed buffer holds TWO layouts of the same bf16 parts, written by the one pack launch -- the image of the
+ * one-block-per-CU kernel (srf_pwconv_x3w.hip: what srf_pw_conv_packed runs) and the image of the paired-block kernel
+ * (srf_pwconv_x3p.hip: two co-resident blocks per CU, bit-identical outputs, what srf_forward / srf_separate run for their
+ * proj_1x1 / res_conv / bottleneck GEMMs so that a caller's second stream can share the CUs); srf_packed_pw_weight_bytes
+ * covers both.  Always size the buffer with that function. */
 size_t srf_packed_pw_weight_bytes(int Cout, int Cin);
 int srf_pack_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n,
                         void* stream);
@@ -194,7 +199,9 @@ int srf_pw_conv_packed(const float* x, const float* w, const void* w_packed, con
                        int Bt, int Cin, int Cout, int L, const srf_norm* in_norm, const float* residual,
                        double* out_sums, int epilogue_mask, const float* mul, int mul_channels, void* stream);
 
-/* The same GEMM with THREE bf16 parts per operand (h + m + l = 24 mantissa bits) and six MFMAs per product block: results in
+/* The same GEMM in the exact-fp32 class for the training forward.  Round 4 (default): TWO FP16 parts per operand (22 mantissa
+ * bits, three MFMAs per product block, the inference kernel's speed; operands beyond +-6e4 are clamped).  Debug flag 16384:
+ * round 3's form, THREE bf16 parts per operand (h + m + l = 24 mantissa bits) and six MFMAs per product block: results in
  * the exact-fp32 class (what srf_forward_train needs: the two-part kernel's 2^-17 representation error is amplified by the
  * early layers' gradients) at ~1.6 x the two-part kernel's time.  Weights packed by srf_pack3_pw_weights (bytes:
  * srf_packed3_pw_weight_bytes, 0 = shape not taken).  No mask epilogue; residual only together with a GlobLN + PReLU
