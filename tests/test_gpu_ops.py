@@ -611,6 +611,40 @@ def test_tac(Bt, G, n, L, flags):
         ops.set_debug_flags(0)
 
 
+def test_tac_mfma_forms_serve_the_cfg3_shape_and_agree_with_the_valu_kernels():
+    """n = 16, G = 16 (BASELINE's GroupComm shape) runs on the matrix pipe -- the in-library profiler proves which kernel served
+    the call, forward and backward -- and agrees with the VALU kernels (debug flag 1 << 22) far inside test_tac's bar: two
+    independent implementations of groupcomm_sudormrf_v2.py:356-377."""
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+    Bt, G, n, L = 3, 16, 16, 1000
+    H = 3 * n
+    x = dev32(rnd(Bt, G, n, L, seed=180, scale=2.0))
+    go = dev32(rnd(Bt, G, n, L, seed=189, scale=1e-4))           # (gradient-sized: far below fp16's normal range)
+    P = [dev32(t) for t in (rnd(H, n, seed=181, scale=n ** -0.5), rnd(H, seed=182, scale=0.2),
+                            torch.tensor([0.2], dtype=torch.float64), rnd(H, H, seed=183, scale=H ** -0.5),
+                            rnd(H, seed=184, scale=0.2), torch.tensor([0.3], dtype=torch.float64),
+                            rnd(n, 2 * H, seed=185, scale=(2 * H) ** -0.5), rnd(n, seed=186, scale=0.2),
+                            torch.tensor([0.15], dtype=torch.float64))]
+    with ops.kernel_trace(DEV) as tr:
+        q = ops.tac(x, P)
+        gx, grads = ops.tac_bwd(x, go, P)
+    assert {"tac_mfma", "tac_bwd_mfma"} <= tr.names, tr.names
+    try:
+        ops.set_debug_flags(1 << 22)
+        with ops.kernel_trace(DEV) as tr2:
+            q2 = ops.tac(x, P)
+            gx2, grads2 = ops.tac_bwd(x, go, P)
+    finally:
+        ops.set_debug_flags(0)
+    assert {"tac", "tac_bwd"} <= tr2.names and not (tr2.names & {"tac_mfma", "tac_bwd_mfma"}), tr2.names
+    assert float((q - q2).abs().max()) <= 5e-6 * max(1.0, float(q2.abs().max()))
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(gx, gx2) <= 3e-5, rel(gx, gx2)
+    for i, (g1, g2) in enumerate(zip(grads, grads2)):
+        assert rel(g1, g2) <= 5e-5, (i, rel(g1, g2))
+
+
 def _tac_case(Bt, G, n, L):
     from sudo_rm_rf_amd import ops
     H = 3 * n
