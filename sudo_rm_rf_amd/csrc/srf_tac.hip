@@ -893,6 +893,9 @@ __global__ __launch_bounds__(256, 2) void srf_tac_bwd_mfma_kernel(TacBwdArgs a, 
   __shared__ tac_f16x8 s_frag[50][64];
   __shared__ float s_bias[HH + HH + NN];   // bi | bm | bo
   __shared__ float s_red[4][3];
+  // wave-private [48 rows][32 columns] strips (pitch 36): the big operand tensors (Z, GPZ: 24 registers per lane and group) leave
+  // as float4 row stores -- 6 vector-memory instructions instead of 24 dword ones (the paired-block GEMM's epilogue lesson)
+  __shared__ __attribute__((aligned(16))) float s_strip[4][HH * 36];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 31, h = lane >> 5;
@@ -994,6 +997,28 @@ __global__ __launch_bounds__(256, 2) void srf_tac_bwd_mfma_kernel(TacBwdArgs a, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -60000.f, 60000.f);
     };
+    // 48 rows (C layout: c[0..15] rows 0..31, c[16..23] rows 32..47) of this tile -> rows row0 .. row0 + 47 of `rs`, through the strip
+    float* strip = s_strip[wave];
+    auto store_rows48 = [&](__amdgpu_buffer_rsrc_t rs, int row0, const float* c) __attribute__((always_inline)) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int r = 0; r < 24; ++r)
+        strip[((r < 16 ? 0 : 32) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h) * 36 + t] = c[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(strip + row * 36 + c4);
+        const u32x4 ov = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        const int off = l0 + c4 < L ? ((row0 + row) * L + l0 + c4) * 4 : 0x7ffffff0;     // (L % 4 == 0: whole float4s)
+        __builtin_amdgcn_raw_buffer_store_b128(ov, rs, off, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     // 2^4 (Wi x + bi) of a group in the C layout (pre-activation): zA rows 0..31, zB rows 32..47 (registers 0..7)
     auto pz_of = [&](Raw8& xr, tac_f32x16& zA, tac_f32x16& zB) __attribute__((always_inline)) {
       tac_f16x8 xh, xl;
@@ -1056,8 +1081,7 @@ __global__ __launch_bounds__(256, 2) void srf_tac_bwd_mfma_kernel(TacBwdArgs a, 
         zsB[r] += zB[r];
         zs[16 + r] = zB[r] * (1.f / TAC_WS);
       }
-      store_c(zrs, g * HH, zs, 16);
-      store_c(zrs, g * HH + 32, zs + 16, 8);
+      store_rows48(zrs, g * HH, zs);
     };
     for (int g = 0; g < G; g += 2) {
       sweep1(xa, xb, g);
@@ -1258,8 +1282,7 @@ __global__ __launch_bounds__(256, 2) void srf_tac_bwd_mfma_kernel(TacBwdArgs a, 
         d_ai = pv < 0.f ? fmaf(gz * vmask, pv, d_ai) : d_ai;
         gpz[16 + r] = gzB[r];
       }
-      store_c(gpzrs, g * HH, gpz, 16);
-      store_c(gpzrs, g * HH + 32, gpz + 16, 8);
+      store_rows48(gpzrs, g * HH, gpz);
       tac_bf16x8 fh[3], fl[3];
       frags_bf(gzA, gzB, fh, fl);
       tac_f32x16 gx;
