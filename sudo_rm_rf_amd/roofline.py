@@ -174,13 +174,88 @@ def train_flops_per_example(variant, B, C, U, D, K, N, S, T, G=1):
     return 3.0 * flops_per_example(variant, B, C, U, D, K, N, S, T, G)
 
 
+def _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A):
+    """GroupComm step (groupcomm_sudormrf_v2.py:232-339; csrc/srf_train.hip with gc = true): per block a TAC (MLP over the G groups
+    of n = B / G channels, hidden H = 3 n) and a U-ConvBlock on the (batch x group)-folded tensor [Bt G, B / G -> C / G, L].  Folding
+    does not change a family's bytes (Bt G rows of C / G channels = Bt rows of C), so the pyramid / norm / depthwise entries are
+    the Improved model's; the per-group 1x1 convs and their gradients run on the thin-shape kernels."""
+    L = frames(T, K, D)
+    f = 4.0 * Bt
+    n = B // G
+    H = 3 * n
+    GH = G * H                                   # rows of the TAC's hidden tensors per example
+    SN, SK = S * A * N, S * A * K
+    P = n_params("groupcomm", B, C, U, D, K, N, S, G, A)
+    lv = [L >> k for k in range(D)]
+    lev_sum = sum(lv)
+    fam = {}
+
+    def add(name, nbytes, flops=0.0):
+        b0, f0 = fam.get(name, (0.0, 0.0))
+        fam[name] = (b0 + nbytes, f0 + flops)
+
+    tac_flops = 2.0 * Bt * L * (2 * G * n * H + H * H + n * H + G * n * H)
+    # ---- forward (training)
+    add("encoder", f * (A * T + N * L), 2.0 * Bt * N * A * K * L)
+    add("pw_conv_x3w4<1>", f * L * (N + B), 2.0 * Bt * N * B * L)
+    add("tac_mfma", U * f * L * 2 * B, U * tac_flops)
+    add("pw_conv_small", U * f * L * (3 * B + C), U * 2.0 * Bt * B * C * L / G)        # proj: x, q in; u, y out
+    dw = 2.0 * 5 * Bt * C * lev_sum
+    add("pyramid_moments", U * f * C * L, U * dw)
+    add("pyramid_finalize", U * 8.0 * Bt * C * D * 5)
+    add("pyramid_merge_save", U * f * C * (2 * L + lev_sum), U * (dw + 2.0 * D * Bt * C * L))
+    add("pw_conv_small", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L / G)        # res_conv + residual
+    add("pw_conv_x3w4<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
+    add("mask_apply", f * L * (2 * SN + N), 2.0 * Bt * SN * L)
+    add("pw_conv_bf16x3_p8<0>", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)
+    add("overlap_add", f * (SK * L + S * A * T), 3.0 * Bt * S * A * T)
+    add("pit_sisdr_stats", f * 2 * S * T, 2.0 * Bt * (4 * S + S * S) * T)
+    add("pit_sisdr_grad", f * 3 * S * T, 4.0 * Bt * S * T)
+    # ---- backward: tail (as the Improved model)
+    add("frames_gather", f * (S * A * T + SK * L) + f * (A * T + A * K * L))
+    add("pw_wgrad", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)
+    add("pw_conv_mfma", f * L * (SK + SN), 2.0 * Bt * SN * SK * L)
+    add("mask_bwd", f * L * (3 * SN + 2 * N), 3.0 * Bt * SN * L)
+    add("pw_wgrad", f * L * (SN + B), 2.0 * Bt * SN * B * L)
+    add("pw_conv_x3w<0>", f * L * (SN + B), 2.0 * Bt * SN * B * L)
+    add("prelu_bwd", f * 3 * B * L, 2.0 * Bt * B * L)
+    # ---- backward: U blocks
+    add("pw_wgrad_small", U * 2 * f * L * (B + C), U * 2 * 2.0 * Bt * B * C * L / G)   # res_conv / proj weight gradients
+    add("pw_conv_small", U * (f * L * (B + C) + f * L * (C + 2 * B)), U * 2 * 2.0 * Bt * B * C * L / G)   # their data gradients
+    add("gln_bwd_reduce", U * f * C * 2 * (L + lv[-1]), U * 4.0 * Bt * C * (L + lv[-1]))
+    add("gln_bwd_apply", U * f * C * (3 * L + (lev_sum - L)) + U * f * C * 3 * L, U * 16.0 * Bt * C * L)
+    dwb = 4 * L + sum(2 * lv[k] + 3 * lv[k - 1] for k in range(1, D))
+    add("dwconv5_bwd", U * f * C * dwb, U * 2.0 * 15 * Bt * C * lev_sum)
+    # TAC backward: x, g_o in (g_po re-read); g_x, Z, GPZ, GPO out (+ the [Bt, H | n, L] tensors of the group mean path)
+    add("tac_bwd_mfma", U * f * L * (5 * B + 2 * GH + 4 * H + n), U * 3.0 * tac_flops)
+    add("gln_bwd_reduce", U * f * B * 2 * L, U * 4.0 * Bt * B * L)                     # TAC_norm
+    add("gln_bwd_apply", U * f * B * 3 * L, U * 8.0 * Bt * B * L)
+    add("accumulate", U * f * B * 3 * L)
+    # the TAC's four weight gradients: g_pz x^T, g_po z^T over (batch, group, time); (sum_g g_po) q^T, g_pq zbar^T over (batch, time)
+    add("pw_wgrad_small", U * (2 * f * L * (GH + B) + f * L * (n + H) + f * L * 2 * H),
+        U * 2.0 * Bt * L * (2 * G * n * H + n * H + H * H))
+    # ---- backward: head
+    add("pw_wgrad", f * L * (B + N), 2.0 * Bt * B * N * L)
+    add("pw_conv_x3w<0>", f * L * (B + N), 2.0 * Bt * B * N * L)
+    add("gln_bwd_reduce", f * N * 2 * L, 4.0 * Bt * N * L)
+    add("gln_bwd_apply", f * N * 4 * L, 8.0 * Bt * N * L)
+    add("pw_wgrad", f * L * (N + A * K), 2.0 * Bt * N * A * K * L)
+    add("grad_sqnorm", 4.0 * P)
+    add("clip_adam", 28.0 * P, 12.0 * P)
+    return fam
+
+
 def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
     """{profiler family: (algorithmic bytes per step, FLOPs per step)} of srf_forward_train + the loss + srf_backward + the
     optimizer for the IMPROVED model (csrc/srf_train.hip is the launch sequence this mirrors; launches per step come from the
     in-library profiler, so per-launch figures = these totals / the launches counted).  Bytes = tensors a kernel family must read
-    + write once per launch, fp32, weights ignored.  GroupComm: None (its thin-shape / TAC families are not modelled)."""
-    if variant != "improved":
+    + write once per launch, fp32, weights ignored.  GroupComm (round 4): the families of its blocks -- TAC forward / backward on
+    the matrix pipe, the thin-shape convs and weight gradients, the (batch x group)-folded pyramid and norm backwards -- plus the
+    head / tail families it shares with the Improved model."""
+    if variant not in ("improved", "groupcomm"):
         return None
+    if variant == "groupcomm":
+        return _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A)
     L = frames(T, K, D)
     f = 4.0 * Bt
     SN, SK = S * A * N, S * A * K

@@ -60,7 +60,14 @@ def test_training_byte_and_flop_model():
     want = 2 * R.bytes_per_example(**d2) + 4.0 * (512 * L + 16 * (256 * L + (4 - 2.0 ** -4) * 512 * L) + 256 * L) + 4.0 * 3 * 2 * 512 * L
     assert abs(R.train_bytes_per_example(**d2) - want) < 1.0
     fam = R.train_family_model(Bt=32, **d2)
-    assert R.train_family_model(Bt=32, **d3) is None
+    fam3 = R.train_family_model(Bt=32, **d3)              # GroupComm (round 4): its own block families, the shared head / tail
+    for name in ("tac_mfma", "tac_bwd_mfma", "pw_conv_small", "pw_wgrad_small", "dwconv5_bwd", "gln_bwd_apply", "pyramid_merge_save"):
+        assert fam3[name][0] > 0, name
+    assert not any(k.startswith("pw_conv_x3w4<0>") or k.startswith("pw_conv_x3w4<2>") for k in fam3)     # no block GEMMs on the MFMA kernels
+    # the TAC backward writes the operand tensors of its weight gradients: Z and GPZ ([Bt G, H, L]) dominate its bytes
+    assert fam3["tac_bwd_mfma"][0] > 8 * 4.0 * 32 * L * 2 * 16 * 48
+    ks3 = sum(b for b, _ in fam3.values())
+    assert 1.0 < ks3 / (32 * R.train_bytes_per_example(**d3)) < 2.5
     for name in ("pw_conv_x3w4<0>", "pw_conv_x3w4<2>", "pw_conv_x3w<0>", "pw_wgrad", "dwconv5_bwd", "gln_bwd_apply", "gln_bwd_reduce",
                  "pyramid_merge_save", "pyramid_moments", "clip_adam"):
         assert fam[name][0] > 0, name
