@@ -781,7 +781,8 @@ def main():
             model._engine().multi_stream = was_multi_p
             engine_mod._GRAPH_MODE = was_graph
         launches = roofline.launch_model(Bt=batch, kernel_mode=args.kernel_mode, packed=not (args.debug_flags & 8),
-                                         fuse_tail=not (args.debug_flags & (4 | 32768)), **dims)
+                                         fuse_tail=not (args.debug_flags & (4 | 32768)),
+                                         pairs=not (args.debug_flags & (1 | 4 | 16)), **dims)
         per = {}
         name, ms = C.c_char_p(), C.c_float()
         marks = []
@@ -805,11 +806,11 @@ def main():
                           "algorithmic_GBps": e["bytes"] / sec / 1e9, "TFLOPs": e["flops"] / sec / 1e12}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_forward"])
         kd = kernels[dom]
-        if dom.startswith("pw_conv"):
+        if dom.startswith(("pw_conv", "pw_pair")):
             # Two ceilings for a 1x1-conv GEMM: the matrix pipe (fp32-equivalent FLOPs; the split-precision kernels issue 3
             # bf16 MFMAs per product block, so their peak is the bf16 dense peak / 3) and HBM (algorithmic bytes).  The
             # BINDING one -- the larger time floor -- is reported as the roofline, the other beside it.
-            split = dom.startswith(("pw_conv_bf16x3", "pw_conv_x3w", "pw_conv_x3p"))
+            split = dom.startswith(("pw_conv_bf16x3", "pw_conv_x3w", "pw_conv_x3p", "pw_pair_x3f"))
             peak = roofline.MFMA_BF16_PEAK_TFLOPS / 3 if split else roofline.MFMA_F32_PEAK_TFLOPS
             mfma = {"bound": "mfma", "achieved": kd["TFLOPs"], "peak": peak, "unit": "TFLOP/s", "frac": kd["TFLOPs"] / peak,
                     "note": ("algorithmic fp32 FLOPs (2*Cin*Cout per output); peak = bf16 dense MFMA peak / 3 because "

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 12
+#define SRF_ABI_VERSION 13
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -105,6 +105,7 @@ int srf_profile_get(int i, const char** name, float* ms);
  * NOT part of the drop-in surface: process-wide switches between kernel variants for A/B measurements and bisection
  * (tools/, bench.py --debug-flags, a handful of tests).  They act on every thread's subsequent launches; a caller that does
  * not define SRF_DIAGNOSTICS before including this header does not see them.  Default 0 = the shipped paths.
+ *   1        srf_forward WITHOUT the fused conv pairs (round 5: res_conv / bottleneck + the next proj_1x1 in one launch)
  *   2        round-2 GEMM: swap the fragment-read order; round-3 GEMM: no m-tile groups (round 2's tile order)
  *   4        without the 256 x 128 GEMM (128 x 128 kernels)
  *   8        WITHOUT pre-packed weights (srf_forward packs by default)
@@ -120,6 +121,7 @@ int srf_profile_get(int i, const char** name, float* ms);
  *   32768    WITHOUT the fused tail: mask GEMM -> masked tensor -> decoder frame GEMM -> overlap-add as separate launches
  *   bits 16-21  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating; the GEMM's
  *            only in lab builds: SRF_BUILD_EXPERIMENTS=1 python -m sudo_rm_rf_amd.build -> libsudormrf_hip_lab.so)
+ *   1<<23    fused conv pair with every counted wait of its DMA pipeline as a full drain (bisection aid, same results)
  *   1<<22    TAC forward / backward on the VALU kernels instead of the MFMA forms (n = 16, G = 16)
  *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
  *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)
@@ -127,6 +129,9 @@ int srf_profile_get(int i, const char** name, float* ms);
  *   1<<31    training forward on the exact-fp32 MFMA kernel instead of the three-part split GEMM (pass INT_MIN) */
 #ifdef SRF_DIAGNOSTICS
 void srf_set_debug_flags(int flags);
+/* the calling thread's next srf_pw_conv_pair launches record per-wavefront shader-clock totals {kernel, conv 1, epilogue 1, conv 2,
+ * epilogues 2, tiles, -, -} (8 dwords per wavefront, 4 wavefronts per block, block-major) into buf (device, >= 64 KB); NULL = off */
+void srf_diag_pair_timeline(void* buf);
 #endif
 
 /* ---- whole-model path ---------------------------------------------------------------------- */
@@ -198,6 +203,21 @@ int srf_pack_pw_weights(const float* const* w, void* const* packed, const int* C
 int srf_pw_conv_packed(const float* x, const float* w, const void* w_packed, const float* bias, float* y,
                        int Bt, int Cin, int Cout, int L, const srf_norm* in_norm, const float* residual,
                        double* out_sums, int epilogue_mask, const float* mul, int mul_channels, void* stream);
+
+/* Round 5: TWO 1x1 convolutions back to back in ONE launch (csrc/srf_pwconv_x3f.hip) -- a conv with Cmid = 256 output channels
+ * and the conv that consumes its output, the 256-channel tensor handed over in registers (it is still written to y: it is the
+ * model's residual stream):
+ *     y  = W1 f(x) + bias1 (+ residual)     f = in_norm: GlobLN (bottleneck, improved_sudormrf.py:292: no residual) or
+ *                                           GlobLN + PReLU (res_conv, :218-220: residual required)
+ *     y2 = W2 y + bias2,  out_sums2 (nullable) += {sum, sumsq} of y2          (proj_1x1 of the next block, :205)
+ * Results are BIT-IDENTICAL to srf_pw_conv_packed(x -> y) followed by srf_pw_conv_packed(y -> y2) (statistics: to rounding).
+ * w1_packed / w2_packed: buffers of srf_pack_pw_weights for [Cmid, Cin1] / [Cout2, Cmid].  srf_pw_conv_pair_supported: the
+ * shapes served (Cmid = 256, Cin1 % 64 == 0, 128 <= Cin1 <= 512, Cout2 % 128 == 0, Cout2 <= 512, L % 4 == 0, Bt <= 512, at least as
+ * many 128-column tiles as CUs) under the default kernel mode; srf_forward uses the pair wherever this says 1. */
+int srf_pw_conv_pair_supported(int Bt, int Cin1, int Cmid, int Cout2, int L);
+int srf_pw_conv_pair(const float* x, const void* w1_packed, const float* bias1, float* y, const srf_norm* in_norm,
+                     const float* residual, const void* w2_packed, const float* bias2, float* y2, double* out_sums2,
+                     int Bt, int Cin1, int Cmid, int Cout2, int L, void* stream);
 
 /* The same GEMM in the exact-fp32 class for the training forward.  Round 4 (default): TWO FP16 parts per operand (22 mantissa
  * bits, three MFMAs per product block, the inference kernel's speed; operands beyond +-6e4 are clamped).  Debug flag 16384:

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # SRF_LIB: an alternative build of the same library (same-box A/B of kernel variants, tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SRF_LIB") or os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 STAT_BUCKETS = 64
 
 SRF_OK = 0
@@ -57,9 +57,12 @@ _PROTOS = {
     "srf_gln_apply_add": (_i, [_vp, _vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _vp]),
     "srf_pw_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _i, _vp, _i, _vp]),
     "srf_set_debug_flags": (None, [_i]),
+    "srf_diag_pair_timeline": (None, [_vp]),
     "srf_packed_pw_weight_bytes": (_sz, [_i, _i]),
     "srf_pack_pw_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
     "srf_pw_conv_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _i, _vp, _i, _vp]),
+    "srf_pw_conv_pair_supported": (_i, [_i, _i, _i, _i, _i]),
+    "srf_pw_conv_pair": (_i, [_vp, _vp, _vp, _vp, C.POINTER(srf_norm), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srf_packed3_pw_weight_bytes": (_sz, [_i, _i]),
     "srf_pack3_pw_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
     "srf_pw_conv_packed3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _vp]),

@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libsudormrf_hip.so")
-SOURCES = ["srf_api.hip", "srf_encoder.hip", "srf_elementwise.hip", "srf_dwconv.hip", "srf_pyramid.hip", "srf_pyramid_reg.hip", "srf_pwconv.hip", "srf_pwconv_bf16x3.hip", "srf_pwconv_x3w.hip", "srf_pwconv_x3p.hip", "srf_pwconv_w4.hip", "srf_pwconv_small.hip",
+SOURCES = ["srf_api.hip", "srf_encoder.hip", "srf_elementwise.hip", "srf_dwconv.hip", "srf_pyramid.hip", "srf_pyramid_reg.hip", "srf_pwconv.hip", "srf_pwconv_bf16x3.hip", "srf_pwconv_x3w.hip", "srf_pwconv_x3p.hip", "srf_pwconv_x3f.hip", "srf_pwconv_w4.hip", "srf_pwconv_small.hip",
            "srf_tac.hip", "srf_loss.hip", "srf_pwconv_wgrad.hip", "srf_backward.hip", "srf_train.hip", "srf_augment.hip", "srf_optim.hip", "srf_feeder.hip"]
 HEADERS = [os.path.join(CSRC, "srf_common.h"), os.path.join(CSRC, "srf_pw.h"), os.path.join(CSRC, "srf_plan.h"), os.path.join(CSRC, "srf_pyr.h"),
            os.path.join(os.path.dirname(PKG), "include", "sudormrf_hip.h")]
@@ -37,6 +37,7 @@ FILE_FLAGS = {
     "experiments/srf_pwconv_x3s.hip": ["-fno-slp-vectorize"],
     "experiments/srf_pwconv_x3t.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_x3p.hip": ["-fno-slp-vectorize"],
+    "srf_pwconv_x3f.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_w4.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_wgrad.hip": ["-fno-slp-vectorize"],
     "srf_pwconv.hip": ["-fno-slp-vectorize"],

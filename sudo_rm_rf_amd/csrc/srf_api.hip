@@ -163,6 +163,10 @@ int srf_mask_decode(const float* x, const float* w, const void* w_packed, const 
 int srf_encoder_impl(const float* wav, const float* w, float* out, double* sums, int Bt, int A, int T, int N, int K, int L,
                      const float* in_stats, void* stream);
 extern "C" int srf_wav_stats(const float* wav, float* stats, int rows, int T, void* stream);
+extern "C" int srf_pw_conv_pair_supported(int Bt, int Cin1, int Cmid, int Cout2, int L);
+extern "C" int srf_pw_conv_pair(const float* x, const void* w1_packed, const float* bias1, float* y, const srf_norm* in_norm,
+                                const float* residual, const void* w2_packed, const float* bias2, float* y2, double* out_sums2,
+                                int Bt, int Cin1, int Cmid, int Cout2, int L, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // decoder = transpose(weight) -> frame GEMM (K2) -> overlap-add + crop
@@ -429,15 +433,30 @@ static int srf_forward_body(const srf_plan* p, const float* const* P, int num_pa
   if (rc) return rc;
   float* cur = fptr(p->off_xa);
   float* nxt = fptr(p->off_xb);
+  float* y1 = fptr(p->off_y1);
+  // Round 5: a 1x1 conv with 256 output channels and the proj_1x1 that consumes its output run as ONE launch, the 256-channel
+  // tensor handed over in registers (srf_pwconv_x3f.hip): bottleneck -> proj_1x1 of block 0, res_conv of block i -> proj_1x1 of
+  // block i + 1 (improved_sudormrf.py:292 -> :205, :220 -> :205).  Needs the fused pyramid (its merged tensor has a buffer of
+  // its own: the pair kernel writes y1 while it reads the merged tensor).  Debug flag 1 = separate launches.
+  const bool pyr_fused_now = p->fused_pyramid && srf_kernel_mode() != 1 && !(srf_debug_flags() & 16);
+  const int pu0 = p->p_block0 + p->p_ublock_off;
+  const bool pair_res = !gc && use_pack && pyr_fused_now && packed(pu0) && packed(pu0 + 5 + 4 * D + 3) &&
+                        srf_pw_conv_pair_supported(Bt, nC, nB, nC, L);
+  const bool pair_head = pair_res && packed(3) && srf_pw_conv_pair_supported(Bt, N, nB, nC, L);
+  bool y1_ready = false;      // proj_1x1 of the coming block has already been computed (with its statistics) by a pair launch
   {
     srf_norm ln{slot(0), P[1], P[2], nullptr};
-    rc = srf_pw_conv_packed(enc, P[3], packed(3), P[4], cur, Bt, N, c.out_channels, L, &ln, nullptr, nullptr,
-                            0, nullptr, 0, stream);
+    if (pair_head) {
+      rc = srf_pw_conv_pair(enc, packed(3), P[4], cur, &ln, nullptr, packed(pu0), P[pu0 + 1], y1, slot(1), Bt, N, nB, nC, L, stream);
+      y1_ready = true;
+    } else {
+      rc = srf_pw_conv_packed(enc, P[3], packed(3), P[4], cur, Bt, N, c.out_channels, L, &ln, nullptr, nullptr,
+                              0, nullptr, 0, stream);
+    }
     if (rc) return rc;
   }
 
   // ---- separation module
-  float* y1 = fptr(p->off_y1);
   for (int i = 0; i < U; ++i) {
     const float* const* Pb = P + p->p_block0 + (size_t)i * p->p_block_stride;
     const float* const* Pu = Pb + p->p_ublock_off;
@@ -466,11 +485,12 @@ static int srf_forward_body(const srf_plan* p, const float* const* P, int num_pa
     }
     // proj_1x1 conv (+ statistics for its GlobLN)            improved_sudormrf.py:205
     const int pu_index = p->p_block0 + i * p->p_block_stride + p->p_ublock_off;
-    if (!tac_norm_fused) {
+    if (!tac_norm_fused && !y1_ready) {
       rc = srf_pw_conv_packed(xin, Pu[0], packed(pu_index), Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0),
                               0, nullptr, 0, stream);
       if (rc) return rc;
     }
+    y1_ready = false;
     // depthwise pyramid + upsample/add                         :206-216
     // unfused path: the merged tensor aliases y1 (dead once every level has been produced); fused path:
     // its own buffer (the otherwise unused level-0 buffer), because pass 2 re-reads y1 with halos
@@ -522,8 +542,17 @@ static int srf_forward_body(const srf_plan* p, const float* const* P, int num_pa
     // final_norm + PReLU folded into res_conv, + residual     :218-220
     const float* const* Pf = Pu + 5 + 4 * D;
     srf_norm fn{slot(s0 + 1 + D), Pf[0], Pf[1], Pf[2]};
-    rc = srf_pw_conv_packed(merged, Pf[3], packed(pu_index + 5 + 4 * D + 3), Pf[4], nxt, Bg, nC, nB, L, &fn, xin,
-                            nullptr, 0, nullptr, 0, stream);
+    if (pair_res && fused && i + 1 < U) {
+      // res_conv of this block + proj_1x1 of the next one (its output into y1 -- dead since this block's pyramid -- and its
+      // statistics into the next block's first slot)
+      const int pn = pu_index + p->p_block_stride;
+      rc = srf_pw_conv_pair(merged, packed(pu_index + 5 + 4 * D + 3), Pf[4], nxt, &fn, xin, packed(pn), P[pn + 1], y1,
+                            slot(1 + (i + 1) * p->slots_per_block), Bt, nC, nB, nC, L, stream);
+      y1_ready = true;
+    } else {
+      rc = srf_pw_conv_packed(merged, Pf[3], packed(pu_index + 5 + 4 * D + 3), Pf[4], nxt, Bg, nC, nB, L, &fn, xin,
+                              nullptr, 0, nullptr, 0, stream);
+    }
     if (rc) return rc;
     float* t = cur;
     cur = nxt;

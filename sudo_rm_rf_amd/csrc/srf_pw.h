@@ -26,6 +26,27 @@ struct PwArgs {
 };
 
 
+// Two 1x1 convolutions back to back in one launch (srf_pwconv_x3f.hip): y = W1 f(x) + b1 (+ residual) with Cout = 256, then
+// y2 = W2 y + b2 and the statistics of y2.  wpack1 / wpack2: the paired-block image of the two weights (srf_x3p_packed_bytes).
+struct PwPairArgs {
+  // conv 1
+  const float* x;
+  const float* residual;
+  const float* bias1;
+  float* y;
+  SrfNormDev nrm;
+  double inv_count;
+  const char* wpack1;
+  // conv 2
+  const char* wpack2;
+  const float* bias2;
+  float* y2;
+  double* out_sums2;
+  int K1, C2, L, Bt, nLt, total;
+  unsigned* tl = nullptr;   // diagnostics: per-wavefront phase clocks (srf_diag_pair_timeline); NULL = the plain kernel
+};
+
+
 // XCD-aware tile numbering: hardware places block id on XCD id%8; give each XCD a contiguous run of
 // virtual ids so the Cout/BM blocks that share one X tile hit the same L2 (bijective for any total).
 __device__ __forceinline__ int srf_xcd_remap(int id, int total) {

@@ -255,6 +255,57 @@ static int srf_pw_256_launch(const PwArgs& a, const char* wpack, int pro, hipStr
 int srf_pw_small_launch(const PwArgs& a, hipStream_t st);
 bool srf_pw_small_supported(int Cin, int Cout, int L);
 
+// Round 5: two 1x1 convolutions back to back in one launch, the intermediate handed over in registers (srf_pwconv_x3f.hip):
+// res_conv (or the bottleneck) and the proj_1x1 that consumes its output.  Both weights come as packed buffers of
+// srf_pack_pw_weights; the kernel streams their paired-block images.
+bool srf_x3f_supported(int Bt, int K1, int C2, int L);
+int srf_pw_x3f_launch(const PwPairArgs& a, int pro, hipStream_t st);
+// diagnostics (SRF_DIAGNOSTICS): this thread's next srf_pw_conv_pair launches write per-wavefront phase clocks (8 dwords per
+// wavefront, 4 wavefronts per block, 2 blocks per CU) to `buf` (device memory, >= 64 KB); NULL = off
+static thread_local unsigned* g_pair_tl = nullptr;
+extern "C" void srf_diag_pair_timeline(void* buf) { g_pair_tl = reinterpret_cast<unsigned*>(buf); }
+// Whether the fused pair serves (Bt, Cin1 -> 256 -> Cout2, L): the kernel's shape limits, the default kernel mode, and a launch
+// that fills the chip (fewer 128-column tiles than CUs: the separate launches' small-launch kernels do better).
+extern "C" int srf_pw_conv_pair_supported(int Bt, int Cin1, int Cmid, int Cout2, int L) {
+  if (srf_kernel_mode() != 0 || (srf_debug_flags() & (1 | 4 | 8))) return 0;
+  if (Cmid != 256 || !srf_x3f_supported(Bt, Cin1, Cout2, L)) return 0;
+  if (!srf_x3w_shape_supported(Cin1, Cmid, L) || !srf_x3w_shape_supported(Cmid, Cout2, L)) return 0;
+  return (long)Bt * ((L + 127) / 128) >= srf_device_cus() ? 1 : 0;
+}
+// y = W1 f(x) + bias1 (+ residual), f = in_norm (GlobLN, or GlobLN + PReLU: then the residual is required -- the two forms the
+// model has); y2 = W2 y + bias2; out_sums2 (nullable) += {sum, sumsq} of y2.  w1_packed / w2_packed: srf_pack_pw_weights.
+extern "C" int srf_pw_conv_pair(const float* x, const void* w1_packed, const float* bias1, float* y, const srf_norm* in_norm,
+                                const float* residual, const void* w2_packed, const float* bias2, float* y2, double* out_sums2,
+                                int Bt, int Cin1, int Cmid, int Cout2, int L, void* stream) {
+  SRF_CHECK_ARG(x && w1_packed && bias1 && y && in_norm && w2_packed && bias2 && y2, "srf_pw_conv_pair: null pointer");
+  SRF_CHECK_ARG(in_norm->sums && in_norm->gamma && in_norm->beta, "srf_pw_conv_pair: conv 1 needs a GlobLN prologue");
+  SRF_CHECK_ARG(srf_pw_conv_pair_supported(Bt, Cin1, Cmid, Cout2, L), "srf_pw_conv_pair: unsupported shape / mode (Bt=%d %d->%d->%d L=%d)",
+                Bt, Cin1, Cmid, Cout2, L);
+  SRF_CHECK_ARG(srf_aligned16(x) && srf_aligned16(y) && srf_aligned16(y2) && srf_aligned16(w1_packed) && srf_aligned16(w2_packed) &&
+                    (!residual || srf_aligned16(residual)),
+                "srf_pw_conv_pair: unaligned operand");
+  PwPairArgs a;
+  a.x = x;
+  a.residual = residual;
+  a.bias1 = bias1;
+  a.y = y;
+  a.nrm = srf_norm_dev(in_norm);
+  a.inv_count = 1.0 / ((double)Cin1 * (double)L);
+  a.wpack1 = reinterpret_cast<const char*>(w1_packed) + srf_x3w_packed_bytes(Cmid, Cin1);
+  a.wpack2 = reinterpret_cast<const char*>(w2_packed) + srf_x3w_packed_bytes(Cout2, Cmid);
+  a.bias2 = bias2;
+  a.y2 = y2;
+  a.out_sums2 = out_sums2;
+  a.K1 = Cin1;
+  a.C2 = Cout2;
+  a.L = L;
+  a.Bt = Bt;
+  a.nLt = 0;
+  a.total = 0;
+  a.tl = g_pair_tl;
+  return srf_pw_x3f_launch(a, a.nrm.prelu ? 2 : 1, (hipStream_t)stream);
+}
+
 // THE predicate of the 256 x 128 dispatch for a whole launch (srf_pw_conv_packed, srf_pw_conv_packed3 and srf_pw_packed_only all
 // use it -- ADVICE r3: the backward's "the fp32 weight is never read" shortcut was a hand-written copy of the dispatch test).
 static bool srf_pw_256_serves(const void* w_packed, const float* x, int Bt, int Cin, int Cout, int L, int pro) {

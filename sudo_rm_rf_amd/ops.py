@@ -143,6 +143,26 @@ def pw_conv(x, weight, bias, in_sums=None, in_gamma=None, in_beta=None, in_prelu
     return y
 
 
+def pw_conv_pair_supported(Bt, Cin1, Cmid, Cout2, L):
+    """Whether srf_pw_conv_pair serves this shape on this device under the current kernel mode / debug flags."""
+    return bool(_lib.load().srf_pw_conv_pair_supported(Bt, Cin1, Cmid, Cout2, L))
+
+
+def pw_conv_pair(x, packed1, bias1, in_sums, in_gamma, in_beta, in_prelu, residual, packed2, bias2, Cmid, Cout2, out_sums2=None):
+    """Two 1x1 convs in one launch (srf_pw_conv_pair): y = W1 f(x) + b1 (+ residual), y2 = W2 y + b2 (+ statistics of y2).
+    packed1 / packed2 = pack_pw_weight(W1 / W2).  Returns (y, y2)."""
+    dev = _chk(x, packed1, bias1, in_sums, in_gamma, in_beta, in_prelu, residual, packed2, bias2, out_sums2)
+    Bt, Cin1, L = x.shape
+    y = torch.empty((Bt, Cmid, L), dtype=torch.float32, device=dev)
+    y2 = torch.empty((Bt, Cout2, L), dtype=torch.float32, device=dev)
+    rc = _lib.load().srf_pw_conv_pair(_lib.ptr(x), _lib.ptr(packed1), _lib.ptr(bias1), _lib.ptr(y),
+                                      _norm(in_sums, in_gamma, in_beta, in_prelu), _lib.ptr(residual), _lib.ptr(packed2),
+                                      _lib.ptr(bias2), _lib.ptr(y2), _lib.ptr(out_sums2), Bt, Cin1, Cmid, Cout2, L,
+                                      _lib.current_stream(dev))
+    _lib.check(rc, "srf_pw_conv_pair")
+    return y, y2
+
+
 def dwconv5(x, weight, bias, stride, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None,
             out_sums=None):
     """depthwise k=5 conv.  x [Bt,C,Lin], weight [C,1,5] -> [Bt,C,Lout]."""

@@ -77,9 +77,18 @@ def fused_tail(B, N, SA, K, L, Bt, kernel_mode=0, packed=True, cus=256):
             Bt * ((SA * N + 255) // 256) * ((L + 127) // 128) >= cus)
 
 
-def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, packed=True, fuse_tail=True):
+def conv_pair(variant, B, C, D, N, L, Bt, kernel_mode=0, packed=True, cus=256, head=False):
+    """Mirror of srf_forward's pair_res / pair_head (srf_api.hip, srf_pw_conv_pair_supported): whether res_conv (head: the
+    bottleneck) and the proj_1x1 that follows run as one launch (srf_pwconv_x3f.hip)."""
+    k1 = N if head else C
+    return (variant == "improved" and kernel_mode == 0 and packed and B == 256 and pyramid_fused(C, L, D) and
+            _packable(k1, B) and _packable(B, C) and k1 % 64 == 0 and 128 <= k1 <= 512 and C % 128 == 0 and C <= 512 and
+            L % 4 == 0 and Bt * k1 * L * 4 < 2 ** 31 and Bt * ((L + 127) // 128) >= cus)
+
+
+def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, packed=True, fuse_tail=True, pairs=True):
     """(family, algorithmic_bytes, flops) for every kernel launch of one srf_forward, in launch order
-    (mirrors srf_api.hip).  Bytes = tensors each kernel must read + write once, fp32."""
+    (mirrors srf_api.hip).  Bytes = tensors each kernel must read + write once, fp32.  pairs = False: debug flag 1."""
     L = frames(T, K, D)
     SA = S * A
     Bg, nB, nC = Bt * G, B // G, C // G
@@ -94,9 +103,15 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, p
     def pw(cin, cout, bt, extra_in=0):
         return ("pw_conv", f * bt * L * (cin + cout + extra_in), 2.0 * bt * cin * cout * L)
 
-    out.append(pw(N, B, Bt))
+    def pair(cin1, cout2, bt, residual):      # y = W1 f(x) + b1 (+ residual) [256 rows, written: the residual stream]; y2 = W2 y + b2
+        return ("pw_pair", f * bt * L * (cin1 + (2 if residual else 1) * nB + cout2), 2.0 * bt * L * nB * (cin1 + cout2))
+
+    pair_res = pairs and conv_pair(variant, B, C, D, N, L, Bt, kernel_mode, packed)
+    pair_head = pair_res and conv_pair(variant, B, C, D, N, L, Bt, kernel_mode, packed, head=True)
+    out.append(pair(N, nC, Bt, False) if pair_head else pw(N, B, Bt))
+    y1_ready = pair_head
     preadd = False
-    for _ in range(U):
+    for blk in range(U):
         if variant == "groupcomm":
             n, h = nB, 3 * nB
             out.append(("tac", f * Bt * B * L * 2, 2.0 * Bt * L * (2 * G * n * h + h * h + n * h + G * n * h)))
@@ -106,8 +121,9 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, p
                 out.append(("pw_conv", f * Bg * L * (3 * nB + nC), 2.0 * Bg * nB * nC * L + 3.0 * Bt * B * L))
             else:
                 out.append(("gln_apply_add", f * Bt * B * L * 3, 3.0 * Bt * B * L))
-        if not (variant == "groupcomm" and preadd):
+        if not (variant == "groupcomm" and preadd) and not y1_ready:
             out.append(pw(nB, nC, Bg))
+        y1_ready = False
         dw_flops = 2.0 * 5 * Bg * nC * sum(L >> k for k in range(D))
         if kernel_mode != 1 and pyramid_fused(nC, L, D):
             if pyramid_tiled(L, D) and not pyramid_regs(L, D):
@@ -121,7 +137,11 @@ def launch_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, kernel_mode=0, p
                 lout = L >> k
                 out.append(("dwconv5", f * Bg * nC * (lin + lout), 2.0 * 5 * Bg * nC * lout))
             out.append(("merge", f * Bg * nC * (sum(L >> k for k in range(D)) + L), 2.0 * D * Bg * nC * L))
-        out.append(pw(nC, nB, Bg, extra_in=nB))
+        if pair_res and blk + 1 < U:
+            out.append(pair(nC, nC, Bt, True))
+            y1_ready = True
+        else:
+            out.append(pw(nC, nB, Bg, extra_in=nB))
     if fuse_tail and fused_tail(B, N, SA, K, L, Bt, kernel_mode, packed):
         # K5: mask GEMM + decoder contraction in one launch (srf_pwconv_x3w.hip EPI 4): the masked tensor is never stored;
         # per-256-channel partial frames [Bt, nparts, SA K, L] instead, summed by the overlap-add

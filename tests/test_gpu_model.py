@@ -105,7 +105,10 @@ def test_unfused_pyramid_agrees(manifest, name):
 
 # (case, bench batch, kernel families the single-stream forward MUST have been dispatched to)
 _X3W = {"pw_conv_x3p<0>", "pw_conv_x3p<1>", "pw_conv_x3p<2>", "pw_mask_decode"}      # (x3p: the paired-block 256 x 128 kernel)
-_BENCH_BATCH = [("cfg2_improved_u16", 32, _X3W), ("cfg3_groupcomm_u8", 32, {"pw_conv_x3p<1>", "pw_mask_decode", "pw_conv_small"}),
+# cfg 2 (B = 256): bottleneck / res_conv run fused with the proj_1x1 that follows (round 5, srf_pwconv_x3f.hip); only the last
+# block's res_conv is still a launch of its own
+_PAIRS = {"pw_pair_x3f<1>", "pw_pair_x3f<2>", "pw_conv_x3p<2>", "pw_mask_decode"}
+_BENCH_BATCH = [("cfg2_improved_u16", 32, _PAIRS), ("cfg3_groupcomm_u8", 32, {"pw_conv_x3p<1>", "pw_mask_decode", "pw_conv_small"}),
                 ("cfg4_improved_u36_n2048", 32, _X3W), ("cfg5_improved_u36_n4096", 16, _X3W)]
 
 
@@ -143,7 +146,13 @@ def test_bench_batch_examples_match_reference_golden(manifest, case, batch, fami
         assert not missing, "single-stream forward did not run %s (ran %s)" % (sorted(missing), sorted(tr.names))
         count = {n: sum(1 for k, _ in tr.launches if k == n) for n in tr.names}
         U = cfg.num_blocks
-        if cfg.variant == "improved":     # bottleneck, U x proj_1x1, U x res_conv, mask + decoder -- ALL on the 256 x 128 kernel
+        if cfg.variant == "improved" and cfg.out_channels == 256:
+            # B = 256 (cfg 2): bottleneck + proj_1x1 of block 0 and res_conv of block i + proj_1x1 of block i + 1 as fused pairs
+            # (srf_pwconv_x3f.hip); the last res_conv and the mask + decoder on the 256 x 128 kernels
+            assert (count["pw_pair_x3f<1>"], count["pw_pair_x3f<2>"], count["pw_conv_x3p<2>"], count["pw_mask_decode"]) == \
+                (1, U - 1, 1, 1), count
+            assert "pw_conv_x3p<0>" not in count and "pw_conv_x3p<1>" not in count, count
+        elif cfg.variant == "improved":   # bottleneck, U x proj_1x1, U x res_conv, mask + decoder -- ALL on the 256 x 128 kernel
             assert (count["pw_conv_x3p<1>"], count["pw_conv_x3p<0>"], count["pw_conv_x3p<2>"], count["pw_mask_decode"]) == \
                 (1, U, U, 1), count
         else:                             # GroupComm: bottleneck + mask on it, the per-group convs on the thin-shape kernel

@@ -211,6 +211,76 @@ def test_pw_conv_persistent_variants(Bt, Cin, Cout, L, pro):
     assert torch.equal(outs["packed 256x128"], outs["dispatched"])
 
 
+@pytest.mark.parametrize("Bt,Cin1,Cout2,L", [(32, 512, 512, 3200),      # cfg 2: res_conv -> proj_1x1 (800 tiles on 512 blocks: two rounds)
+                                             (12, 512, 512, 3200),      # a sub-batch of the stream split: one round, blocks with one tile
+                                             (24, 256, 384, 1604),      # ragged last tile (L % 128 = 68), three passes of conv 2, K1 = 256
+                                             (40, 128, 128, 1000)])     # shortest k loop (8 steps), one pass, ragged
+@pytest.mark.parametrize("pro", [1, 2])
+def test_pw_conv_pair_is_bitwise_the_two_launches(Bt, Cin1, Cout2, L, pro):
+    """srf_pw_conv_pair (round 5: res_conv / bottleneck + the next block's proj_1x1 in one launch, the 256-channel tensor handed
+    over in registers) against the two srf_pw_conv_packed launches it replaces -- BIT FOR BIT on both outputs -- against an fp64
+    reference, its statistics against the fp64 sums; the form with full-drain waits (flag 1 << 23) must agree bitwise too (a
+    difference = a miscounted vmcnt in the DMA pipeline)."""
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+    Cmid = 256
+    if not ops.pw_conv_pair_supported(Bt, Cin1, Cmid, Cout2, L):
+        pytest.skip("shape not served on this device")
+    x = dev32(rnd(Bt, Cin1, L, seed=50, scale=1.3, shift=0.2))
+    w1, b1 = dev32(rnd(Cmid, Cin1, 1, seed=51, scale=Cin1 ** -0.5)), dev32(rnd(Cmid, seed=52, scale=0.2))
+    w2, b2 = dev32(rnd(Cout2, Cmid, 1, seed=53, scale=Cmid ** -0.5)), dev32(rnd(Cout2, seed=54, scale=0.2))
+    res = dev32(rnd(Bt, Cmid, L, seed=55)) if pro == 2 else None
+    gamma, beta = rnd(Cin1, seed=56, scale=0.3, shift=1.0), rnd(Cin1, seed=57, scale=0.3)
+    xin = x.double().cpu()
+    kw = dict(in_sums=sums64(xin).to(DEV), in_gamma=dev32(gamma), in_beta=dev32(beta))
+    xin = gln64(xin, gamma, beta)
+    slope = None
+    if pro == 2:
+        slope = dev32(torch.tensor([0.17], dtype=torch.float64))
+        kw.update(in_prelu=slope)
+        xin = torch.where(xin >= 0, xin, 0.17 * xin)
+    want1 = F.conv1d(xin, w1.double().cpu(), b1.double().cpu())
+    if res is not None:
+        want1 = want1 + res.double().cpu()
+    p1, p2 = ops.pack_pw_weight(w1), ops.pack_pw_weight(w2)
+    assert p1 is not None and p2 is not None
+    # the two launches
+    y_ref = ops.pw_conv(x, w1, b1, residual=res, packed=p1, **kw)
+    sums_ref = ops.new_sums(Bt, DEV)
+    y2_ref = ops.pw_conv(y_ref, w2, b2, out_sums=sums_ref, packed=p2)
+    want2 = F.conv1d(y_ref.double().cpu(), w2.double().cpu(), b2.double().cpu())
+    outs = {}
+    try:
+        for name, flags in (("counted waits", 0), ("full drains", 1 << 23)):
+            ops.set_debug_flags(flags)
+            sums = ops.new_sums(Bt, DEV)
+            y, y2 = ops.pw_conv_pair(x, p1, b1, kw["in_sums"], kw["in_gamma"], kw["in_beta"], slope, res, p2, b2, Cmid, Cout2, out_sums2=sums)
+            outs[name] = (y, y2, sums)
+    finally:
+        ops.set_debug_flags(0)
+    def where(got, ref):      # a failure report that shows the pattern (which examples / row blocks / column phases)
+        bad = (got != ref) | torch.isnan(got)
+        if not bad.any():
+            return ""
+        idx = bad.nonzero().cpu()
+        return ("%d of %d values differ (max |d| %.3e, nan %d); examples %s; rows/32 %s; columns %% 128 / 32 %s; first %s" %
+                (idx.shape[0], got.numel(), (got - ref).abs().nan_to_num(0).max().item(), int(torch.isnan(got).sum()),
+                 sorted(set(idx[:, 0].tolist()))[:8], sorted(set((idx[:, 1] // 32).tolist())),
+                 sorted(set(((idx[:, 2] % 128) // 32).tolist())), idx[0].tolist()))
+    for name, (y, y2, sums) in outs.items():
+        msg = where(y, y_ref)
+        assert not msg, "pair conv 1 (%s) vs the separate launch: %s" % (name, msg)
+        msg = where(y2, y2_ref)
+        assert not msg, "pair conv 2 (%s) vs the separate launch: %s" % (name, msg)
+        check(y, want1, 1e-4, "pair conv 1 (%s)" % name)
+        check(y2, want2, 1e-4, "pair conv 2 (%s)" % name)
+        check_sums(sums, y2.double().cpu(), "pair statistics (%s)" % name)
+    # twice in a row on the same buffers: a persistent pipeline that leaves state behind would show here
+    y, y2, _ = outs["counted waits"]
+    ya, y2a = ops.pw_conv_pair(x, p1, b1, kw["in_sums"], kw["in_gamma"], kw["in_beta"], slope, res, p2, b2, Cmid, Cout2)
+    assert torch.equal(ya, y) and torch.equal(y2a, y2)
+
+
 @pytest.mark.parametrize("Bt,Cin,Cout,L", [(1, 256, 512, 3200), (1, 512, 256, 3200), (1, 256, 1024, 1600), (2, 128, 200, 708),
                                            (1, 512, 512, 1600)])
 @pytest.mark.parametrize("pro", [0, 1, 2, 3])

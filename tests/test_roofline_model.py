@@ -24,7 +24,15 @@ def test_launch_model_follows_the_dispatch():
     # fused tail at bench batch: pack, one GEMM launch, overlap-add -- no masked tensor, no frame GEMM
     assert big[-3:] == ["pack_decoder", "pw_mask_decode", "overlap_add"] and "transpose" not in big
     assert big.count("pyramid_moments") == big.count("pyramid_finalize") == big.count("pyramid_merge") == 16
-    assert big.count("pw_conv") == 1 + 2 * 16                      # bottleneck + proj / res_conv per block
+    # round 5: bottleneck + proj_1x1 of block 0, res_conv of block i + proj_1x1 of block i + 1 as ONE launch each; the last res_conv alone
+    assert big.count("pw_pair") == 16 and big.count("pw_conv") == 1
+    sep = [n for n, _, _ in roofline.launch_model(Bt=32, pairs=False, **CFG2)]
+    assert sep.count("pw_conv") == 1 + 2 * 16 and "pw_pair" not in sep      # debug flag 1: bottleneck + proj / res_conv per block
+    paired_bytes = sum(b for _, b, _ in roofline.launch_model(Bt=32, **CFG2))
+    sep_bytes = sum(b for _, b, _ in roofline.launch_model(Bt=32, pairs=False, **CFG2))
+    assert sep_bytes - paired_bytes == 16 * 4 * 32 * 3200 * 256           # proj_1x1 no longer re-reads the 256-channel tensor
+    cfg4 = dict(CFG2, B=512, U=36, D=6, N=2048)
+    assert "pw_pair" not in [n for n, _, _ in roofline.launch_model(Bt=32, **cfg4)]     # B = 512: no block holds all of conv 2's k
     small = names(Bt=1, **dict(CFG2, U=8))
     # batch 1: fewer 256 x 128 tiles than CUs -> the tail stays unfused (mask GEMM, transpose, zero bias, frame GEMM)
     assert small[-5:] == ["pw_conv", "transpose", "zero_fill", "pw_conv", "overlap_add"]
