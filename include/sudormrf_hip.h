@@ -121,6 +121,7 @@ int srf_profile_get(int i, const char** name, float* ms);
  *   32768    WITHOUT the fused tail: mask GEMM -> masked tensor -> decoder frame GEMM -> overlap-add as separate launches
  *   bits 16-21  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating; the GEMM's
  *            only in lab builds: SRF_BUILD_EXPERIMENTS=1 python -m sudo_rm_rf_amd.build -> libsudormrf_hip_lab.so)
+ *   1<<21    fused conv pair on persistent blocks (2 per CU, several tiles each) whatever the launch size -- default: one tile per block
  *   1<<23    fused conv pair with every counted wait of its DMA pipeline as a full drain (bisection aid, same results)
  *   1<<22    TAC forward / backward on the VALU kernels instead of the MFMA forms (n = 16, G = 16)
  *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
@@ -130,7 +131,7 @@ int srf_profile_get(int i, const char** name, float* ms);
 #ifdef SRF_DIAGNOSTICS
 void srf_set_debug_flags(int flags);
 /* the calling thread's next srf_pw_conv_pair launches record per-wavefront shader-clock totals {kernel, conv 1, epilogue 1, conv 2,
- * epilogues 2, tiles, -, -} (8 dwords per wavefront, 4 wavefronts per block, block-major) into buf (device, >= 64 KB); NULL = off */
+ * epilogues 2, tiles, -, -} (16 dwords per wavefront, 4 wavefronts per block, block-major) into buf (device, >= 1 MB); NULL = off */
 void srf_diag_pair_timeline(void* buf);
 #endif
 

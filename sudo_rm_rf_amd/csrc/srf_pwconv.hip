@@ -260,8 +260,8 @@ bool srf_pw_small_supported(int Cin, int Cout, int L);
 // srf_pack_pw_weights; the kernel streams their paired-block images.
 bool srf_x3f_supported(int Bt, int K1, int C2, int L);
 int srf_pw_x3f_launch(const PwPairArgs& a, int pro, hipStream_t st);
-// diagnostics (SRF_DIAGNOSTICS): this thread's next srf_pw_conv_pair launches write per-wavefront phase clocks (8 dwords per
-// wavefront, 4 wavefronts per block, 2 blocks per CU) to `buf` (device memory, >= 64 KB); NULL = off
+// diagnostics (SRF_DIAGNOSTICS): this thread's next srf_pw_conv_pair launches write per-wavefront phase clocks (16 dwords per
+// wavefront, 4 wavefronts per block, 2 blocks per CU) to `buf` (device memory, >= 1 MB); NULL = off
 static thread_local unsigned* g_pair_tl = nullptr;
 extern "C" void srf_diag_pair_timeline(void* buf) { g_pair_tl = reinterpret_cast<unsigned*>(buf); }
 // Whether the fused pair serves (Bt, Cin1 -> 256 -> Cout2, L): the kernel's shape limits, the default kernel mode, and a launch

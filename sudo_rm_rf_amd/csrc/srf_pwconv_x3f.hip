@@ -36,14 +36,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int F_BM = 256;                                  // rows of conv 1 = k of conv 2
 constexpr int F_STAGE = 16384, F_NSTAGE = 3;
-constexpr int F_STRIP_FLOATS = 16 * SRF_EPI_PITCH_H;       // 16 rows x 36 floats per wavefront
+constexpr int F_STRIP_FLOATS = 32 * SRF_EPI_PITCH_H;       // 32 rows x 36 floats per wavefront
 constexpr int F_MAX_K1 = 512, F_MAX_C2 = 512;
+constexpr int F_G = 1;             // 32-row units per epilogue group (its stores / residual loads go out as one batch)
 constexpr int F_OFF_STRIP = F_NSTAGE * F_STAGE;
 constexpr int F_OFF_GB = F_OFF_STRIP + 4 * F_STRIP_FLOATS * 4;
 constexpr int F_OFF_BIAS = F_OFF_GB + 2 * F_MAX_K1 * 4;
 constexpr int F_LDS_BYTES = F_OFF_BIAS + (F_BM + F_MAX_C2) * 4;
 static_assert(2 * F_LDS_BYTES <= 160 * 1024, "two blocks per CU");
-constexpr int F_RL = 4;                                    // residual units in flight ahead of the epilogue
 
 __device__ __forceinline__ int f_swz(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
 #define F_LDS(p) ((__attribute__((address_space(3))) void*)(p))
@@ -54,7 +54,7 @@ using f_int = std::integral_constant<int, V>;
 
 // PRO: 1 = GlobLN, 2 = GlobLN + PReLU (conv 1's operand load).  EPI: 0 = bias, 1 = bias + residual (conv 1's epilogue).
 // DBG 1: every counted wait of the DMA pipeline becomes vmcnt(0) (bisection aid: same results, slower).
-// DBG 2: per-wavefront shader-clock totals {kernel, conv 1, epilogue 1, conv 2, epilogues 2, tiles} as 8 dwords per wavefront to
+// DBG 2: per-wavefront shader-clock totals {kernel, conv 1, epilogue 1, conv 2, epilogues 2, tiles, real time, waits, barriers} as 16 dwords per wavefront to
 // a.tl (tools/pair_timeline.py; results stay correct).
 template <int PRO, int EPI, int DBG>
 __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const float* __restrict__ gamma,
@@ -130,34 +130,31 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
       r.v[it] = make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
     }
   };
-  const int st_row = (lane >> 3) * SRF_EPI_PITCH_H + (lane & 7) * 4;     // float4 side of the strip: row lane >> 3 (+ 8), 4 columns
-  const int st_col = 8 * h * SRF_EPI_PITCH_H + n;                       // operand side: rows 8 h + j of column n
-  auto convert = [&](const Regs& r, const Tile& t, int kt, bf16x8& bh, bf16x8& bl) __attribute__((always_inline)) {
+  const int st_row = (lane >> 3) * SRF_EPI_PITCH_H + (lane & 7) * 4;     // float4 side of the strip: row lane >> 3 (+ 8 ..), 4 columns
+  const int st_col = 8 * h * SRF_EPI_PITCH_H + n;                       // operand side: rows 8 h + j (+ 16) of column n
+  // raw x of one 16-k step -> this lane's eight operand values (rows 8 h + j of column n)
+  auto stage_x = [&](const Regs& r, float (&x)[8]) __attribute__((always_inline)) {
     *reinterpret_cast<float4*>(strip + st_row) = r.v[0];
     *reinterpret_cast<float4*>(strip + st_row + 8 * SRF_EPI_PITCH_H) = r.v[1];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = strip[st_col + j * SRF_EPI_PITCH_H];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int k0 = kt * 16 + 8 * h;
-    const float4 g0 = *reinterpret_cast<const float4*>(g_tab + k0), g1 = *reinterpret_cast<const float4*>(g_tab + k0 + 4);
-    const float4 e0 = *reinterpret_cast<const float4*>(b_tab + k0), e1 = *reinterpret_cast<const float4*>(b_tab + k0 + 4);
-    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float sc = gm[j] * t.rstd;
-      float x0 = fmaf(x[j], sc, be[j] - t.mean * sc);
-      if (PRO == 2) x0 = srf_prelu(x0, slope);
-      const __bf16 hh = (__bf16)x0;
-      bh[j] = hh;
-      bl[j] = (__bf16)(x0 - (float)hh);
-    }
+  };
+  // element j of k-step kt's operand: GlobLN affine (+ PReLU), split into bf16 hi | lo (the arithmetic of srf_pwconv_x3p.hip)
+  const float* g_lane = g_tab + 8 * h;
+  const float* b_lane = b_tab + 8 * h;
+  auto cvt1 = [&](float xv, int kt, int j, const Tile& t, bf16x8& bh, bf16x8& bl) __attribute__((always_inline)) {
+    const float sc = g_lane[kt * 16 + j] * t.rstd;
+    float x0 = fmaf(xv, sc, b_lane[kt * 16 + j] - t.mean * sc);
+    if (PRO == 2) x0 = srf_prelu(x0, slope);
+    const __bf16 hh = (__bf16)x0;
+    bh[j] = hh;
+    bl[j] = (__bf16)(x0 - (float)hh);
   };
 
   // ---- weight stages: step g of a tile's sequence (conv 1: g < nk1; conv 2: pass (g - nk1) >> 3, 32-k step (g - nk1) & 7).
@@ -200,10 +197,21 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
   // End of a step: this wavefront's pieces of the NEXT step's image have landed (VM = vector-memory operations it has issued
   // since: counted per call site, see the table at the tile loop), its fragment reads are done; the barrier publishes the
   // next stage and frees the current one.
+  unsigned tl_wait = 0, tl_bar = 0;      // (DBG 2: clocks spent in the counted waits / at the barriers)
   auto end_step = [&](auto vm_tag) __attribute__((always_inline)) {
-    constexpr int VM = DBG ? 0 : decltype(vm_tag)::value;
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
-    __builtin_amdgcn_s_barrier();
+    constexpr int VM = DBG == 1 ? 0 : decltype(vm_tag)::value;
+    if constexpr (DBG == 2) {
+      const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
+      const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      const unsigned t2 = (unsigned)__builtin_amdgcn_s_memtime();
+      tl_wait += t1 - t0;
+      tl_bar += t2 - t1;
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     s0 = stage_after(s0, 1);
   };
 
@@ -226,31 +234,43 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
   // per-tile epilogue addressing: one per-lane offset (row lane >> 3 of a 16-row unit, this lane's float4 column), the unit's
   // first row in the scalar offset
   int ep_vo = 0;                   // (rsub Lt + col4) 4, or out of range
-  float4 rv[F_RL][2];
-  auto res_issue = [&](__amdgpu_buffer_rsrc_t rrs, int slot, int u) __attribute__((always_inline)) {
+  float4 rv[F_G][4];               // residual of a group of F_G 32-row units (4 float4 rows per lane and unit)
+  // part 0 .. 2 F_G - 1 of group g: two of its 4 F_G loads
+  auto res_issue = [&](__amdgpu_buffer_rsrc_t rrs, int g, int part) __attribute__((always_inline)) {
     if constexpr (EPI == 1) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rrs, ep_vo, (16 * u + it * 8) * Lt * 4, 2);
-        rv[slot][it] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+      for (int i = 0; i < 2; ++i) {
+        const int uu = part >> 1, it = 2 * (part & 1) + i;
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rrs, ep_vo, (32 * (F_G * g + uu) + it * 8) * Lt * 4, 2);
+        rv[uu][it] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
       }
     }
   };
 
-  // conv 1, one 16-k step: LOADS = the activation set is reloaded with k-step kt + 4; RES >= 0: residual unit RES is requested
-  auto stepA = [&](auto loads_tag, auto res_tag, auto vm_tag, Regs& set, int kt, const Tile& t, __amdgpu_buffer_rsrc_t rrs)
-      __attribute__((always_inline)) {
-    constexpr bool LOADS = decltype(loads_tag)::value != 0;
-    constexpr int RES = decltype(res_tag)::value;
-    bf16x8 bh, bl;
-    convert(set, t, kt, bh, bl);
-    const unsigned dep = __builtin_bit_cast(u32x4, bl)[3];       // (the last value the conversion produces)
-    if constexpr (RES < 2) dma_issue(srcA(kt + 2), stage_after(s0, 2), dep);     // (RES 2 / 3: the last two steps of conv 1)
-    else dma_issue(srcB(0, RES - 2), stage_after(s0, 2), dep);
-    if constexpr (LOADS) gload_b(set, t, kt + 4);
-    if constexpr (RES >= 0) res_issue(rrs, RES, RES);
+  // conv 1, one 16-k step kt.  The step multiplies the operand converted during the PREVIOUS step (bhC | blC) and, between its
+  // MFMAs, converts the next one: STAGE = k-step kt + 1 (held raw in `set`) goes through the strip and is converted element by
+  // element behind the eight accumulator tiles' MFMAs (the matrix pipe takes an MFMA every 32 cycles: ~6 issue slots per MFMA
+  // are free for this wavefront's own VALU / LDS work -- in the first build the conversion ran in front of the burst, 1400
+  // cycles per step with the pipe idle unless the SIMD's other wavefront happened to multiply); LOADS = `set` is reloaded with
+  // k-step kt + 5; RES = part of the first residual group requested; DMAB = the stage fetched is conv 2's step DMAB (else conv
+  // 1's kt + 2).
+  bf16x8 bhC, blC;
+  auto stepA = [&](auto stage_tag, auto loads_tag, auto res_tag, auto dmab_tag, auto vm_tag, Regs& set, int kt, const Tile& t,
+                   __amdgpu_buffer_rsrc_t rrs) __attribute__((always_inline)) {
+    constexpr bool STAGE = decltype(stage_tag)::value != 0, LOADS = decltype(loads_tag)::value != 0;
+    constexpr int RES = decltype(res_tag)::value, DMAB = decltype(dmab_tag)::value;
+    float xin[8];
+    unsigned dep = 0u;
+    if constexpr (STAGE) {
+      stage_x(set, xin);
+      dep = __float_as_uint(xin[7]);
+    }
+    if constexpr (DMAB < 0) dma_issue(srcA(kt + 2), stage_after(s0, 2), dep);
+    else dma_issue(srcB(0, DMAB), stage_after(s0, 2), dep);
+    if constexpr (LOADS) gload_b(set, t, kt + 5);
+    if constexpr (RES >= 0) res_issue(rrs, 0, RES);
     const char* base = smem + s0 * F_STAGE;
-    bf16x8 ah[2], al[2];
+    bf16x8 ah[2], al[2], bhN, blN;
     ah[0] = *reinterpret_cast<const bf16x8*>(base + a_hi0);
     al[0] = *reinterpret_cast<const bf16x8*>(base + a_lo0);
 #pragma unroll
@@ -259,17 +279,22 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
         ah[(mt + 1) & 1] = *reinterpret_cast<const bf16x8*>(base + a_hi0 + (mt + 1) * 2048);
         al[(mt + 1) & 1] = *reinterpret_cast<const bf16x8*>(base + a_lo0 + (mt + 1) * 2048);
       }
-      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt & 1], bh, acc[mt], 0, 0, 0);
-      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt & 1], bl, acc[mt], 0, 0, 0);
-      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt & 1], bh, acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt & 1], bhC, acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt & 1], blC, acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt & 1], bhC, acc[mt], 0, 0, 0);
+      if constexpr (STAGE) cvt1(xin[mt], kt + 1, mt, t, bhN, blN);
     }
-    frag_schedule();
     end_step(vm_tag);
+    if constexpr (STAGE) {
+      bhC = bhN;
+      blC = blN;
+    }
   };
 
   // ---- prologue: the first two weight stages and the first four activation sets
   unsigned tl_c1 = 0, tl_e1 = 0, tl_c2 = 0, tl_e2 = 0;
   const unsigned tl_begin = DBG == 2 ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+  const unsigned tl_rbegin = DBG == 2 ? (unsigned)__builtin_amdgcn_s_memrealtime() : 0u;      // (100 MHz)
   auto tl_now = [&]() __attribute__((always_inline)) { return DBG == 2 ? (unsigned)__builtin_amdgcn_s_memtime() : 0u; };
   Regs r0, r1, r2, r3;
   dma_issue(srcA(0), 0);
@@ -283,14 +308,16 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
 
   // Counted waits (vector-memory operations a wavefront issues after the last DMA piece of step g + 1, up to the end of step g;
   // a smaller number is always safe).  A load step issues DMA x 4, then 2 loads; a no-load step DMA x 4, then 2 residual loads
-  // (EPI 1); epilogue 1: per 4-unit group 8 stores + the next group's 8 residual loads; a conv-2 step DMA x 4; epilogue 2: 16 stores (+ 2
-  // atomics after the last pass); the next tile's 8 activation loads go out before the last epilogue 2.
-  //   conv 1, load step after a load step         2 + 4 + 2        = 8    (also used for step 0 of a tile: 32 there)
-  //   conv 1, first no-load step                  2 + 4 (+ 2)      = 6 / 8
+  // (EPI 1, the last four steps); epilogue 1: per two-unit group 8 stores + the next group's 8 residual loads; a conv-2 step
+  // DMA x 4; epilogue 2: 16 stores (+ 2 atomics after the last pass); the next tile's 8 activation loads go out before the last
+  // epilogue 2, its first set's reload (2) in front of its step 0.
+  //   conv 1, load step after a load step         2 + 4 + 2        = 8    (also used for step 0 of a tile: >= 32 there)
+  //   conv 1, first no-load step                  2 + 4            = 6
+  //   conv 1, second no-load step                 0 + 4 (+ 2)      = 4 / 6
   //   conv 1, later no-load steps                 (2 +) 4 (+ 2)    = 4 / 8
   //   conv 2, first step of a pass                >= 16 stores + 4 = 20   (pass 0: 32 stores + 4)
   //   conv 2, other steps                                            4
-  constexpr int VM_A = 8, VM_A_NL0 = EPI == 1 ? 8 : 6, VM_A_NL = EPI == 1 ? 8 : 4, VM_BP = 20, VM_B = 4;
+  constexpr int VM_A = 8, VM_A_NL0 = 6, VM_A_NL1 = EPI == 1 ? 6 : 4, VM_A_NL = EPI == 1 ? 8 : 4, VM_BP = 20, VM_B = 4;
 
   int i = 0;
   do {
@@ -314,84 +341,118 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
 
     // ================= conv 1: nk1 steps of 16 k =================
     const unsigned tl_t0 = tl_now();
-    // (do-while: nk1 >= 8.  In the for form the loop exits at its header, the accumulators' header values are live out of the
-    // loop, the first MFMA of the body no longer kills its accumulator operand, hipcc picks the untied MFMA form for it and
-    // every accumulator tile exists twice -- +128 registers, ~300 spilled)
+    {   // the first step's operand (the only conversion a tile does in front of its MFMAs); its set goes back out for k-step 4
+      float x0[8];
+      stage_x(r0, x0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cvt1(x0[j], 0, j, tc, bhC, blC);
+      gload_b(r0, tc, 4);
+    }
+    // (do-while: in the for form the loop exits at its header, the accumulators' header values are live out of the loop, the
+    // first MFMA of the body no longer kills its accumulator operand, hipcc picks the untied MFMA form for it and every
+    // accumulator tile exists twice -- +128 registers, ~300 spilled)
     int kt = 0;
-    do {
-      stepA(f_int<1>{}, f_int<-1>{}, f_int<VM_A>{}, r0, kt, tc, rrs);
-      stepA(f_int<1>{}, f_int<-1>{}, f_int<VM_A>{}, r1, kt + 1, tc, rrs);
-      stepA(f_int<1>{}, f_int<-1>{}, f_int<VM_A>{}, r2, kt + 2, tc, rrs);
-      stepA(f_int<1>{}, f_int<-1>{}, f_int<VM_A>{}, r3, kt + 3, tc, rrs);
-      kt += 4;
-    } while (kt < nk1 - 4);
-    stepA(f_int<0>{}, f_int<0>{}, f_int<VM_A_NL0>{}, r0, nk1 - 4, tc, rrs);
-    stepA(f_int<0>{}, f_int<1>{}, f_int<VM_A_NL>{}, r1, nk1 - 3, tc, rrs);
-    stepA(f_int<0>{}, f_int<2>{}, f_int<VM_A_NL>{}, r2, nk1 - 2, tc, rrs);
-    stepA(f_int<0>{}, f_int<3>{}, f_int<VM_A_NL>{}, r3, nk1 - 1, tc, rrs);
+    if (nk1 > 8) {
+      do {     // step kt stages / reloads the set of k-step kt + 1: r1, r2, r3, r0
+        stepA(f_int<1>{}, f_int<1>{}, f_int<-1>{}, f_int<-1>{}, f_int<VM_A>{}, r1, kt, tc, rrs);
+        stepA(f_int<1>{}, f_int<1>{}, f_int<-1>{}, f_int<-1>{}, f_int<VM_A>{}, r2, kt + 1, tc, rrs);
+        stepA(f_int<1>{}, f_int<1>{}, f_int<-1>{}, f_int<-1>{}, f_int<VM_A>{}, r3, kt + 2, tc, rrs);
+        stepA(f_int<1>{}, f_int<1>{}, f_int<-1>{}, f_int<-1>{}, f_int<VM_A>{}, r0, kt + 3, tc, rrs);
+        kt += 4;
+      } while (kt < nk1 - 8);
+    }
+    // the last eight steps: reloads stop after three (k-step kt + 5 >= nk1), the last four request the first residual group,
+    // the last two fetch conv 2's first stages, the last one has no next operand
+    stepA(f_int<1>{}, f_int<1>{}, f_int<-1>{}, f_int<-1>{}, f_int<VM_A>{}, r1, kt, tc, rrs);
+    stepA(f_int<1>{}, f_int<1>{}, f_int<-1>{}, f_int<-1>{}, f_int<VM_A>{}, r2, kt + 1, tc, rrs);
+    stepA(f_int<1>{}, f_int<1>{}, f_int<-1>{}, f_int<-1>{}, f_int<VM_A>{}, r3, kt + 2, tc, rrs);
+    stepA(f_int<1>{}, f_int<0>{}, f_int<-1>{}, f_int<-1>{}, f_int<VM_A_NL0>{}, r0, kt + 3, tc, rrs);
+    static_assert(F_G == 1 || F_G == 2, "residual parts of the first group: the last 2 F_G steps");
+    // (counted waits: the step before a residual part issued none -> VM_A_NL1, one -> VM_A_NL; no part in this step or the last: 4)
+    stepA(f_int<1>{}, f_int<0>{}, f_int<(F_G == 2 ? 0 : -1)>{}, f_int<-1>{}, f_int<(F_G == 2 ? VM_A_NL1 : 4)>{}, r1, kt + 4, tc, rrs);
+    stepA(f_int<1>{}, f_int<0>{}, f_int<(F_G == 2 ? 1 : -1)>{}, f_int<-1>{}, f_int<(F_G == 2 ? VM_A_NL : 4)>{}, r2, kt + 5, tc, rrs);
+    stepA(f_int<1>{}, f_int<0>{}, f_int<(F_G == 2 ? 2 : 0)>{}, f_int<0>{}, f_int<(F_G == 2 ? VM_A_NL : VM_A_NL1)>{}, r3, kt + 6, tc, rrs);
+    stepA(f_int<0>{}, f_int<0>{}, f_int<(F_G == 2 ? 3 : 1)>{}, f_int<1>{}, f_int<VM_A_NL>{}, r0, kt + 7, tc, rrs);
 
     const unsigned tl_t1 = tl_now();
     // ================= epilogue 1: y = acc + bias (+ residual) -> HBM, and -> conv 2's B operand =================
-    // Unit u = rows 16 u .. 16 u + 15 (accumulator tile u >> 1, registers 8 (u & 1) ..): MFMA layout -> strip -> float4 rows
-    // (bias, residual, store; the sum goes back into the strip) -> strip columns in B-operand order (lane (n, h): rows 8 h + j).
-    // The stores (and the next group's residual loads) go out in batches of a 4-unit group -- 16 vector-memory instructions
-    // back to back instead of four per unit between LDS round trips (see dma_issue: a wavefront stalls at a vector-memory
-    // instruction for as long as its SIMD partner multiplies, with everything behind it).
+    // Unit t = accumulator tile t (rows 32 t .. 32 t + 31): MFMA layout -> strip -> float4 rows (bias, residual; the sum goes
+    // back into the strip and into a register batch) -> strip columns in B-operand order (lane (n, h): rows 16 c + 8 h + j =
+    // conv 2's k-block 2 t + c).  The stores and the next group's residual loads go out in batches of a two-unit group -- 16
+    // vector-memory instructions back to back (see dma_issue: a wavefront stalls at a vector-memory instruction for as long as
+    // its SIMD partner multiplies, with everything behind it).
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      u32x4 ob[4][2];
+    for (int g2 = 0; g2 < 8 / F_G; ++g2) {
+      u32x4 ob[F_G][4];
 #pragma unroll
-      for (int uu = 0; uu < 4; ++uu) {
-        const int u = 4 * g4 + uu, t = u >> 1, c = u & 1;
+      for (int uu = 0; uu < F_G; ++uu) {
+        const int t = F_G * g2 + uu;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) strip[((e & 3) + 8 * (e >> 2) + 4 * h) * SRF_EPI_PITCH_H + n] = acc[t][8 * c + e];
+        for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * h) * SRF_EPI_PITCH_H + n] = acc[t][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // (all reads of a phase first, ONE wait, then the arithmetic, then all writes: read - modify - write per row makes hipcc
+        // keep the may-alias order and pay an LDS round trip per row; same for the 16 operand reads below)
+        float4 o[4];
+        float bs[4];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int r16 = it * 8 + rsub;
-          float4 o = *reinterpret_cast<const float4*>(strip + r16 * SRF_EPI_PITCH_H + c4);
-          const float bs = bias1_t[16 * u + r16];
-          o.x += bs;
-          o.y += bs;
-          o.z += bs;
-          o.w += bs;
+        for (int it = 0; it < 4; ++it) {
+          o[it] = *reinterpret_cast<const float4*>(strip + (it * 8 + rsub) * SRF_EPI_PITCH_H + c4);
+          bs[it] = bias1_t[32 * t + it * 8 + rsub];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(o[it].x), "+v"(o[it].y), "+v"(o[it].z), "+v"(o[it].w), "+v"(bs[it]));
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          o[it].x += bs[it];
+          o[it].y += bs[it];
+          o[it].z += bs[it];
+          o[it].w += bs[it];
           if constexpr (EPI == 1) {
             const float4 e4 = rv[uu][it];
-            o.x += e4.x;
-            o.y += e4.y;
-            o.z += e4.z;
-            o.w += e4.w;
+            o[it].x += e4.x;
+            o[it].y += e4.y;
+            o[it].z += e4.z;
+            o[it].w += e4.w;
           }
-          ob[uu][it] = u32x4{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-          *reinterpret_cast<float4*>(strip + r16 * SRF_EPI_PITCH_H + c4) = o;
+          ob[uu][it] = u32x4{__float_as_uint(o[it].x), __float_as_uint(o[it].y), __float_as_uint(o[it].z), __float_as_uint(o[it].w)};
         }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(strip + (it * 8 + rsub) * SRF_EPI_PITCH_H + c4) = o[it];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        bf16x8 ph, pl;
+        float xr[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float x0 = strip[(8 * h + j) * SRF_EPI_PITCH_H + n];
-          const __bf16 hh = (__bf16)x0;
-          ph[j] = hh;
-          pl[j] = (__bf16)(x0 - (float)hh);
+        for (int j = 0; j < 16; ++j) xr[j] = strip[st_col + ((j >> 3) * 16 + (j & 7)) * SRF_EPI_PITCH_H];
+        asm volatile("" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]),
+                          "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]), "+v"(xr[15]));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          bf16x8 ph, pl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float x0 = xr[8 * c + j];
+            const __bf16 hh = (__bf16)x0;
+            ph[j] = hh;
+            pl[j] = (__bf16)(x0 - (float)hh);
+          }
+          x2h[2 * t + c] = ph;
+          x2l[2 * t + c] = pl;
         }
-        x2h[u] = ph;
-        x2l[u] = pl;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
 #pragma unroll
-      for (int uu = 0; uu < 4; ++uu)
+      for (int uu = 0; uu < F_G; ++uu)
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
-          __builtin_amdgcn_raw_buffer_store_b128(ob[uu][it], yrs, ep_vo, (16 * (4 * g4 + uu) + it * 8) * Lt * 4, 2);
-      if (g4 < 3) {
+        for (int it = 0; it < 4; ++it)
+          __builtin_amdgcn_raw_buffer_store_b128(ob[uu][it], yrs, ep_vo, (32 * (F_G * g2 + uu) + it * 8) * Lt * 4, 2);
+      if (g2 + 1 < 8 / F_G) {
 #pragma unroll
-        for (int uu = 0; uu < 4; ++uu) res_issue(rrs, uu, 4 * (g4 + 1) + uu);
+        for (int part = 0; part < 2 * F_G; ++part) res_issue(rrs, g2 + 1, part);
       }
     }
 
@@ -437,25 +498,32 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
     // epilogue 2 of pass p: y2 rows 128 p .. 128 p + 127 = acc2 + bias, {sum, sumsq}
     auto epiB = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
-      for (int g4 = 0; g4 < 2; ++g4) {
-        u32x4 ob[4][2];
+      for (int g2 = 0; g2 < 4 / F_G; ++g2) {
+        u32x4 ob[F_G][4];
 #pragma unroll
-        for (int uu = 0; uu < 4; ++uu) {
-          const int u = 4 * g4 + uu, t = u >> 1, c = u & 1;
+        for (int uu = 0; uu < F_G; ++uu) {
+          const int t = F_G * g2 + uu;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) strip[((e & 3) + 8 * (e >> 2) + 4 * h) * SRF_EPI_PITCH_H + n] = acc2[t][8 * c + e];
+          for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * h) * SRF_EPI_PITCH_H + n] = acc2[t][r];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          float4 o4[4];
+          float bs[4];
 #pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            const int r16 = it * 8 + rsub;
-            float4 o = *reinterpret_cast<const float4*>(strip + r16 * SRF_EPI_PITCH_H + c4);
-            const float bs = bias2_t[128 * p + 16 * u + r16];
-            o.x += bs;
-            o.y += bs;
-            o.z += bs;
-            o.w += bs;
+          for (int it = 0; it < 4; ++it) {
+            o4[it] = *reinterpret_cast<const float4*>(strip + (it * 8 + rsub) * SRF_EPI_PITCH_H + c4);
+            bs[it] = bias2_t[128 * p + 32 * t + it * 8 + rsub];
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(o4[it].x), "+v"(o4[it].y), "+v"(o4[it].z), "+v"(o4[it].w), "+v"(bs[it]));
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            float4 o = o4[it];
+            o.x += bs[it];
+            o.y += bs[it];
+            o.z += bs[it];
+            o.w += bs[it];
             ob[uu][it] = u32x4{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
             if (ok4) {
               s += (o.x + o.y) + (o.z + o.w);
@@ -467,10 +535,10 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 #pragma unroll
-        for (int uu = 0; uu < 4; ++uu)
+        for (int uu = 0; uu < F_G; ++uu)
 #pragma unroll
-          for (int it = 0; it < 2; ++it)
-            __builtin_amdgcn_raw_buffer_store_b128(ob[uu][it], y2rs, ep_vo, (128 * p + 16 * (4 * g4 + uu) + it * 8) * Lt * 4, 0);
+          for (int it = 0; it < 4; ++it)
+            __builtin_amdgcn_raw_buffer_store_b128(ob[uu][it], y2rs, ep_vo, (128 * p + 32 * (F_G * g2 + uu) + it * 8) * Lt * 4, 0);
       }
     };
     for (int p = 0; p < npass - 1; ++p) {
@@ -509,13 +577,16 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus DMA of the pipeline tail must not outlive the block's LDS
   if constexpr (DBG == 2) {
     if (a.tl && lane == 0) {
-      unsigned* o = a.tl + ((size_t)blockIdx.x * 4 + wave) * 8;
+      unsigned* o = a.tl + ((size_t)blockIdx.x * 4 + wave) * 16;
       o[0] = tl_now() - tl_begin;
       o[1] = tl_c1;
       o[2] = tl_e1;
       o[3] = tl_c2;
       o[4] = tl_e2;
       o[5] = (unsigned)ntile;
+      o[6] = (unsigned)__builtin_amdgcn_s_memrealtime() - tl_rbegin;
+      o[7] = tl_wait;
+      o[8] = tl_bar;
     }
   }
 }
@@ -553,7 +624,8 @@ int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
   // are left: with one tile per block the dispatcher hands the next tile to whichever slot frees first (cfg 2: 800 tiles on 512
   // slots = 1.56 rounds instead of the 2 full rounds of a static split).
   const long slots = 2L * srf_device_cus();
-  long nb = total <= 16 * slots ? total : slots - slots % 8;
+  long nb = total <= 16 * slots && !(srf_debug_flags() & (1 << 21)) ? total : slots - slots % 8;   // (flag 1 << 21: always persistent -- tests)
+  if (nb > total) nb = total;
   dim3 grid((unsigned)nb), block(256);
 #define F_GO(...) hipLaunchKernelGGL((srf_pw_x3f_kernel<__VA_ARGS__>), grid, block, F_LDS_BYTES, st, a, a.nrm.gamma, a.nrm.beta)
   if (pro == 1) {

@@ -1218,7 +1218,9 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
   dim3 grid((unsigned)nb), block(512);
   PwArgs ap = a;
   if (!(srf_debug_flags() & 512)) ap.epi_mask |= 1 << 12;   // quarter tiles first (flag 512: last)
+#ifdef SRF_EXPERIMENTS     // (lab builds only -- ADVICE r4: in the product build bits 22 / 23 belong to other switches)
   ap.epi_mask |= ((srf_debug_flags() >> 22) & 3) << 8;      // diagnostics: start-up stagger units (flag bits 22-23)
+#endif
   const bool res = a.residual != nullptr, mask = !res && (a.epi_mask & 1);
 #define W_GO(P, E, A, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
 #ifdef SRF_EXPERIMENTS

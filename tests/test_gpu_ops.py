@@ -220,7 +220,8 @@ def test_pw_conv_pair_is_bitwise_the_two_launches(Bt, Cin1, Cout2, L, pro):
     """srf_pw_conv_pair (round 5: res_conv / bottleneck + the next block's proj_1x1 in one launch, the 256-channel tensor handed
     over in registers) against the two srf_pw_conv_packed launches it replaces -- BIT FOR BIT on both outputs -- against an fp64
     reference, its statistics against the fp64 sums; the form with full-drain waits (flag 1 << 23) must agree bitwise too (a
-    difference = a miscounted vmcnt in the DMA pipeline)."""
+    difference = a miscounted vmcnt in the DMA pipeline), and so must the persistent-block form (flag 1 << 21: several tiles per
+    block, the operand pipeline running across tile boundaries -- what launches beyond 16 rounds of the chip get)."""
     from sudo_rm_rf_amd import ops
     ops.set_kernel_mode(0)
     Cmid = 256
@@ -251,7 +252,7 @@ def test_pw_conv_pair_is_bitwise_the_two_launches(Bt, Cin1, Cout2, L, pro):
     want2 = F.conv1d(y_ref.double().cpu(), w2.double().cpu(), b2.double().cpu())
     outs = {}
     try:
-        for name, flags in (("counted waits", 0), ("full drains", 1 << 23)):
+        for name, flags in (("counted waits", 0), ("full drains", 1 << 23), ("persistent blocks", 1 << 21)):
             ops.set_debug_flags(flags)
             sums = ops.new_sums(Bt, DEV)
             y, y2 = ops.pw_conv_pair(x, p1, b1, kw["in_sums"], kw["in_gamma"], kw["in_beta"], slope, res, p2, b2, Cmid, Cout2, out_sums2=sums)

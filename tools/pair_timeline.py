@@ -29,7 +29,7 @@ def main():
         gamma, beta = torch.rand(K1, generator=g, device=DEV) + 0.5, torch.randn(K1, generator=g, device=DEV) * 0.3
         sums = ops.gln_stats(x, Bt)
         p1, p2 = ops.pack_pw_weight(w1), ops.pack_pw_weight(w2)
-        buf = torch.zeros(512 * 4 * 8, dtype=torch.int32, device=DEV)
+        buf = torch.zeros(4096 * 4 * 16, dtype=torch.int32, device=DEV)
         run = lambda: ops.pw_conv_pair(x, p1, b1, sums, gamma, beta, slope, res, p2, b2, Cmid, C2)   # noqa: E731
         run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,15 +48,18 @@ def main():
         e1.synchronize()
         lib.srf_diag_pair_timeline(C.c_void_p(0))
         inst = e0.elapsed_time(e1) * 100
-        t = buf.cpu().view(-1, 8).to(torch.float64)
+        t = buf.cpu().view(-1, 16).to(torch.float64)
         t = t[t[:, 5] > 0]
         tot = t[:, 0].mean().item()
-        print("Bt=%d: %.1f us plain, %.1f us instrumented; %d wavefronts, ticks/us %.0f" % (Bt, plain, inst, t.shape[0], t[:, 0].max().item() / inst))
+        clk = (t[:, 0] / (t[:, 6] / 100.0)).mean().item()       # s_memtime ticks per us of s_memrealtime (100 MHz)
+        print("Bt=%d: %.1f us plain, %.1f us instrumented; %d wavefronts, %.0f ticks per us (wavefront lifetime %.1f us)" %
+              (Bt, plain, inst, t.shape[0], clk, (t[:, 6] / 100.0).mean().item()))
         for nt in sorted(set(t[:, 5].tolist())):
             s = t[t[:, 5] == nt]
             m = s.mean(0)
-            print("  %d tile(s): %4d wavefronts | kernel %7.0f ticks | per tile: conv1 %6.0f  epi1 %6.0f  conv2 %6.0f  epi2 %6.0f | other %5.1f %%" %
-                  (nt, s.shape[0], m[0], m[1] / nt, m[2] / nt, m[3] / nt, m[4] / nt, 100 * (m[0] - m[1] - m[2] - m[3] - m[4]) / m[0]))
+            print("  %d tile(s): %4d wavefronts | kernel %7.0f ticks | per tile: conv1 %6.0f  epi1 %6.0f  conv2 %6.0f  epi2 %6.0f | counted waits %6.0f  barriers %6.0f | other %5.1f %%" %
+                  (nt, s.shape[0], m[0], m[1] / nt, m[2] / nt, m[3] / nt, m[4] / nt, m[7] / nt, m[8] / nt,
+                   100 * (m[0] - m[1] - m[2] - m[3] - m[4]) / m[0]))
         del tot
 
 
