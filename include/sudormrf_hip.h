@@ -100,6 +100,10 @@ int srf_get_kernel_mode(void);
 int srf_profile_begin(void* stream);
 int srf_profile_end(void* stream, int* count);
 int srf_profile_get(int i, const char** name, float* ms);
+/* The same marks as a timeline: completion time of launch i in ms since srf_profile_begin and the index (order of first
+ * appearance) of the stream it ran on -- for forwards whose sub-batches run on several streams (synchronise the device before
+ * srf_profile_end); tools/two_stream_events.py. */
+int srf_profile_timeline(int i, const char** name, float* t_ms, int* stream_index);
 
 /* ---- SRF_DIAGNOSTICS -----------------------------------------------------------------------------------------------------
  * NOT part of the drop-in surface: process-wide switches between kernel variants for A/B measurements and bisection

@@ -42,6 +42,7 @@ _PROTOS = {
     "srf_profile_begin": (_i, [_vp]),
     "srf_profile_end": (_i, [_vp, C.POINTER(_i)]),
     "srf_profile_get": (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
+    "srf_profile_timeline": (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_i)]),
     "srf_plan_create": (_i, [C.POINTER(srf_config), _i, _i, C.POINTER(_vp)]),
     "srf_plan_destroy": (None, [_vp]),
     "srf_plan_workspace_bytes": (_sz, [_vp]),

@@ -77,6 +77,7 @@ long srf_device_cached(int slot, long (*compute)(void*), void* arg) {
 struct ProfMark {
   const char* name;
   hipEvent_t ev;
+  hipStream_t st;     // the stream the event was recorded on (timeline mode: launches of several streams in one list)
 };
 static bool g_prof = false;
 static std::vector<ProfMark> g_marks;
@@ -95,7 +96,7 @@ void srf_prof_mark(const char* name, hipStream_t st) {
     return;
   }
   (void)hipEventRecord(ev, st);
-  g_marks.push_back(ProfMark{name, ev});
+  g_marks.push_back(ProfMark{name, ev, st});
 }
 
 extern "C" int srf_profile_begin(void* stream) {
@@ -117,6 +118,33 @@ extern "C" int srf_profile_end(void* stream, int* count) {
     g_ms[i] = ms;
   }
   if (count) *count = g_marks.empty() ? 0 : (int)g_marks.size() - 1;
+  return SRF_OK;
+}
+
+// Timeline view of the same marks (the forward AS TIMED runs on two streams, rocprofv3's kernel trace
+// serialises them): mark i's completion time in ms since mark 0 ("begin") and the index of its stream in order of first
+// appearance.  The caller synchronises the device before srf_profile_end when more than one stream was used.
+extern "C" int srf_profile_timeline(int i, const char** name, float* t_ms, int* stream_index) {
+  SRF_CHECK_ARG(i >= 0 && (size_t)(i + 1) < g_marks.size() && name && t_ms && stream_index, "srf_profile_timeline: bad index %d", i);
+  float ms = 0.f;
+  SRF_CHECK_HIP(hipEventElapsedTime(&ms, g_marks[0].ev, g_marks[i + 1].ev));
+  int idx = 0;
+  std::vector<hipStream_t> seen;
+  for (size_t j = 1; j <= (size_t)(i + 1); ++j) {
+    bool known = false;
+    for (size_t k = 0; k < seen.size(); ++k)
+      if (seen[k] == g_marks[j].st) {
+        known = true;
+        if (j == (size_t)(i + 1)) idx = (int)k;
+      }
+    if (!known) {
+      if (j == (size_t)(i + 1)) idx = (int)seen.size();
+      seen.push_back(g_marks[j].st);
+    }
+  }
+  *name = g_marks[i + 1].name;
+  *t_ms = ms;
+  *stream_index = idx;
   return SRF_OK;
 }
 
