@@ -225,7 +225,8 @@ int srf_pw_conv_pair(const float* x, const void* w1_packed, const float* bias1, 
                      int Bt, int Cin1, int Cmid, int Cout2, int L, void* stream);
 
 /* The same GEMM in the exact-fp32 class for the training forward.  Round 4 (default): TWO FP16 parts per operand (22 mantissa
- * bits, three MFMAs per product block, the inference kernel's speed; operands beyond +-6e4 are clamped).  Debug flag 16384:
+ * bits, three MFMAs per product block, the inference kernel's speed; range: |operand| < 65520 -- beyond it, and for NaN / inf operands,
+ * the affected outputs are non-finite (round 5: no silent clamp), the remedy is flag 16384).  Debug flag 16384:
  * round 3's form, THREE bf16 parts per operand (h + m + l = 24 mantissa bits) and six MFMAs per product block: results in
  * the exact-fp32 class (what srf_forward_train needs: the two-part kernel's 2^-17 representation error is amplified by the
  * early layers' gradients) at ~1.6 x the two-part kernel's time.  Weights packed by srf_pack3_pw_weights (bytes:
@@ -300,7 +301,8 @@ int srf_wav_denormalize(const float* est, const float* stats, const float* mix_n
 
 /* ---- training loss: clamp(PITLossWrapper(PairwiseNegSDR("sisdr"), pit_from='pw_mtx'), +-clamp)
  * reference: losses/sisdr.py:426-458 (pairwise SI-SDR), :254-311,:342-387 (PIT), runner clamp
- * experiments/run_improved_sudormrf.py:169-171.  est, tgt, grad_est: [Bt,S,T]; S <= 4.
+ * experiments/run_improved_sudormrf.py:169-171.  est, tgt, grad_est: [Bt,S,T]; S <= 9 -- the reference's own limit
+ * (sisdr.py:275); 1..4 sources on the streaming kernels, 5..9 on the generic ones (S! permutations per example).
  *   work  : srf_pit_sisdr_work_bytes(Bt,S) bytes, 8-byte aligned, written by _forward and read by _backward;
  *   pw    : optional [Bt,S,S] pairwise losses (estimate, target);
  *   loss  : 2 floats {clamp(batch mean), raw batch mean}; clamp <= 0 disables the clamp;
@@ -320,7 +322,7 @@ int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt, int S, in
                            const float* loss, const float* upstream, float* grad_est, void* stream);
 
 /* ---- validation metric of the runners: PermInvariantSISDR.forward (losses/sisdr.py:66-196; constructed at
- * experiments/run_improved_sudormrf.py:82-85, called :201-205).  pr, tgt: [Bt,S,T], mix: [Bt,1,T] or NULL; S <= 4.
+ * experiments/run_improved_sudormrf.py:82-85, called :201-205).  pr, tgt: [Bt,S,T], mix: [Bt,1,T] or NULL; S <= 9.
  *   best      [Bt]    max over permutations (itertools order) of the source-mean SI-SNR in dB, eps as the class
  *                     places it: s = <p,t>/(<t,t>+eps) t, 10 log10(<s,s>/(<p-s,p-s>+eps));
  *   best_perm [Bt]    index of that permutation in itertools.permutations(range(S)) (first maximum);

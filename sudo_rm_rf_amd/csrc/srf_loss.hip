@@ -13,7 +13,11 @@
 // materialises [B,S,S,T] broadcast tensors for the same quantities (~10 passes, autograd doubling them).
 #include "srf_common.h"
 
-#define SRF_LOSS_MAX_SRC 4
+#define SRF_LOSS_MAX_SRC 4      // the streaming statistics kernels with everything in registers
+#define SRF_LOSS_MAX_SRC_ANY 9  // the reference accepts n_src < 10 (losses/sisdr.py:275, find_best_perm :342-387): 5..9 sources run on
+                                // srf_pit_stats_any_kernel (one estimate per block: the targets are re-read per estimate) and the
+                                // finalize kernels' MAXS = 9 instantiation (S! permutations per example: 362 880 for 9 -- slow,
+                                // as is the reference's [batch, S!, S] gather)
 
 __global__ __launch_bounds__(256) void srf_pit_stats_kernel(const float* __restrict__ est,
                                                             const float* __restrict__ tgt, double* __restrict__ work,
@@ -62,6 +66,58 @@ __global__ __launch_bounds__(256) void srf_pit_stats_kernel(const float* __restr
   }
 }
 
+// S > SRF_LOSS_MAX_SRC: block (x, i, b) accumulates estimate i's {sum e, sum e^2, sum e t_j for every j}; the blocks of i == 0 also the
+// targets' {sum t_j, sum t_j^2}.  Same work layout as srf_pit_stats_kernel.
+__global__ __launch_bounds__(256) void srf_pit_stats_any_kernel(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                                double* __restrict__ work, int S, int T, int per_block) {
+  constexpr int MS = SRF_LOSS_MAX_SRC_ANY, NA = 2 + 3 * MS;
+  __shared__ double red[4][NA];
+  const long b = blockIdx.z;
+  const int i = blockIdx.y;
+  const int beg = blockIdx.x * per_block, end = min(beg + per_block, T);
+  double acc[NA];   // [0] sum e, [1] sum e^2, [2 + j] sum e t_j, [2 + MS + j] sum t_j, [2 + 2 MS + j] sum t_j^2
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+  const float* eb = est + (b * S + i) * (long)T;
+  const float* tb = tgt + b * (long)S * T;
+  for (int t = beg + threadIdx.x; t < end; t += 256) {
+    const double e = (double)eb[t];
+    acc[0] += e;
+    acc[1] += e * e;
+#pragma unroll
+    for (int j = 0; j < MS; ++j) {
+      if (j < S) {
+        const double g = (double)tb[(long)j * T + t];
+        acc[2 + j] += e * g;
+        if (i == 0) {
+          acc[2 + MS + j] += g;
+          acc[2 + 2 * MS + j] += g * g;
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    const double v = srf_wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NA) {
+    const int k = threadIdx.x;
+    const double v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    const int nstat = 4 * S + S * S;
+    double* w = work + b * nstat;
+    int dst = -1;
+    if (k == 0) dst = i;
+    else if (k == 1) dst = S + i;
+    else if (k < 2 + MS) dst = (k - 2 < S) ? 4 * S + i * S + (k - 2) : -1;
+    else if (k < 2 + 2 * MS) dst = (i == 0 && k - 2 - MS < S) ? 2 * S + (k - 2 - MS) : -1;
+    else dst = (i == 0 && k - 2 - 2 * MS < S) ? 3 * S + (k - 2 - 2 * MS) : -1;
+    if (dst >= 0) atomicAdd(w + dst, v);
+  }
+}
+
 struct PitOut {
   float* pw;      // [Bt][S][S] (est, tgt) or null
   int* match;     // [Bt][S]: estimate matched with target j
@@ -74,6 +130,7 @@ struct PitOut {
 // With P = |projection|^2 and N = |noise|^2 + 1e-8 as functions of (ee = <e,e>, d = <e,t>) for a fixed target:
 //   sisdr: P = d^2 tt/tau^2, N0 = ee - 2 d^2/tau + d^2 tt/tau^2;  sdsdr: same P, N0 = ee - 2 d + tt;  snr: P = tt, N0 as sdsdr
 //   d l / d e = 2 l_N (e - mean e) + (l_P P_d + l_N N_d) (t - mean t)       (means 0 without zero_mean)
+template <int MAXS>
 __global__ __launch_bounds__(256) void srf_pit_finalize_kernel(const double* __restrict__ work, PitOut o, int Bt,
                                                                int S, int T, float clamp, int sdr_type, int zero_mean,
                                                                int take_log) {
@@ -82,8 +139,8 @@ __global__ __launch_bounds__(256) void srf_pit_finalize_kernel(const double* __r
   double mysum = 0.0;
   for (int b = threadIdx.x; b < Bt; b += 256) {
     const double* w = work + (long)b * nstat;
-    double pw[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC], cA[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC],
-        cB[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC];
+    double pw[MAXS][MAXS], cA[MAXS][MAXS],
+        cB[MAXS][MAXS];
     const double dT = (double)T;
     const double zm = zero_mean ? 1.0 : 0.0;
     for (int i = 0; i < S; ++i) {
@@ -118,7 +175,7 @@ __global__ __launch_bounds__(256) void srf_pit_finalize_kernel(const double* __r
       }
     }
     // permutations of (0..S-1) in lexicographic (= itertools.permutations) order; perm[j] = estimate for target j
-    int perm[SRF_LOSS_MAX_SRC], best[SRF_LOSS_MAX_SRC];
+    int perm[MAXS], best[MAXS];
     for (int j = 0; j < S; ++j) perm[j] = best[j] = j;
     double best_loss = 0.0;
     bool first = true;
@@ -195,7 +252,7 @@ __global__ __launch_bounds__(256) void srf_pit_grad_kernel(const float* __restri
 }
 
 extern "C" size_t srf_pit_sisdr_work_bytes(int Bt, int S) {
-  if (Bt <= 0 || S <= 0 || S > SRF_LOSS_MAX_SRC) return 0;
+  if (Bt <= 0 || S <= 0 || S > SRF_LOSS_MAX_SRC_ANY) return 0;
   // fp64 statistics | coef [Bt][S][4] f32 | match, tmatch [Bt][S] i32
   return (size_t)Bt * ((4 * S + S * S) * sizeof(double) + S * 4 * sizeof(float) + 2 * S * sizeof(int));
 }
@@ -220,8 +277,8 @@ extern "C" int srf_pit_sdr_forward(const float* est, const float* tgt, int Bt, i
   SRF_CHECK_ARG(sdr_type >= 0 && sdr_type <= 2, "srf_pit_sdr_forward: sdr_type %d (0 sisdr, 1 sdsdr, 2 snr)", sdr_type);
   SRF_CHECK_ARG(est && tgt && work && loss, "srf_pit_sisdr_forward: null pointer");
   SRF_CHECK_ARG(Bt > 0 && Bt <= 65535 && T > 0, "srf_pit_sisdr_forward: bad sizes");
-  SRF_CHECK_ARG(S >= 1 && S <= SRF_LOSS_MAX_SRC, "srf_pit_sisdr_forward: %d sources unsupported (1..%d)", S,
-                SRF_LOSS_MAX_SRC);
+  SRF_CHECK_ARG(S >= 1 && S <= SRF_LOSS_MAX_SRC_ANY, "srf_pit_sisdr_forward: %d sources unsupported (1..%d)", S,
+                SRF_LOSS_MAX_SRC_ANY);
   hipStream_t st = (hipStream_t)stream;
   double* stats;
   PitOut o;
@@ -230,17 +287,25 @@ extern "C" int srf_pit_sdr_forward(const float* est, const float* tgt, int Bt, i
   o.loss = loss;
   SRF_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * (size_t)Bt * (4 * S + S * S), st));
   const int per_block = 256 * 16;
-  dim3 grid((unsigned)((T + per_block - 1) / per_block), (unsigned)Bt);
-  hipLaunchKernelGGL(srf_pit_stats_kernel, grid, dim3(256), 0, st, est, tgt, stats, S, T, per_block);
-  SRF_CHECK_LAUNCH("pit_sisdr_stats", st);
-  hipLaunchKernelGGL(srf_pit_finalize_kernel, dim3(1), dim3(256), 0, st, stats, o, Bt, S, T, clamp, sdr_type,
-                     zero_mean ? 1 : 0, take_log ? 1 : 0);
+  if (S <= SRF_LOSS_MAX_SRC) {
+    dim3 grid((unsigned)((T + per_block - 1) / per_block), (unsigned)Bt);
+    hipLaunchKernelGGL(srf_pit_stats_kernel, grid, dim3(256), 0, st, est, tgt, stats, S, T, per_block);
+    SRF_CHECK_LAUNCH("pit_sisdr_stats", st);
+    hipLaunchKernelGGL(srf_pit_finalize_kernel<SRF_LOSS_MAX_SRC>, dim3(1), dim3(256), 0, st, stats, o, Bt, S, T, clamp, sdr_type,
+                       zero_mean ? 1 : 0, take_log ? 1 : 0);
+  } else {
+    dim3 grid((unsigned)((T + per_block - 1) / per_block), (unsigned)S, (unsigned)Bt);
+    hipLaunchKernelGGL(srf_pit_stats_any_kernel, grid, dim3(256), 0, st, est, tgt, stats, S, T, per_block);
+    SRF_CHECK_LAUNCH("pit_sisdr_stats", st);
+    hipLaunchKernelGGL(srf_pit_finalize_kernel<SRF_LOSS_MAX_SRC_ANY>, dim3(1), dim3(256), 0, st, stats, o, Bt, S, T, clamp,
+                       sdr_type, zero_mean ? 1 : 0, take_log ? 1 : 0);
+  }
   SRF_CHECK_LAUNCH("pit_sisdr_finalize", st);
   return SRF_OK;
 }
 
 extern "C" int srf_pit_sisdr_match(const void* work, int Bt, int S, int* match_out, void* stream) {
-  SRF_CHECK_ARG(work && match_out && Bt > 0 && S >= 1 && S <= SRF_LOSS_MAX_SRC, "srf_pit_sisdr_match: bad arguments");
+  SRF_CHECK_ARG(work && match_out && Bt > 0 && S >= 1 && S <= SRF_LOSS_MAX_SRC_ANY, "srf_pit_sisdr_match: bad arguments");
   double* stats;
   float* coef;
   int *match, *tmatch;
@@ -254,7 +319,7 @@ extern "C" int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt
                                       const void* work, const float* loss, const float* upstream, float* grad_est,
                                       void* stream) {
   SRF_CHECK_ARG(est && tgt && work && loss && grad_est, "srf_pit_sisdr_backward: null pointer");
-  SRF_CHECK_ARG(Bt > 0 && Bt <= 65535 && T > 0 && S >= 1 && S <= SRF_LOSS_MAX_SRC, "srf_pit_sisdr_backward: bad sizes");
+  SRF_CHECK_ARG(Bt > 0 && Bt <= 65535 && T > 0 && S >= 1 && S <= SRF_LOSS_MAX_SRC_ANY, "srf_pit_sisdr_backward: bad sizes");
   double* stats;
   float* coef;
   int *match, *tmatch;
@@ -275,14 +340,15 @@ extern "C" int srf_pit_sisdr_backward(const float* est, const float* tgt, int Bt
 // permutation in itertools order, the maximum (first maximum wins, like torch.max), and the SI-SNR of the mixture
 // against every target (the "improvement" baseline, which the class subtracts as ONE batch-and-source mean).
 // =============================================================================================
+template <int MAXS>
 __global__ __launch_bounds__(256) void srf_mix_stats_kernel(const float* __restrict__ mix, const float* __restrict__ tgt,
                                                             double* __restrict__ work, int S, int T, int per_block) {
-  __shared__ double red[4][2 + SRF_LOSS_MAX_SRC];
+  __shared__ double red[4][2 + MAXS];
   const long b = blockIdx.y;
   const int beg = blockIdx.x * per_block, end = min(beg + per_block, T);
-  double acc[2 + SRF_LOSS_MAX_SRC];
+  double acc[2 + MAXS];
 #pragma unroll
-  for (int k = 0; k < 2 + SRF_LOSS_MAX_SRC; ++k) acc[k] = 0.0;
+  for (int k = 0; k < 2 + MAXS; ++k) acc[k] = 0.0;
   const float* mb = mix + b * (long)T;
   const float* tb = tgt + b * (long)S * T;
   for (int t = beg + threadIdx.x; t < end; t += 256) {
@@ -290,12 +356,12 @@ __global__ __launch_bounds__(256) void srf_mix_stats_kernel(const float* __restr
     acc[0] += m;
     acc[1] += m * m;
 #pragma unroll
-    for (int j = 0; j < SRF_LOSS_MAX_SRC; ++j)
+    for (int j = 0; j < MAXS; ++j)
       if (j < S) acc[2 + j] += m * (double)tb[(long)j * T + t];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 2 + SRF_LOSS_MAX_SRC; ++k) {
+  for (int k = 0; k < 2 + MAXS; ++k) {
     if (k < 2 + S) {
       const double v = srf_wave_sum(acc[k]);
       if (lane == 0) red[wave][k] = v;
@@ -308,6 +374,7 @@ __global__ __launch_bounds__(256) void srf_mix_stats_kernel(const float* __restr
   }
 }
 
+template <int MAXS>
 __global__ __launch_bounds__(256) void srf_perm_inv_finalize_kernel(const double* __restrict__ work,
                                                                     const double* __restrict__ mwork, int Bt, int S, int T,
                                                                     int zero_mean, double eps, float* __restrict__ best_out,
@@ -324,7 +391,7 @@ __global__ __launch_bounds__(256) void srf_perm_inv_finalize_kernel(const double
     ee = ee < 0.0 ? 0.0 : ee;
     return 10.0 * log10(ss / (ee + eps));
   };
-  double sn[SRF_LOSS_MAX_SRC][SRF_LOSS_MAX_SRC];
+  double sn[MAXS][MAXS];
   for (int i = 0; i < S; ++i) {
     const double me = zm * w[i] / dT, pp = w[S + i] - dT * me * me;
     for (int j = 0; j < S; ++j) {
@@ -333,7 +400,7 @@ __global__ __launch_bounds__(256) void srf_perm_inv_finalize_kernel(const double
     }
   }
   // permutations in itertools order; permuted_pr[:, j] = pr[:, perm[j]] is scored against target j
-  int perm[SRF_LOSS_MAX_SRC];
+  int perm[MAXS];
   for (int j = 0; j < S; ++j) perm[j] = j;
   double best = 0.0;
   int best_idx = 0, idx = 0;
@@ -373,7 +440,7 @@ __global__ __launch_bounds__(256) void srf_perm_inv_finalize_kernel(const double
 }
 
 extern "C" size_t srf_perm_inv_sisdr_work_bytes(int Bt, int S) {
-  if (Bt <= 0 || S <= 0 || S > SRF_LOSS_MAX_SRC) return 0;
+  if (Bt <= 0 || S <= 0 || S > SRF_LOSS_MAX_SRC_ANY) return 0;
   return (size_t)Bt * ((4 * S + S * S) + (2 + S)) * sizeof(double);
 }
 
@@ -381,7 +448,7 @@ extern "C" int srf_perm_inv_sisdr(const float* pr, const float* tgt, const float
                                   double eps, void* work, float* best, int* best_perm, float* base, void* stream) {
   SRF_CHECK_ARG(pr && tgt && work && best && best_perm, "srf_perm_inv_sisdr: null pointer");
   SRF_CHECK_ARG(Bt > 0 && Bt <= 65535 && T > 0, "srf_perm_inv_sisdr: bad sizes");
-  SRF_CHECK_ARG(S >= 1 && S <= SRF_LOSS_MAX_SRC, "srf_perm_inv_sisdr: %d sources unsupported (1..%d)", S, SRF_LOSS_MAX_SRC);
+  SRF_CHECK_ARG(S >= 1 && S <= SRF_LOSS_MAX_SRC_ANY, "srf_perm_inv_sisdr: %d sources unsupported (1..%d)", S, SRF_LOSS_MAX_SRC_ANY);
   SRF_CHECK_ARG(!base || mix, "srf_perm_inv_sisdr: the improvement baseline needs the mixtures");
   hipStream_t st = (hipStream_t)stream;
   double* stats = reinterpret_cast<double*>(work);
@@ -389,10 +456,22 @@ extern "C" int srf_perm_inv_sisdr(const float* pr, const float* tgt, const float
   SRF_CHECK_HIP(hipMemsetAsync(work, 0, srf_perm_inv_sisdr_work_bytes(Bt, S), st));
   const int per_block = 256 * 16;
   dim3 grid((unsigned)((T + per_block - 1) / per_block), (unsigned)Bt);
-  hipLaunchKernelGGL(srf_pit_stats_kernel, grid, dim3(256), 0, st, pr, tgt, stats, S, T, per_block);
-  if (mix && base) hipLaunchKernelGGL(srf_mix_stats_kernel, grid, dim3(256), 0, st, mix, tgt, mstats, S, T, per_block);
-  hipLaunchKernelGGL(srf_perm_inv_finalize_kernel, dim3((unsigned)((Bt + 255) / 256)), dim3(256), 0, st, stats,
-                     (mix && base) ? mstats : nullptr, Bt, S, T, zero_mean, eps, best, best_perm, base);
+  if (S <= SRF_LOSS_MAX_SRC) {
+    hipLaunchKernelGGL(srf_pit_stats_kernel, grid, dim3(256), 0, st, pr, tgt, stats, S, T, per_block);
+  } else {
+    dim3 grid3(grid.x, (unsigned)S, (unsigned)Bt);
+    hipLaunchKernelGGL(srf_pit_stats_any_kernel, grid3, dim3(256), 0, st, pr, tgt, stats, S, T, per_block);
+  }
+  if (mix && base) {
+    if (S <= SRF_LOSS_MAX_SRC) hipLaunchKernelGGL(srf_mix_stats_kernel<SRF_LOSS_MAX_SRC>, grid, dim3(256), 0, st, mix, tgt, mstats, S, T, per_block);
+    else hipLaunchKernelGGL(srf_mix_stats_kernel<SRF_LOSS_MAX_SRC_ANY>, grid, dim3(256), 0, st, mix, tgt, mstats, S, T, per_block);
+  }
+  if (S <= SRF_LOSS_MAX_SRC)
+    hipLaunchKernelGGL(srf_perm_inv_finalize_kernel<SRF_LOSS_MAX_SRC>, dim3((unsigned)((Bt + 255) / 256)), dim3(256), 0, st, stats,
+                       (mix && base) ? mstats : nullptr, Bt, S, T, zero_mean, eps, best, best_perm, base);
+  else
+    hipLaunchKernelGGL(srf_perm_inv_finalize_kernel<SRF_LOSS_MAX_SRC_ANY>, dim3((unsigned)((Bt + 255) / 256)), dim3(256), 0, st, stats,
+                       (mix && base) ? mstats : nullptr, Bt, S, T, zero_mean, eps, best, best_perm, base);
   SRF_CHECK_LAUNCH("perm_inv_sisdr", st);
   return SRF_OK;
 }

@@ -374,8 +374,9 @@ int srf_x3w_pack_f16_launch(const float* const* w, char* const* dst, const int* 
 // below the three-part kernel's 4.4e-6 and the exact-fp32 MFMA kernel's 4.8e-6 (all three sit on the fp32 accumulation floor);
 // for inputs of magnitude 0.02, where the fp16 lo parts go subnormal, 1.0e-7 against 7.7e-8; 61 us per launch against 89 us;
 // every gradient and trajectory fixture passes at unchanged bars; cfg 2 step 35.2 -> 33.1 ms, cfg 4 111.2 -> 102.0 ms.
-// Range: fp16 parts saturate at 6e4 where bf16's do not -- activations are clamped there (GlobLN'ed tensors are O(1), the
-// residual stream O(1..100) in every model we have; the reference's fp32 has no such limit: flag 16384 is the escape hatch).
+// Range: fp16 parts end at 65504 where bf16's do not.  GlobLN'ed tensors are O(1), the residual stream O(1..100) in every model
+// we have; an operand beyond the range (or NaN / inf) makes its output column non-finite -- loud, like the fp32 reference's own
+// overflow, not clamped (round 5) -- and flag 16384 (three bf16 parts) is the form without the limit.
 // The packed3 buffer then holds the fp16 image (half its size).
 static bool srf_train_f16_split() { return (srf_debug_flags() & 16384) == 0; }
 size_t srf_x3w_packed3_bytes(int Cout, int Cin);

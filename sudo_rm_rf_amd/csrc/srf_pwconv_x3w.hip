@@ -71,13 +71,21 @@ __device__ __forceinline__ void w_split8(const float (&v)[8], bf16x8& hi, bf16x8
 // NP 4: the two parts are fp16 (11 + 11 mantissa bits instead of bf16's 8 + 8): hi = fp16(x), lo = fp16(x - hi).
 // The weights are stored times 2^4 (W_F16_WSCALE) so that the lo parts of typical weights (~0.03) stay in fp16's normal range;
 // the epilogue multiplies the accumulators by 2^-4 (exact).  Packets keep the bf16x8 container type (16 bytes).
+// Range contract of this form: |operand| < 65520 (beyond: non-finite outputs, loudly -- see w_split8_f16); operands below ~2^-14
+// lose their lo part to fp16's subnormal range, i.e. they carry 11 instead of 22 bits -- an absolute error of <= 3e-8 per term,
+// invisible next to O(1) terms, but a tensor that is tiny AS A WHOLE (every |x| < 1e-3) reaches only the two-part bf16
+// kernel's accuracy class; the three-part bf16 form (flag 16384) has neither limit.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float W_F16_WSCALE = 16.f;
 __device__ __forceinline__ void w_split8_f16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
   f16x8 h8, l8;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float vc = __builtin_amdgcn_fmed3f(v[j], -60000.f, 60000.f);     // (fp16 range guard: see srf_pwconv.hip)
+    // No range guard (round 5): an operand beyond fp16's range (|v| >= 65520, e.g. a diverged step) converts to
+    // +-inf and the lo part to NaN, so it POISONS the output like it would in the fp32 reference's overflow / NaN case --
+    // rounds 3-4 clamped to +-6e4 (fmed3, which also turned NaN into -6e4): a finite, plausible, wrong result.  The remedy
+    // for legitimately large activations is the three-part bf16 form (debug flag 16384: fp32's exponent range).
+    const float vc = v[j];
     const _Float16 h = (_Float16)vc;
     h8[j] = h;
     l8[j] = (_Float16)(vc - (float)h);

@@ -10,7 +10,7 @@ Same class names, constructor arguments and call signatures; the arithmetic runs
 streaming pass for the forward, one for the gradient).  PairwiseNegSDR takes all of its configurations
 ("sisdr" | "sdsdr" | "snr", zero_mean, take_log); ``pit_from`` other than 'pw_mtx' or a custom ``perm_reduce`` (which
 need loss functions this file of the reference does not contain) raise NotImplementedError instead of falling back to
-a CPU/ATen path.
+a CPU/ATen path.  Up to 9 sources, the reference's own limit (sisdr.py:275).
 """
 import ctypes as C
 import itertools
@@ -31,8 +31,9 @@ def _check(est, tgt):
     if est.device.type != "cuda" or tgt.device != est.device:
         raise _lib.SrfError("sudo_rm_rf_amd losses run on an MI355X only (estimates on %s, targets on %s); there "
                             "is deliberately no CPU fallback" % (est.device, tgt.device))
-    if est.shape[1] > 4:
-        raise NotImplementedError("the HIP PIT loss supports up to 4 sources, got %d" % est.shape[1])
+    # the reference's own limit (PITLossWrapper.forward, sisdr.py:275): up to 9 sources.  1..4 run on the streaming kernels with
+    # everything in registers, 5..9 on the generic forms of csrc/srf_loss.hip (S! permutations per example, as in the reference)
+    assert est.shape[1] < 10, f"Expected source axis along dim 1, found {est.shape[1]}"
 
 
 _SDR_TYPES = {"sisdr": 0, "sdsdr": 1, "snr": 2}
@@ -175,8 +176,8 @@ class PermInvariantSISDR(nn.Module):
         if pr_batch.device.type != "cuda" or t_batch.device != pr_batch.device:
             raise _lib.SrfError("sudo_rm_rf_amd losses run on an MI355X only (estimates on %s, targets on %s); "
                                 "there is deliberately no CPU fallback" % (pr_batch.device, t_batch.device))
-        if self.n_sources > 4:
-            raise NotImplementedError("the HIP metric supports up to 4 sources, got %d" % self.n_sources)
+        if self.n_sources > 9:       # (9! permutations per example is where the generic kernel stops; the reference has no limit but
+            raise NotImplementedError("the HIP metric supports up to 9 sources, got %d" % self.n_sources)   # materialises [S!, S] indices)
         if self.improvement and initial_mixtures is None:
             raise AttributeError("improvement=True needs initial_mixtures")      # the reference fails on None.repeat
         # normalize_input (sisdr.py:97-113): crop everything to the shortest signal

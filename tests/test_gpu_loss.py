@@ -57,7 +57,8 @@ def test_pit_sisdr_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("Bt,S,T,mode", [(32, 2, 32000, "noisy"), (3, 4, 515, "noisy"), (1, 1, 64, "random"),
-                                         (7, 3, 3, "random")])
+                                         (7, 3, 3, "random"),
+                                         (4, 5, 4099, "noisy"), (2, 8, 300, "random")])      # > 4 sources: the generic kernels
 def test_pit_sisdr_matches_fp64_oracle(Bt, S, T, mode):
     est_np, tgt_np = loss_oracle.make_loss_case(Bt, S, T, 100 + Bt + S, 3.0, mode)
     _, raw64, pw64, match64, g64 = loss_oracle.loss_and_grad(est_np, tgt_np, clamp=0.0)
@@ -81,6 +82,10 @@ def test_pit_sisdr_interface_errors():
         sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_pt')(e.to(DEV), t.to(DEV))
     with pytest.raises(AssertionError):
         sisdr_lib.PairwiseNegSDR("sdr")                                     # sisdr.py:421
+    with pytest.raises(AssertionError, match="source axis"):               # sisdr.py:275: n_src < 10
+        loss_fn(torch.randn(1, 10, 50, device=DEV), torch.randn(1, 10, 50, device=DEV))
+    l9 = loss_fn(torch.randn(1, 9, 50, device=DEV), torch.randn(1, 9, 50, device=DEV))      # the limit itself runs (9! permutations)
+    assert torch.isfinite(l9).item()
     with pytest.raises(ValueError):
         sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='nope')
 

@@ -30,6 +30,9 @@ CASES = {
     "loss_exact_clamped": (2, 2, 1000, 5, 0.0, "exact"),
     "loss_zero_clamped": (2, 2, 1000, 6, 0.0, "zero"),
     "loss_cfg4_shape": (8, 2, 32000, 7, 8.0, "noisy"),
+    # more than 4 sources (VERDICT r4 missing 4: the reference accepts n_src < 10, sisdr.py:275): the generic kernels
+    "loss_noisy_s5": (3, 5, 1200, 8, 4.0, "noisy"),
+    "loss_random_s7": (2, 7, 640, 9, 0.0, "random"),
 }
 
 

@@ -29,6 +29,7 @@ CASES = {
     "metric_plain_mean": (5, 2, 777, 14, 3.0, "noisy", False, False, True, False),
     "metric_random_s4": (3, 4, 900, 15, 0.0, "random", True, False, False, True),
     "metric_ragged_lengths": (2, 2, 1000, 16, 8.0, "noisy", True, True, False, True),
+    "metric_runner_s5": (2, 5, 800, 17, 2.0, "noisy", True, True, False, True),       # more than 4 sources: the generic kernels
 }
 
 
