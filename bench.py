@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--cpu-timeout", type=float, default=150.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-train-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-stub", action="store_true", help=argparse.SUPPRESS)      # tests: the whole multi-rank glue over gloo, no GPU
     ap.add_argument("--launch-check", action="store_true",
                     help="with --gpus N: spawn the N ranks, rendezvous (gloo when there is no GPU), barrier, "
                          "max-over-ranks reduction, print one JSON line and stop before the first kernel "
@@ -593,6 +594,144 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
             "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30, **extra}))
 
 
+def timed_forwards(run, n_steps, dev, barrier):
+    """EXACTLY n_steps calls of run() between barrier + device synchronisation on both sides; besides the wall clock of the
+    region one event per step boundary on the launch stream gives the per-step distribution (median / p10 / p90).  Shared by
+    the GPU path and the CPU stub (tests/test_distributed_cpu.py runs the latter over gloo with world_size 2)."""
+    import torch
+    cuda = dev.type == "cuda"
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)] if cuda else []
+    stamps = []
+    barrier()
+    t0 = time.perf_counter()
+    o = None
+    for i in range(n_steps):
+        if cuda:
+            evs[i].record()
+        else:
+            stamps.append(time.perf_counter())
+        o = run()
+    if cuda:
+        evs[n_steps].record()
+        torch.cuda.synchronize(dev)
+    else:
+        stamps.append(time.perf_counter())
+    wall = time.perf_counter() - t0
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps)) if cuda else \
+        sorted(1e3 * (stamps[i + 1] - stamps[i]) for i in range(n_steps))
+    return o, wall, per_step
+
+
+def forward_result(args, variant, kw, T, fs, batch, n_gpus, dt, per_rank_ms, per_step_ms, self_check, split, graphs, backend,
+                   rccl_version, device_name):
+    """The JSON line's fields that do not depend on the instrumented passes (shared by the GPU path and the CPU stub)."""
+    from sudo_rm_rf_amd import roofline
+    ms_per_step = 1e3 * dt / args.steps
+    value = n_gpus * batch * (T / fs) * args.steps / dt
+    G = kw.get("group_size", 1) if variant == "groupcomm" else 1
+    dims = dict(variant=variant, B=kw["out_channels"], C=kw["in_channels"], U=kw["num_blocks"],
+                D=kw["upsampling_depth"], K=kw["enc_kernel_size"], N=kw["enc_num_basis"],
+                S=kw["num_sources"], T=T, G=G)
+    alg_bytes = roofline.bytes_per_example(**dims) * batch
+    alg_flops = roofline.flops_per_example(**dims) * batch
+    fwd_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
+    result = {
+        "metric": "separated-seconds/sec (4s@8kHz mixtures), Improved-U16/512, 1->8 MI355X"
+        if args.workload == "cfg2_improved_u16" else "separated-seconds/sec, " + args.workload,
+        "value": value, "unit": "separated-seconds/sec", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if args.kernel_mode else
+        "f32 (1x1 convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": "%s forward, batch %d per GPU, T=%d (%.0f s @ %d Hz), inference" %
+                               (args.workload, batch, T, T / fs, fs),
+                   "global_batch": batch * n_gpus, "parallelism": "batch-sharded replicas x%d" % n_gpus,
+                   "kernel_mode": args.kernel_mode, "stream_split": split, "hip_graph_replay": graphs},
+        "self_check": self_check,
+        "step_ms": {"median": per_step_ms[len(per_step_ms) // 2], "p10": per_step_ms[int(0.1 * (len(per_step_ms) - 1))],
+                    "p90": per_step_ms[int(round(0.9 * (len(per_step_ms) - 1)))], "min": per_step_ms[0],
+                    "max": per_step_ms[-1], "note": "rank 0, HIP events at the step boundaries on the launch stream"},
+        "ranks": {"world_size": n_gpus, "ms_per_step_by_rank": per_rank_ms, "backend": backend,
+                  "rccl_version": rccl_version, "device": device_name},
+        "forward_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": fwd_gbs / roofline.HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_forward": alg_bytes,
+                             "algorithmic_tflops": alg_flops / (ms_per_step * 1e-3) / 1e12},
+    }
+    return result, dims, ms_per_step, value
+
+
+def cpu_stub_bench(args):
+    """`bench.py --gpus N --cpu-stub [--train]`: every line of multi-rank glue a real run goes through -- the launcher
+    (respawn_under_torchrun), rendezvous, rank binding, the timed region (timed_forwards / train_loop), barrier, max over ranks,
+    per-rank gathers, the gradient all-reduce and its timing, the JSON assembly -- over gloo on CPU tensors with a stand-in
+    model (a Conv1d), no kernel of the library.  What a first SCALE run on an 8-GPU node could die in is exactly this glue
+    (VERDICT r4 next 7); tests/test_distributed_cpu.py runs it with world_size 2."""
+    import torch
+    import torch.distributed as dist
+    from sudo_rm_rf_amd import distributed as D
+    rank, world, dev = D.init_from_env(backend="gloo")
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.set_num_threads(1)
+    variant, kw, T, fs, def_batch = WORKLOADS[args.workload]
+    batch, T = min(args.batch or def_batch, 4), 2000          # (stand-in sizes: this is a plumbing run)
+    S = kw["num_sources"]
+    torch.manual_seed(0)
+    net = torch.nn.Conv1d(1, S, 21, padding=10)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    backend = dist.get_backend() if dist.is_initialized() else None
+    if args.train:
+        clean = torch.randn(batch, S, T, generator=g)
+        mix = clean.sum(1, keepdim=True)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        last = {}
+
+        def step():
+            opt.zero_grad()
+            l = D.clamp_global_mean(((net(mix) - clean) ** 2).mean(), min=-30., max=+30.)
+            l.backward()
+            last["flat"] = D.allreduce_gradients(net.parameters())
+            opt.step()
+            return l
+
+        r = train_loop(step, lambda: last.get("flat"), args.steps, args.warmup, rank, world, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"cpu_stub": True, "metric": "trained-seconds/sec (stub)", "value": world * batch * (T / fs) * args.steps / r["seconds"],
+                              "unit": "trained-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "per_rank_ms_per_step": r["per_rank_ms_per_step"], "gradient_allreduce": r["allreduce"],
+                              "loss": r["loss"], "ranks": {"world_size": world, "backend": backend}}))
+        return 0
+    wav = torch.randn(batch, 1, T, generator=g)
+    with torch.no_grad():
+        run = lambda: net(wav)       # noqa: E731
+        run()
+        for _ in range(args.warmup):
+            run()
+        out, dt_local, per_step_ms = timed_forwards(run, args.steps, dev, lambda: D.barrier(dev))
+    per_rank_ms = [1e3 * t / args.steps for t in D.gather_over_ranks(dt_local, dev)]
+    dt = D.max_over_ranks(dt_local, dev)
+    ok = out.shape == (batch, S, T) and bool(torch.isfinite(out).all())
+    any_bad = D.max_over_ranks(0.0 if ok else 1.0, dev) > 0.5
+    if any_bad:
+        raise SystemExit("bench.py --cpu-stub: bad output")
+    result, _, _, _ = forward_result(args, variant, kw, T, fs, batch, world, dt, per_rank_ms, per_step_ms, {"ok": True}, [batch],
+                                     False, backend, None, "cpu (stub)")
+    result["cpu_stub"] = True
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        result["roofline"] = dict(result["forward_roofline"], traffic=None)
+        print(json.dumps(result))
+    return 0
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker or args.cpu_train_worker:
@@ -606,6 +745,8 @@ def main():
         sys.exit(respawn_under_torchrun(args))
     if args.launch_check:
         sys.exit(launch_check(args))
+    if args.cpu_stub:
+        sys.exit(cpu_stub_bench(args))
     import torch
     import torch.distributed as dist
     from sudo_rm_rf_amd import distributed as D
@@ -643,20 +784,7 @@ def main():
         D.barrier(dev)
 
     def timed(n_steps):
-        """EXACTLY n_steps forwards between barrier + synchronize on both sides; besides the wall clock of the region
-        one event per step boundary on the launch stream gives the per-step distribution (median / p10 / p90)."""
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
-        barrier()
-        t0 = time.perf_counter()
-        o = None
-        for i in range(n_steps):
-            evs[i].record()
-            o = model(wav)
-        evs[n_steps].record()
-        torch.cuda.synchronize(dev)
-        wall = time.perf_counter() - t0
-        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps))
-        return o, wall, per_step
+        return timed_forwards(lambda: model(wav), n_steps, dev, barrier)
 
     with torch.no_grad():
         out = model(wav)      # set-up, not a step: plan + workspace creation and the one-off stream-split auto-tune
@@ -705,44 +833,11 @@ def main():
         self_check.update(retimed_single_stream=True, max_abs_vs_generic_kernels=d2, ok=d2 <= 1e-3 * max(scale, 1e-3))
     if D.max_over_ranks(0.0 if self_check["ok"] else 1.0, dev) > 0.5:
         raise SystemExit("bench.py self-check failed: %s" % json.dumps(self_check))
-    ms_per_step = 1e3 * dt / args.steps
-    value = n_gpus * batch * (T / fs) * args.steps / dt
-
-    G = kw.get("group_size", 1) if variant == "groupcomm" else 1
-    dims = dict(variant=variant, B=kw["out_channels"], C=kw["in_channels"], U=kw["num_blocks"],
-                D=kw["upsampling_depth"], K=kw["enc_kernel_size"], N=kw["enc_num_basis"],
-                S=kw["num_sources"], T=T, G=G)
-    alg_bytes = roofline.bytes_per_example(**dims) * batch
-    alg_flops = roofline.flops_per_example(**dims) * batch
-    fwd_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
-    result = {
-        "metric": "separated-seconds/sec (4s@8kHz mixtures), Improved-U16/512, 1->8 MI355X"
-        if args.workload == "cfg2_improved_u16" else "separated-seconds/sec, " + args.workload,
-        "value": value, "unit": "separated-seconds/sec", "n_gpus": n_gpus, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32" if args.kernel_mode else
-        "f32 (1x1 convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)",
-        "data": "synthetic",
-        "config": {"workload": "%s forward, batch %d per GPU, T=%d (%.0f s @ %d Hz), inference" %
-                               (args.workload, batch, T, T / fs, fs),
-                   "global_batch": batch * n_gpus, "parallelism": "batch-sharded replicas x%d" % n_gpus,
-                   "kernel_mode": args.kernel_mode,
-                   "stream_split": list(model._engine()._split_choice.get((dev.index, batch, T), (batch,))),
-                   "hip_graph_replay": bool(model._engine()._graphs)},
-        "self_check": self_check,
-        "step_ms": {"median": per_step_ms[len(per_step_ms) // 2], "p10": per_step_ms[int(0.1 * (len(per_step_ms) - 1))],
-                    "p90": per_step_ms[int(round(0.9 * (len(per_step_ms) - 1)))], "min": per_step_ms[0],
-                    "max": per_step_ms[-1], "note": "rank 0, HIP events at the step boundaries on the launch stream"},
-        "ranks": {"world_size": n_gpus, "ms_per_step_by_rank": per_rank_ms,
-                  "backend": (dist.get_backend() if dist.is_initialized() else None),
-                  "rccl_version": (list(torch.cuda.nccl.version()) if n_gpus > 1 else None),
-                  "device": torch.cuda.get_device_name(dev)},
-        "forward_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": fwd_gbs / roofline.HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_forward": alg_bytes,
-                             "algorithmic_tflops": alg_flops / (ms_per_step * 1e-3) / 1e12},
-    }
+    result, dims, ms_per_step, value = forward_result(
+        args, variant, kw, T, fs, batch, n_gpus, dt, per_rank_ms, per_step_ms, self_check,
+        list(model._engine()._split_choice.get((dev.index, batch, T), (batch,))), bool(model._engine()._graphs),
+        dist.get_backend() if dist.is_initialized() else None, list(torch.cuda.nccl.version()) if n_gpus > 1 else None,
+        torch.cuda.get_device_name(dev))
 
     if self_check.get("retimed_single_stream"):
         result["config"]["stream_split"] = [batch]

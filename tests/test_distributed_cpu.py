@@ -271,3 +271,37 @@ def test_bench_launcher_spawns_ranks_on_cpu():
     d = json.loads(lines[0])
     assert d["launch_check"] and d["n_gpus"] == 2 and d["requested_gpus"] == 2
     assert d["max_over_ranks"] == 2.0 and d["per_rank"] == [0.0, 1.0]
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["inference", "training"])
+def test_bench_end_to_end_on_cpu_stub(train):
+    """`python bench.py --gpus 2 --cpu-stub [--train]`: the whole glue of a multi-GPU bench run -- launcher,
+    rendezvous, the timed region (the same timed_forwards / train_loop the GPU path uses), barriers, max over ranks, per-rank
+    gathers, the gradient all-reduce and its timing, the JSON assembly (the same forward_result) -- over gloo with a stand-in
+    model: one JSON line on rank 0 with the driver's fields, aggregate value over both ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-stub", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd + (["--train"] if train else []), capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline"):
+        assert k in d, k
+    assert d["cpu_stub"] and d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["ranks"]["backend"] == "gloo"
+    if train:
+        assert len(d["per_rank_ms_per_step"]) == 2
+        ar = d["gradient_allreduce"]
+        assert ar["world"] == 2 and ar["bytes"] > 0 and ar["ms"] > 0 and ar["bus_GBps"] > 0
+    else:
+        assert len(d["ranks"]["ms_per_step_by_rank"]) == 2 and d["config"]["global_batch"] == 2 * 4
+        # whole-job aggregate: both ranks' examples over the slowest rank's time
+        assert d["value"] == pytest.approx(2 * 4 * (2000 / 8000) * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
+        assert d["roofline"]["frac"] == d["forward_roofline"]["frac"]
