@@ -324,13 +324,13 @@ def power_pass(run, seconds=2.0):
 
 def pmc_traffic(kernel_family, workload, train=False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE are collected in their own runs of this same command -- tools/gpu_profiles_r4.sh, summarised by
-    tools/collect_profiles4.py -- and stored under profiles/; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
+    WRITE_SIZE are collected in their own runs of this same command -- tools/gpu_profiles.sh, summarised by
+    tools/collect_profiles.py -- and stored under profiles/; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     for gfx950)."""
     short = {"cfg2_improved_u16": "cfg2_bs32", "cfg4_improved_u36_n2048": "cfg4_u36_n2048_bs32",
              "cfg5_improved_u36_n4096": "cfg5_u36_n4096_8s16k_bs16"}.get(workload)
     rel = None
-    for tag in ("r04", "r03"):             # the newest committed counter pass of this workload
+    for tag in ("r05", "r04", "r03"):      # the newest committed counter pass of this workload
         cand = "profiles/%s_%s%s_pmc_hbm_traffic.csv" % (tag, short, "_train_step" if train else "")
         if short is not None and os.path.exists(os.path.join(ROOT, cand)):
             rel = cand
@@ -346,12 +346,14 @@ def pmc_traffic(kernel_family, workload, train=False):
     must = ""
     if kernel_family.startswith("pw_conv_x3w<"):
         must = ", 2>"                                        # (two-part operands: the last template argument)
-    if kernel_family.startswith(("pw_conv_x3w3<", "pw_conv_x3w4<")):   # "srf_pw_x3w_kernel<k, e, a, c, 3 | 4>": three bf16 / two fp16 parts
+    if kernel_family.startswith(("pw_conv_x3w3<", "pw_conv_x3w4<")):   # "srf_pw_x3w_kernel<k, e, c, 3 | 4>": three bf16 / two fp16 parts
         key, must = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3w3<"):-1], ", %s>" % kernel_family[11]
     if kernel_family.startswith("pw_conv_x3w<"):             # family "pw_conv_x3w<2>" = every cache-policy instantiation of "srf_pw_x3w_kernel<2, ..."
         key = "srf_pw_x3w_kernel<%s," % kernel_family[len("pw_conv_x3w<"):-1]
-    if kernel_family.startswith("pw_conv_x3p<"):             # the paired-block form: "srf_pw_x3p_kernel<k, e, 0, 0>"
+    if kernel_family.startswith("pw_conv_x3p<"):             # the paired-block form: "srf_pw_x3p_kernel<k, e(, c)>"
         key = "srf_pw_x3p_kernel<%s," % kernel_family[len("pw_conv_x3p<"):-1]
+    if kernel_family.startswith("pw_pair_x3f<"):             # the fused conv pair: "srf_pw_x3f_kernel<k, e, false>"
+        key = "srf_pw_x3f_kernel<%s," % kernel_family[len("pw_pair_x3f<"):-1]
     if kernel_family.startswith("pw_conv_bf16x3_p8<"):       # one label per prologue variant = one rocprof kernel name
         key = "srf_pw_bf16x3_p8_kernel<%s," % kernel_family[len("pw_conv_bf16x3_p8<"):-1]
     fetch, write = {}, {}
@@ -919,9 +921,11 @@ def main():
                   "unit": "GB/s", "frac": kd["algorithmic_GBps"] / roofline.HBM_PEAK_GBS, "traffic": None}
         rl.update(pmc_traffic(dom, args.workload))
         rl["avg_launch_us"] = kd["avg_launch_us"]
-        rl["measured"] = ("per-kernel durations from a single-stream pass (SRF_STREAM_SPLIT=off equivalent); the timed "
-                          "region above runs the auto-tuned two-stream split " +
-                          str(result["config"].get("stream_split")))
+        rl["measured"] = ("avg_launch_us, achieved, frac and the `kernels` table: per-kernel durations from a SINGLE-STREAM "
+                          "instrumented pass of the whole batch (SRF_STREAM_SPLIT=off equivalent); value / ms_per_step / "
+                          "forward_roofline: the timed region, which runs the auto-tuned two-stream split " +
+                          str(result["config"].get("stream_split")) + " (per-kernel durations under that co-residency: "
+                          "profiles/r05_cfg2_two_stream_timeline.txt, tools/two_stream_events.py)")
         rl["share_of_forward"] = kd["ms_per_forward"] / sum(v["ms_per_forward"] for v in kernels.values())
         result["roofline"] = rl
         result["kernels"] = kernels

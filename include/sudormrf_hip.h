@@ -110,7 +110,7 @@ int srf_profile_timeline(int i, const char** name, float* t_ms, int* stream_inde
  * (tools/, bench.py --debug-flags, a handful of tests).  They act on every thread's subsequent launches; a caller that does
  * not define SRF_DIAGNOSTICS before including this header does not see them.  Default 0 = the shipped paths.
  *   1        srf_forward WITHOUT the fused conv pairs (round 5: res_conv / bottleneck + the next proj_1x1 in one launch)
- *   2        round-2 GEMM: swap the fragment-read order; round-3 GEMM: no m-tile groups (round 2's tile order)
+ *   2        256 x 128 GEMMs: no m-tile groups (round 2's tile order); paired-block form: plain cache policy
  *   4        without the 256 x 128 GEMM (128 x 128 kernels)
  *   8        WITHOUT pre-packed weights (srf_forward packs by default)
  *   16       per-level depthwise + merge kernels instead of the fused pyramid (inference and training)
@@ -123,20 +123,16 @@ int srf_profile_timeline(int i, const char** name, float* t_ms, int* stream_inde
  *            every other caller the paired-block kernel (srf_pwconv_x3p.hip) -- default: the paired form inside the forward only
  *   16384    training forward: three bf16 parts per operand (6 MFMAs, round 3) instead of two fp16 parts (3 MFMAs, round 4)
  *   32768    WITHOUT the fused tail: mask GEMM -> masked tensor -> decoder frame GEMM -> overlap-add as separate launches
- *   bits 16-21  ablations / start-up stagger of the GEMM and pyramid kernels (results are WRONG when ablating; the GEMM's
- *            only in lab builds: SRF_BUILD_EXPERIMENTS=1 python -m sudo_rm_rf_amd.build -> libsudormrf_hip_lab.so)
  *   1<<21    fused conv pair on persistent blocks (2 per CU, several tiles each) whatever the launch size -- default: one tile per block
  *   1<<23    fused conv pair with every counted wait of its DMA pipeline as a full drain (bisection aid, same results)
  *   1<<22    TAC forward / backward on the VALU kernels instead of the MFMA forms (n = 16, G = 16)
- *   1<<24..26  TAC forward variants                                1<<27     64-bit pointer loads in the GEMMs (no buffer loads)
+ *   1<<24    TAC forward on the generic kernel (no lane-per-time-step form)      1<<26   its lane form with four tiles per block
+ *   1<<27    64-bit pointer loads in the 128 x 128 GEMM (no buffer loads)
  *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)
  *   1<<29 / 1<<30  chunked depthwise-backward / scalar GlobLN-backward kernels and no backward fusion
  *   1<<31    training forward on the exact-fp32 MFMA kernel instead of the three-part split GEMM (pass INT_MIN) */
 #ifdef SRF_DIAGNOSTICS
 void srf_set_debug_flags(int flags);
-/* the calling thread's next srf_pw_conv_pair launches record per-wavefront shader-clock totals {kernel, conv 1, epilogue 1, conv 2,
- * epilogues 2, tiles, -, -} (16 dwords per wavefront, 4 wavefronts per block, block-major) into buf (device, >= 1 MB); NULL = off */
-void srf_diag_pair_timeline(void* buf);
 #endif
 
 /* ---- whole-model path ---------------------------------------------------------------------- */

@@ -58,7 +58,6 @@ _PROTOS = {
     "srf_gln_apply_add": (_i, [_vp, _vp, _vp, C.POINTER(srf_norm), _i, _i, _i, _vp]),
     "srf_pw_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _i, _vp, _i, _vp]),
     "srf_set_debug_flags": (None, [_i]),
-    "srf_diag_pair_timeline": (None, [_vp]),
     "srf_packed_pw_weight_bytes": (_sz, [_i, _i]),
     "srf_pack_pw_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
     "srf_pw_conv_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _i, _vp, _i, _vp]),

@@ -18,15 +18,6 @@ HEADERS = [os.path.join(CSRC, "srf_common.h"), os.path.join(CSRC, "srf_pw.h"), o
            os.path.join(os.path.dirname(PKG), "include", "sudormrf_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
-# SRF_BUILD_EXPERIMENTS=1: a LAB build -- adds the GEMM experiments of csrc/experiments/ (role-split / one-SIMD-for-memory kernels,
-# selected at run time with SRF_GEMM=x3s | x3t | x3w), the ablated instantiations of the shipped GEMM (debug flag bits 16..21,
-# SRF_X3W_ABL) and its in-kernel timeline.  The default build -- what ships, what the tests and the bench load -- has none of it.
-EXPERIMENTS = os.environ.get("SRF_BUILD_EXPERIMENTS", "") not in ("", "0")
-EXPERIMENT_SOURCES = ["experiments/srf_pwconv_x3s.hip", "experiments/srf_pwconv_x3t.hip"]
-if EXPERIMENTS:
-    FLAGS = FLAGS + ["-DSRF_EXPERIMENTS=1"]
-    LIB = os.path.join(PKG, "libsudormrf_hip_lab.so")       # its own file (load it with SRF_LIB=...): never the product library
-    OBJ = os.path.join(CSRC, "build_lab")
 # Per-file flags.  The MFMA GEMM files are built without the SLP vectorizer: what it forms there are packed-fp32 VALU
 # instructions (v_pk_mul/fma/add_f32) out of the operand prologue's scalar code -- not fewer instructions (the persistent
 # res_conv kernel: 1721 VALU with, 1702 without), more expensive beside MFMAs (MI355X_MICROARCH.md, "price of one filler"),
@@ -34,8 +25,6 @@ if EXPERIMENTS:
 FILE_FLAGS = {
     "srf_pwconv_bf16x3.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_x3w.hip": ["-fno-slp-vectorize"],
-    "experiments/srf_pwconv_x3s.hip": ["-fno-slp-vectorize"],
-    "experiments/srf_pwconv_x3t.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_x3p.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_x3f.hip": ["-fno-slp-vectorize"],
     "srf_pwconv_w4.hip": ["-fno-slp-vectorize"],
@@ -123,7 +112,7 @@ def build(force=False, verbose=True, extra_flags=()):
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
-    sources = SOURCES + (EXPERIMENT_SOURCES if EXPERIMENTS else [])
+    sources = SOURCES
     with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 4)) as ex:
         res = list(ex.map(lambda s: _compile(cc, s, extra_flags), sources))
     objs = [o for o, _ in res]

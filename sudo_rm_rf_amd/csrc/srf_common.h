@@ -15,7 +15,7 @@
 void srf_set_error(const char* fmt, ...);
 int srf_kernel_mode();  // 0 = fast paths, 1 = generic kernels only, 2 = fast paths with exact-fp32 MFMA GEMMs
 int srf_kernel_mode_override(int mode);   // per-thread override (-1 = none); returns the previous override
-int srf_debug_flags();  // bit0: x3p kernel without sched_group_barrier hints
+int srf_debug_flags();  // kernel-variant switches for A/B runs and tests (table: include/sudormrf_hip.h, SRF_DIAGNOSTICS)
 bool srf_profiling();
 void srf_prof_hold(int delta);   // +1 / -1 around all but the last launch of an operation that is one profiler interval
 void srf_prof_mark(const char* name, hipStream_t st);

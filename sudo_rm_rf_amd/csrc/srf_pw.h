@@ -43,7 +43,6 @@ struct PwPairArgs {
   float* y2;
   double* out_sums2;
   int K1, C2, L, Bt, nLt, total;
-  unsigned* tl = nullptr;   // diagnostics: per-wavefront phase clocks (srf_diag_pair_timeline); NULL = the plain kernel
 };
 
 

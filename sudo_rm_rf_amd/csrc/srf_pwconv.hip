@@ -19,6 +19,8 @@
 #include "srf_common.h"
 
 #include "srf_pw.h"
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 // ---------------------------------------------------------------------------------------------
@@ -212,24 +214,13 @@ bool srf_x3w_supported(int Bt, int pro);
 bool srf_x3w_shape_supported(int Cin, int Cout, int L);
 size_t srf_x3w_packed_bytes(int Cout, int Cin);
 int srf_x3w_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
-#ifdef SRF_EXPERIMENTS
-// Round-4 GEMM experiments (csrc/experiments/, SRF_BUILD_EXPERIMENTS=1 builds only; selected with SRF_GEMM=x3s | x3t | x3p; all
-// bit-identical to the shipped kernel): wavefronts split by role / one SIMD reserved for memory work.  In such a build a packed
-// weight buffer holds TWO images: [x3w image | x3t image].
-int srf_pw_x3s_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
-bool srf_x3s_supported(int Bt, int pro);
-int srf_pw_x3t_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
-bool srf_x3t_supported(int Bt, int Cin, int pro);
-size_t srf_x3t_packed_bytes(int Cout, int Cin);
-int srf_x3t_pack_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
-#endif
 // Round 4: the paired-block form of the 256 x 128 kernel (srf_pwconv_x3p.hip: two co-resident blocks per CU; bit-identical
 // outputs).  In isolation it ties with the one-block kernel on proj_1x1 / bottleneck and loses on res_conv (127 vs 113 us) and
 // in the single-stream training step (+3.5 % / +4.5 % at cfg 2 / cfg 4); INSIDE srf_forward, whose caller runs two sub-batches
 // on two streams, its half-CU blocks let the other stream's kernels co-reside (cfg 2: 6.74 -> 6.36-6.48 ms).  So srf_forward
 // asks for it (srf_pw_prefer_paired, thread-local, scoped to the call) and every other caller -- srf_pw_conv_packed on its
 // own, the backward's data-gradient GEMMs -- keeps the one-block kernel.  Debug flag 8192 swaps the two choices (A/B, tests).
-// A packed weight buffer holds TWO images: [x3w image | x3p image] (lab builds: + the x3t image).
+// A packed weight buffer holds TWO images: [x3w image | x3p image].
 int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
 bool srf_x3p_supported(const PwArgs& a, int pro);
 size_t srf_x3p_packed_bytes(int Cout, int Cin);
@@ -240,14 +231,6 @@ void srf_pw_prefer_paired(bool on) { g_pw_prefer_paired = on ? 1 : 0; }      // 
 static bool srf_pw_paired_wanted() { return g_pw_prefer_paired != 0; }
 static int srf_pw_256_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
   const char* wpack_p = wpack + srf_x3w_packed_bytes(a.Cout, a.Cin);
-#ifdef SRF_EXPERIMENTS
-  const char* sel = getenv("SRF_GEMM");
-  if (sel && sel[0] == 'x' && sel[2] == 's' && srf_x3s_supported(a.Bt, pro)) return srf_pw_x3s_launch(a, wpack, pro, st);
-  if (sel && sel[0] == 'x' && sel[2] == 't' && srf_x3t_supported(a.Bt, a.Cin, pro) &&
-      (long)a.Bt * ((a.Cout + 255) / 256) * ((a.L + 191) / 192) >= srf_device_cus())
-    return srf_pw_x3t_launch(a, wpack_p + srf_x3p_packed_bytes(a.Cout, a.Cin), pro, st);
-  if (sel && sel[0] == 'x' && sel[2] == 'w') return srf_pw_x3w_launch(a, wpack, pro, st);
-#endif
   const bool paired = srf_pw_paired_wanted() != ((srf_debug_flags() & 8192) != 0);
   if (paired && srf_x3p_supported(a, pro)) return srf_pw_x3p_launch(a, wpack_p, pro, st);
   return srf_pw_x3w_launch(a, wpack, pro, st);
@@ -260,10 +243,6 @@ bool srf_pw_small_supported(int Cin, int Cout, int L);
 // srf_pack_pw_weights; the kernel streams their paired-block images.
 bool srf_x3f_supported(int Bt, int K1, int C2, int L);
 int srf_pw_x3f_launch(const PwPairArgs& a, int pro, hipStream_t st);
-// diagnostics (SRF_DIAGNOSTICS): this thread's next srf_pw_conv_pair launches write per-wavefront phase clocks (16 dwords per
-// wavefront, 4 wavefronts per block, 2 blocks per CU) to `buf` (device memory, >= 1 MB); NULL = off
-static thread_local unsigned* g_pair_tl = nullptr;
-extern "C" void srf_diag_pair_timeline(void* buf) { g_pair_tl = reinterpret_cast<unsigned*>(buf); }
 // Whether the fused pair serves (Bt, Cin1 -> 256 -> Cout2, L): the kernel's shape limits, the default kernel mode, and a launch
 // that fills the chip (fewer 128-column tiles than CUs: the separate launches' small-launch kernels do better).
 extern "C" int srf_pw_conv_pair_supported(int Bt, int Cin1, int Cmid, int Cout2, int L) {
@@ -302,7 +281,6 @@ extern "C" int srf_pw_conv_pair(const float* x, const void* w1_packed, const flo
   a.Bt = Bt;
   a.nLt = 0;
   a.total = 0;
-  a.tl = g_pair_tl;
   return srf_pw_x3f_launch(a, a.nrm.prelu ? 2 : 1, (hipStream_t)stream);
 }
 
@@ -379,6 +357,17 @@ int srf_x3w_pack_f16_launch(const float* const* w, char* const* dst, const int* 
 // overflow, not clamped (round 5) -- and flag 16384 (three bf16 parts) is the form without the limit.
 // The packed3 buffer then holds the fp16 image (half its size).
 static bool srf_train_f16_split() { return (srf_debug_flags() & 16384) == 0; }
+// The two image formats differ in layout and size, and which one a buffer holds is decided at PACK time: every
+// buffer srf_pack3_pw_weights has written is remembered with its format (device, address), and a launch whose flag disagrees
+// with the buffer it is handed is refused with SRF_EINVAL instead of reinterpreting the bits.  (A buffer this process never
+// packed -- e.g. a device-to-device copy of one -- is not in the table and is taken as what the caller says it is.)
+static std::mutex g_pk3_mu;
+static std::unordered_map<unsigned long long, int> g_pk3_format;     // key: device << 56 | address; value: 4 = fp16 x 2, 3 = bf16 x 3
+static unsigned long long srf_pk3_key(const void* p) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return ((unsigned long long)dev << 56) | ((unsigned long long)(size_t)p & ((1ull << 56) - 1));
+}
 size_t srf_x3w_packed3_bytes(int Cout, int Cin);
 int srf_x3w_pack3_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
 
@@ -392,8 +381,12 @@ extern "C" int srf_pack3_pw_weights(const float* const* w, void* const* packed, 
   for (int i = 0; i < n; ++i)
     SRF_CHECK_ARG(w[i] && packed[i] && srf_packed3_pw_weight_bytes(Cout[i], Cin[i]) > 0 && srf_aligned16(packed[i]),
                   "srf_pack3_pw_weights: entry %d unsupported (Cout=%d Cin=%d)", i, Cout[i], Cin[i]);
-  if (srf_train_f16_split())
-    return srf_x3w_pack_f16_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
+  const bool f16 = srf_train_f16_split();
+  {
+    std::lock_guard<std::mutex> lk(g_pk3_mu);
+    for (int i = 0; i < n; ++i) g_pk3_format[srf_pk3_key(packed[i])] = f16 ? 4 : 3;
+  }
+  if (f16) return srf_x3w_pack_f16_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
   return srf_x3w_pack3_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
 }
 // y = W f(x) + bias (+ residual), out_sums as in srf_pw_conv; w_packed3 from srf_pack3_pw_weights (NULL, a shape the
@@ -431,7 +424,15 @@ extern "C" int srf_pw_conv_packed3(const float* x, const float* w, const void* w
   a.Bt = Bt;
   a.mul_channels = 1;
   a.epi_mask = 0;
-  if (srf_train_f16_split()) return srf_pw_x3w4_launch(a, reinterpret_cast<const char*>(w_packed3), pro, (hipStream_t)stream);
+  const bool f16 = srf_train_f16_split();
+  {
+    std::lock_guard<std::mutex> lk(g_pk3_mu);
+    const auto it = g_pk3_format.find(srf_pk3_key(w_packed3));
+    SRF_CHECK_ARG(it == g_pk3_format.end() || it->second == (f16 ? 4 : 3),
+                  "srf_pw_conv_packed3: the weight image was packed as %s but debug flag 16384 now asks for %s -- pack again",
+                  it->second == 4 ? "two fp16 parts" : "three bf16 parts", f16 ? "two fp16 parts" : "three bf16 parts");
+  }
+  if (f16) return srf_pw_x3w4_launch(a, reinterpret_cast<const char*>(w_packed3), pro, (hipStream_t)stream);
   return srf_pw_x3w3_launch(a, reinterpret_cast<const char*>(w_packed3), pro, (hipStream_t)stream);
 }
 
@@ -474,23 +475,13 @@ int srf_pw_conv_preadd(const float* x, const float* q, const srf_norm* qnorm, fl
 
 extern "C" size_t srf_packed_pw_weight_bytes(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0 || !srf_x3w_shape_supported(Cin, Cout, 4)) return 0;
-#ifdef SRF_EXPERIMENTS
-  return srf_x3w_packed_bytes(Cout, Cin) + srf_x3p_packed_bytes(Cout, Cin) + srf_x3t_packed_bytes(Cout, Cin);
-#else
   return srf_x3w_packed_bytes(Cout, Cin) + srf_x3p_packed_bytes(Cout, Cin);
-#endif
 }
 static int srf_pack_both(const float* const* w, void* const* packed, const int* Cout, const int* Cin_signed, int n, hipStream_t st) {
   std::vector<char*> second(n);     // the x3p image of every entry behind its x3w image (one launch writes both)
   for (int i = 0; i < n; ++i)
     second[i] = reinterpret_cast<char*>(packed[i]) + srf_x3w_packed_bytes(Cout[i], Cin_signed[i] < 0 ? -Cin_signed[i] : Cin_signed[i]);
   int rc = srf_x3w_pack2_launch(w, reinterpret_cast<char* const*>(packed), second.data(), Cout, Cin_signed, n, st);
-#ifdef SRF_EXPERIMENTS
-  if (rc) return rc;
-  for (int i = 0; i < n; ++i)       // (experiment builds: the x3t image behind that)
-    second[i] += srf_x3p_packed_bytes(Cout[i], Cin_signed[i] < 0 ? -Cin_signed[i] : Cin_signed[i]);
-  rc = srf_x3t_pack_launch(w, second.data(), Cout, Cin_signed, n, st);
-#endif
   return rc;
 }
 

@@ -15,9 +15,12 @@
 // 256-B row segments per wavefront), applies the GlobLN/PReLU prologue, splits, and writes the 8-k packets as
 // 16-B ds_write_b128 into [time][k] LDS images (row pitch 80 B: conflict-free ds_read_b128 fragment fetches).
 // W is [m][k] row-major already.  LDS: 4 images x 2 stages = 80 KB -> 2 blocks = 16 wavefronts per CU; global
-// loads run two k-tiles ahead of their use.  Two kernels: one tile per block (srf_pw_bf16x3_w8_kernel, also the
-// carrier of the ablation / timeline diagnostics) and the persistent one (srf_pw_bf16x3_p8_kernel, default for
-// >= 3 tiles per block slot).
+// loads run two k-tiles ahead of their use.  Two kernels: one tile per block (srf_pw_bf16x3_w8_kernel) and the persistent
+// one (srf_pw_bf16x3_p8_kernel, default for >= 3 tiles per block slot).
+// WHAT THIS FILE SERVES since the 256 x 128 kernels (srf_pwconv_x3w.hip / _x3p.hip / _x3f.hip) took the large launches: 1x1
+// convs with Cin % 64 == 0 whose launch has FEWER 256 x 128 tiles than the chip has CUs (batches of 2-8 at cfg 2: the 128 x 128
+// tiles here make twice as many blocks), Cout < 192, callers that pass no packed weight image, the decoder's frame GEMM
+// (800 tiles) and the backward's small data-gradient GEMMs.  Batch 1 goes to the 64 x 64 tiles of srf_pwconv_w4.hip.
 #include "srf_pw.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -55,23 +58,15 @@ __device__ __forceinline__ void srf_split8(const float (&v)[8], bf16x8& hi, bf16
 // ---------------------------------------------------------------------------------------------
 // One tile per block.
 // ---------------------------------------------------------------------------------------------
-// ABL (ablation, diagnostics only; results are wrong when != 0): 1 = no A loads, 2 = no B loads,
-// 4 = no MFMAs, 8 = no conversion / LDS stores
 // (An instruction-interleave variant -- unconditional store + sched_group_barrier(MFMA 1 / VALU 7) -- was
 // measured: 131 us vs 151 us on proj_1x1 but slower on the prologue variants and miscompiled for PRO 0;
 // dropped.)
 // BUF: operand loads as buffer loads (see the persistent kernel); false = 64-bit pointer form for tensors whose
 // byte offsets do not fit 32 bits.
-template <int PRO, int ABL = 0, bool BUF = true>
+template <int PRO, bool BUF = true>
 __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int nMt, int nLt, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];   // exactly 80 KB
 
-  // first-round blocks only: de-phase the chip (see the persistent kernel below); epi_mask bits 8..
-  if ((a.epi_mask >> 8) && blockIdx.x < 512) {
-    const int units = (a.epi_mask >> 8) & 15, four = (a.epi_mask >> 12) & 1;
-    const int phase = four ? ((blockIdx.x >> 3) & 3) : 2 * ((blockIdx.x >> 3) & 1);
-    for (int i = 0; i < units * phase; ++i) __builtin_amdgcn_s_sleep(64);   // ~4K cycles each
-  }
   const int v = srf_xcd_remap(blockIdx.x, total);
   const int mt = v % nMt;
   const int lt = (v / nMt) % nLt;
@@ -81,22 +76,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves, 32 x 64 each
 
-  // ABL & 16: in-kernel timeline (diagnostics).  Lane i of every wavefront keeps the i-th s_memtime
-  // stamp; the 64 stamps go to the buffer passed in a.mul.  Per k-tile: after the barrier, after the
-  // prefetched operands have landed, after split + LDS stores, after LDS reads + MFMA issue.
-  unsigned tsv = 0;
-  int tsi = 0;
-  const unsigned rt0 = (ABL & 16) ? (unsigned)__builtin_amdgcn_s_memrealtime() : 0u;   // constant 100 MHz
-  auto stamp = [&]() {
-    if (ABL & 16) {
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
-      tsv = (lane == tsi) ? t : tsv;
-      ++tsi;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  stamp();
 
   float mean = 0.f, rstd = 1.f, slope = 1.f;
   if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
@@ -132,13 +111,8 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
     float b[8];
   };
   Regs r0, r1;
-  if (ABL & 3) {   // ablation: registers that are never loaded still need defined contents
-    r0.a[0] = r0.a[1] = r1.a[0] = r1.a[1] = make_float4(1.f, 2.f, 3.f, 4.f);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r0.b[j] = r1.b[j] = 0.5f * j;
-  }
   auto gload = [&](Regs& r, int k0) {
-    if (!(ABL & 1)) {
+    {
       if (BUF) {
         const auto w0 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo, k0 * 4, 0);
         const auto w1 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo, k0 * 4 + 16, 0);
@@ -149,7 +123,7 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
         r.a[1] = *reinterpret_cast<const float4*>(a_src + k0 + 4);
       }
     }
-    if (!(ABL & 2)) {
+    {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         r.b[j] = BUF ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, b_vo, (k0 + j) * L * 4, 0))
@@ -176,10 +150,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
     }
     bf16x8 hib, lob;
     srf_split8(vb, hib, lob);
-    if (ABL & 16) {
-      asm volatile("" ::"v"(hi), "v"(lo), "v"(hib), "v"(lob));
-      stamp();
-    }
     *reinterpret_cast<bf16x8*>(base + 0 * X3_IMG + a_lds) = hi;
     *reinterpret_cast<bf16x8*>(base + 1 * X3_IMG + a_lds) = lo;
     *reinterpret_cast<bf16x8*>(base + 2 * X3_IMG + b_lds) = hib;
@@ -201,10 +171,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
       const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * X3_IMG + b_row1 + ko);
       const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row0 + ko);
       const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * X3_IMG + b_row1 + ko);
-      if ((ABL & 16) && ks == 0) {
-        asm volatile("" ::"v"(ah), "v"(al), "v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
-        stamp();
-      }
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
@@ -214,18 +180,9 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
     }
   };
   auto step = [&](Regs& nx, int kt) {
-    stamp();
-    if (ABL & 16) {
-      asm volatile("" ::"v"(nx.a[0].x), "v"(nx.a[0].w), "v"(nx.a[1].x), "v"(nx.a[1].w), "v"(nx.b[0]), "v"(nx.b[1]),
-                   "v"(nx.b[2]), "v"(nx.b[3]), "v"(nx.b[4]), "v"(nx.b[5]), "v"(nx.b[6]), "v"(nx.b[7]));
-      stamp();
-    }
-    if (!(ABL & 8) && kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
-    stamp();
+    if (kt + 1 < nk_) lds_store(nx, (kt + 1) & 1, (kt + 1) * X3_BK);
     gload(nx, min(kt + 3, nk_ - 1) * X3_BK);
-    stamp();
-    if (!(ABL & 4)) mma_tile(kt & 1);
-    stamp();
+    mma_tile(kt & 1);
     __syncthreads();
   };
 
@@ -234,32 +191,18 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_w8_kernel(PwArgs a, int 
   lds_store(r0, 0, 0);
   gload(r0, min(2, nk_ - 1) * X3_BK);
   __syncthreads();
-  stamp();
   for (int kt = 0; kt < nk_; kt += 2) {
     step(r1, kt);
     step(r0, kt + 1);
   }
-  stamp();
-  if (ABL) {   // keep everything the ablated pipeline produced alive
-    asm volatile("" ::"v"(r0.a[0].x), "v"(r1.a[0].x), "v"(r0.b[0]), "v"(r1.b[0]), "v"(r0.a[1].w), "v"(r1.b[7]));
-  }
 
   float s = 0.f, q = 0.f;
   float* strip = reinterpret_cast<float*>(smem) + wave * (32 * SRF_EPI_PITCH);
-  srf_pw_epilogue_strip(a, acc0, acc1, strip, b, m0 + wm * 32, (ABL & 32) ? a.L : l0 + wn * 64, lane, s, q);
+  srf_pw_epilogue_strip(a, acc0, acc1, strip, b, m0 + wm * 32, l0 + wn * 64, lane, s, q);
   __syncthreads();
   if (a.out_sums)
     srf_block_stats_atomic<8>((double)s, (double)q, srf_stat_slot(a.out_sums, b, v),
                               reinterpret_cast<double*>(smem));
-  if (ABL & 16) {
-    stamp();
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
-    const unsigned rt1 = (unsigned)__builtin_amdgcn_s_memrealtime();
-    tsv = lane == 62 ? hw : (lane == 63 ? xcc : tsv);
-    tsv = lane == 60 ? rt0 : (lane == 61 ? rt1 : tsv);
-    reinterpret_cast<unsigned*>(const_cast<float*>(a.mul))[((size_t)blockIdx.x * 8 + wave) * 64 + lane] = tsv;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,12 +242,11 @@ __global__ __launch_bounds__(512, 4) void srf_pw_bf16x3_p8_kernel(PwArgs a, int 
                           : (total - (int)blockIdx.x + nblk - 1) / nblk;   // >= 1 (host: grid <= total)
   const int nsteps = ntile * nk_;
   const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
-  // experiment (epi_mask bits 8..): delay every other block once, by roughly half a tile, so that the
-  // chip's epilogue write bursts stop coinciding
+  // one-off start-up stagger: blocks start in four phases ~4K cycles apart, so that the chip's epilogue write bursts stop
+  // coinciding (measured in round 2 against none / two phases / longer units)
   {
-    const int units = (a.epi_mask >> 8) & 15, four = (a.epi_mask >> 12) & 1;
-    const int phase = four ? ((blockIdx.x >> 3) & 3) : 2 * ((blockIdx.x >> 3) & 1);
-    for (int i = 0; i < units * phase; ++i) __builtin_amdgcn_s_sleep(64);   // ~4K cycles each
+    const int phase = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(64);
   }
 
   // tile i of this block -> virtual tile id (XCD-contiguous runs, see srf_xcd_remap; nblk % 8 == 0 keeps
@@ -550,19 +492,14 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
   SRF_CHECK_ARG(total < (1L << 31), "srf_pw_conv: too many tiles");
   {
     dim3 grid8((unsigned)total), block8(512);
-    const int abl = (srf_debug_flags() >> 16) & 15;   // diagnostics: ablated pipelines (PRO 0 only)
     // Persistent blocks (2 per CU) whenever every block gets >= 3 tiles; fewer tiles and the idle slots
     // of the last round cost more than the pipelining across tiles gains (decoder frame GEMM: 800 tiles).
     // Debug flag 2048 forces the one-tile-per-block kernel.
     long nb = 2L * srf_device_cus();
     nb -= nb % 8;
-    if (!abl && !(srf_debug_flags() & 2048) && nb >= 8 && total >= 3 * nb) {
+    if (!(srf_debug_flags() & 2048) && nb >= 8 && total >= 3 * nb) {
       dim3 gridp((unsigned)nb);
       PwArgs ap = a;
-      // start-up stagger: 4 phases x ~4K cycles (flags bits 20..23 override the unit count, 15 = none;
-      // bit 12 selects 2 phases)
-      const int su = (srf_debug_flags() >> 20) & 15;
-      ap.epi_mask |= ((su == 15 ? 0 : (su ? su : 1)) << 8) | ((((srf_debug_flags() >> 12) & 1) ^ 1) << 12);
       // leftover tiles of the last round as half tiles when they fill at most half of it (debug flag 256: off)
       const long rem = total % nb;
       const int nhalf = (rem > 0 && 2 * rem <= nb && !(srf_debug_flags() & 256)) ? (int)(2 * rem) : 0;
@@ -590,34 +527,13 @@ int srf_pw_bf16x3_launch(const PwArgs& a, int pro, hipStream_t st) {
       SRF_CHECK_LAUNCH(kLabel[pro < 0 || pro > 3 ? 3 : pro], st);
       return SRF_OK;
     }
-    if (abl && pro == 0) {
-      switch (abl) {
-        case 1: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 1>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 2: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 2>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 3: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 3>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 4: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 4>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 8: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 8>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 12: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 12>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-        case 10:  // no epilogue stores (everything else intact)
-          hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 32>), grid8, block8, 0, st, a, nMt, nLt, (int)total);
-          break;
-        case 9:   // (flag value 9 is not an ablation: in-kernel timeline into the buffer passed as `mul`)
-          SRF_CHECK_ARG(a.mul != nullptr && a.Cin <= 256, "srf_pw_conv: timeline needs a buffer in mul, Cin <= 256");
-          hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 16>), grid8, block8, 0, st, a, nMt, nLt, (int)total);
-          break;
-        default: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 15>), grid8, block8, 0, st, a, nMt, nLt, (int)total); break;
-      }
-      SRF_CHECK_LAUNCH("pw_conv_bf16x3_w8_ablated", st);
-      return SRF_OK;
-    }
-    PwArgs aw = a;
-    aw.epi_mask |= (((srf_debug_flags() >> 20) & 15) << 8) | (((srf_debug_flags() >> 12) & 1) << 12);
+    const PwArgs& aw = a;
     if (!srf_pw_buffer_ok(a)) {
       switch (pro) {
-        case 0: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, 0, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
-        case 1: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<1, 0, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
-        case 2: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<2, 0, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
-        default: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<3, 0, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+        case 0: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<0, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+        case 1: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<1, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+        case 2: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<2, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
+        default: hipLaunchKernelGGL((srf_pw_bf16x3_w8_kernel<3, false>), grid8, block8, 0, st, aw, nMt, nLt, (int)total); break;
       }
     } else
     switch (pro) {

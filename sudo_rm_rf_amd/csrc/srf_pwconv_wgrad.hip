@@ -394,7 +394,14 @@ static int wg_pick_partials(int ntiles, int nchunks) {
   int P = (2 * 256 + ntiles - 1) / ntiles;   // one resident wave of blocks (2 per CU): fewer, longer partials
   if (P > nchunks) P = nchunks;
   if (P > 128) P = 128;
-  if (P >= 8) P &= ~7;                       // a multiple of the XCD count (the kernel's xcd_map)
+  // A multiple of the XCD count (the kernel's xcd_map) where that costs little: rounded UP when the chunk count allows, DOWN
+  // otherwise, and left alone (plain mapping) when rounding down would drop more than a fifth of the blocks (ADVICE r4:
+  // ntiles = 36 gave P = 15 -> 8, half a wave of blocks).  The models' shapes (8, 16, 32, 64 tiles) land on multiples as is.
+  if (P >= 8 && (P & 7)) {
+    const int up = (P + 7) & ~7, down = P & ~7;
+    if (up <= nchunks && up <= 128) P = up;
+    else if (5 * down >= 4 * P) P = down;
+  }
   if (P < 1) P = 1;
   return P;
 }

@@ -53,10 +53,9 @@ template <int V>
 using f_int = std::integral_constant<int, V>;
 
 // PRO: 1 = GlobLN, 2 = GlobLN + PReLU (conv 1's operand load).  EPI: 0 = bias, 1 = bias + residual (conv 1's epilogue).
-// DBG 1: every counted wait of the DMA pipeline becomes vmcnt(0) (bisection aid: same results, slower).
-// DBG 2: per-wavefront shader-clock totals {kernel, conv 1, epilogue 1, conv 2, epilogues 2, tiles, real time, waits, barriers} as 16 dwords per wavefront to
-// a.tl (tools/pair_timeline.py; results stay correct).
-template <int PRO, int EPI, int DBG>
+// DRAIN: every counted wait of the DMA pipeline becomes vmcnt(0) -- the conservative form (debug flag 1 << 23), kept so that a
+// test can hold the counted waits against it bit for bit (same results, ~1.5 % slower).
+template <int PRO, int EPI, bool DRAIN>
 __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta) {
   static_assert(PRO == 1 || PRO == 2, "conv 1 of the built pairs has a GlobLN prologue");
@@ -197,21 +196,10 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
   // End of a step: this wavefront's pieces of the NEXT step's image have landed (VM = vector-memory operations it has issued
   // since: counted per call site, see the table at the tile loop), its fragment reads are done; the barrier publishes the
   // next stage and frees the current one.
-  unsigned tl_wait = 0, tl_bar = 0;      // (DBG 2: clocks spent in the counted waits / at the barriers)
   auto end_step = [&](auto vm_tag) __attribute__((always_inline)) {
-    constexpr int VM = DBG == 1 ? 0 : decltype(vm_tag)::value;
-    if constexpr (DBG == 2) {
-      const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
-      const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();
-      const unsigned t2 = (unsigned)__builtin_amdgcn_s_memtime();
-      tl_wait += t1 - t0;
-      tl_bar += t2 - t1;
-    } else {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    constexpr int VM = DRAIN ? 0 : decltype(vm_tag)::value;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
+    __builtin_amdgcn_s_barrier();
     s0 = stage_after(s0, 1);
   };
 
@@ -292,10 +280,6 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
   };
 
   // ---- prologue: the first two weight stages and the first four activation sets
-  unsigned tl_c1 = 0, tl_e1 = 0, tl_c2 = 0, tl_e2 = 0;
-  const unsigned tl_begin = DBG == 2 ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
-  const unsigned tl_rbegin = DBG == 2 ? (unsigned)__builtin_amdgcn_s_memrealtime() : 0u;      // (100 MHz)
-  auto tl_now = [&]() __attribute__((always_inline)) { return DBG == 2 ? (unsigned)__builtin_amdgcn_s_memtime() : 0u; };
   Regs r0, r1, r2, r3;
   dma_issue(srcA(0), 0);
   dma_issue(srcA(1), 1);
@@ -340,7 +324,6 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
       for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
     // ================= conv 1: nk1 steps of 16 k =================
-    const unsigned tl_t0 = tl_now();
     {   // the first step's operand (the only conversion a tile does in front of its MFMAs); its set goes back out for k-step 4
       float x0[8];
       stage_x(r0, x0);
@@ -374,7 +357,6 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
     stepA(f_int<1>{}, f_int<0>{}, f_int<(F_G == 2 ? 2 : 0)>{}, f_int<0>{}, f_int<(F_G == 2 ? VM_A_NL : VM_A_NL1)>{}, r3, kt + 6, tc, rrs);
     stepA(f_int<0>{}, f_int<0>{}, f_int<(F_G == 2 ? 3 : 1)>{}, f_int<1>{}, f_int<VM_A_NL>{}, r0, kt + 7, tc, rrs);
 
-    const unsigned tl_t1 = tl_now();
     // ================= epilogue 1: y = acc + bias (+ residual) -> HBM, and -> conv 2's B operand =================
     // Unit t = accumulator tile t (rows 32 t .. 32 t + 31): MFMA layout -> strip -> float4 rows (bias, residual; the sum goes
     // back into the strip and into a register batch) -> strip columns in B-operand order (lane (n, h): rows 16 c + 8 h + j =
@@ -456,7 +438,6 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
       }
     }
 
-    const unsigned tl_t2 = tl_now();
     // ================= conv 2: npass passes of 128 rows x 8 steps of 32 k, B operand from registers =================
     __amdgpu_buffer_rsrc_t y2rs = __builtin_amdgcn_make_buffer_rsrc(a.y2 + (size_t)b * C2 * Lt, 0, C2 * Lt * 4, 0x00020000);
     float s = 0.f, q = 0.f;
@@ -543,12 +524,9 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
     };
     for (int p = 0; p < npass - 1; ++p) {
       passB(p);
-      const unsigned te = tl_now();
       epiB(p);
-      tl_e2 += tl_now() - te;
     }
     passB(npass - 1);
-    const unsigned tl_t3 = tl_now();
     // the next tile's first four activation sets travel during the last epilogue (conv 2's operand registers are free now)
     if (i + 1 < ntile) {
       gload_b(r0, tn, 0);
@@ -565,30 +543,9 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
         atomicAdd(dst + 1, dq);
       }
     }
-    if constexpr (DBG == 2) {
-      const unsigned t4 = tl_now();
-      tl_c1 += tl_t1 - tl_t0;
-      tl_e1 += tl_t2 - tl_t1;
-      tl_e2 += t4 - tl_t3;
-      tl_c2 += tl_t3 - tl_t2;       // (includes the epilogues 2 of all passes but the last)
-    }
     tc = tn;
   } while (++i < ntile);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus DMA of the pipeline tail must not outlive the block's LDS
-  if constexpr (DBG == 2) {
-    if (a.tl && lane == 0) {
-      unsigned* o = a.tl + ((size_t)blockIdx.x * 4 + wave) * 16;
-      o[0] = tl_now() - tl_begin;
-      o[1] = tl_c1;
-      o[2] = tl_e1;
-      o[3] = tl_c2;
-      o[4] = tl_e2;
-      o[5] = (unsigned)ntile;
-      o[6] = (unsigned)__builtin_amdgcn_s_memrealtime() - tl_rbegin;
-      o[7] = tl_wait;
-      o[8] = tl_bar;
-    }
-  }
 }
 
 bool srf_x3f_supported(int Bt, int K1, int C2, int L) {
@@ -608,13 +565,11 @@ int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
   const long total = (long)a.Bt * a.nLt;
   SRF_CHECK_ARG(total < (1L << 30), "srf_pw_conv_pair: too many tiles");
   a.total = (int)total;
-  const bool dbg = (srf_debug_flags() & (1 << 23)) != 0;
-  const bool tl = a.tl != nullptr;
+  const bool drain = (srf_debug_flags() & (1 << 23)) != 0;
   const long ok = srf_device_cached(7, [](void*) -> long {
     bool good = true;
-    const void* fns[] = {(const void*)&srf_pw_x3f_kernel<1, 0, 0>, (const void*)&srf_pw_x3f_kernel<2, 1, 0>,
-                         (const void*)&srf_pw_x3f_kernel<1, 0, 1>, (const void*)&srf_pw_x3f_kernel<2, 1, 1>,
-                         (const void*)&srf_pw_x3f_kernel<1, 0, 2>, (const void*)&srf_pw_x3f_kernel<2, 1, 2>};
+    const void* fns[] = {(const void*)&srf_pw_x3f_kernel<1, 0, false>, (const void*)&srf_pw_x3f_kernel<2, 1, false>,
+                         (const void*)&srf_pw_x3f_kernel<1, 0, true>, (const void*)&srf_pw_x3f_kernel<2, 1, true>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
@@ -629,13 +584,11 @@ int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
   dim3 grid((unsigned)nb), block(256);
 #define F_GO(...) hipLaunchKernelGGL((srf_pw_x3f_kernel<__VA_ARGS__>), grid, block, F_LDS_BYTES, st, a, a.nrm.gamma, a.nrm.beta)
   if (pro == 1) {
-    if (tl) F_GO(1, 0, 2);
-    else if (dbg) F_GO(1, 0, 1);
-    else F_GO(1, 0, 0);
+    if (drain) F_GO(1, 0, true);
+    else F_GO(1, 0, false);
   } else {
-    if (tl) F_GO(2, 1, 2);
-    else if (dbg) F_GO(2, 1, 1);
-    else F_GO(2, 1, 0);
+    if (drain) F_GO(2, 1, true);
+    else F_GO(2, 1, false);
   }
 #undef F_GO
   SRF_CHECK_LAUNCH(pro == 1 ? "pw_pair_x3f<1>" : "pw_pair_x3f<2>", st);

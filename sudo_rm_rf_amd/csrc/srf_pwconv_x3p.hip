@@ -47,22 +47,12 @@ size_t srf_x3p_packed_bytes(int Cout, int Cin) {
   return (size_t)((Cout + P_BM - 1) / P_BM) * (size_t)(Cin / P_KT) * (size_t)P_A_IMG;
 }
 
-// ABL (diagnostics, lab builds only): the instantiation that obeys the run-time mask `rabl` (results wrong): 1 = no epilogue, 2 = no MFMAs, 4 = no
-// weight DMA, 8 = no activation loads / conversion / ds_write, 16 = no fragment reads, 32 = no barriers.
-// TL (diagnostics, lab builds only; results stay correct): per-wavefront shader-clock totals {whole kernel, counted waits, barriers, epilogues,
-// steps} as 8 dwords per wavefront to `a.mul` (tools/gemm_timeline_x3s.py with TL_GEMM=x3p).
 // CP (cache policy, as in srf_pwconv_x3w.hip): bit 0 = non-temporal output stores, bit 2 = non-temporal activation loads -- for the
 // forms whose streamed tensors would otherwise displace the weight image every CU re-reads from L2 for every tile.
-template <int PRO, int EPI, int ABL = 0, int TL = 0, int CP = 0>
+template <int PRO, int EPI, int CP = 0>
 __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt, int total,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const float* __restrict__ bias_r, int rabl_arg, int stagger) {
-  const int rabl = ABL ? rabl_arg : 0;
-  // Two blocks share a CU and run tiles of equal length: left alone they reach their epilogues together.  The blocks of the
-  // grid's second half (the ones the dispatcher places as second residents) start `stagger` x ~8 K cycles late, so that one
-  // block's epilogue (stores, residual loads) falls into the other's k-loop.
-  if (blockIdx.x >= (gridDim.x >> 1))
-    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+                                                            const float* __restrict__ bias_r) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,7 +127,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
     float b[4];
   };
   auto gload_a = [&](const TileP& t, int kt, int stage) __attribute__((always_inline)) {
-    if (ABL && (rabl & 4)) return;
     const char* src = t.a_src + (size_t)kt * P_A_IMG + lane * 16;
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)P_LDS(smem + stage * P_STAGE + wave * 2048));
 #pragma unroll
@@ -151,17 +140,11 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
     }
   };
   auto gload_b = [&](Regs& r, const TileP& t, int kt) __attribute__((always_inline)) {
-    if (ABL && (rabl & 8)) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(r.b[j]));
-      return;
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * P_KT + j) * L * 4, (CP & 4) ? 2 : 0));
   };
   auto lds_store = [&](const Regs& r, const TileP& t, int kt, int stage) __attribute__((always_inline)) {
-    if (ABL && (rabl & 8)) return;
     float x[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[j] = r.b[j];
@@ -203,11 +186,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
     bf16x8 ah[2], al[2], bh[2], bl[2];
   };
   auto read_frags = [&](Frags& f, int stage) __attribute__((always_inline)) {
-    if (ABL && (rabl & 16)) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) asm volatile("" : "=v"(f.ah[t]), "=v"(f.al[t]), "=v"(f.bh[t]), "=v"(f.bl[t]));
-      return;
-    }
     const char* base = smem + stage * P_STAGE;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -218,10 +196,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
     }
   };
   auto mma = [&](const Frags& f) __attribute__((always_inline)) {
-    if (ABL && (rabl & 2)) {
-      asm volatile("" ::"v"(f.ah[0]), "v"(f.al[0]), "v"(f.bh[0]), "v"(f.bl[0]), "v"(f.ah[1]), "v"(f.al[1]), "v"(f.bh[1]), "v"(f.bl[1]));
-      return;
-    }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -242,8 +216,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
   // are done and its DMA pieces of k-step kt+1 -- issued a step ago, 10 memory operations ago -- have landed.
   int s0 = 0;
   TileP tc, tn;
-  unsigned tl_wait = 0, tl_bar = 0, tl_epi = 0, tl_steps = 0;
-  const unsigned tl_begin = TL ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
   auto pick = [&](int k, int& kk) __attribute__((always_inline)) {
     const bool nx = k >= nk;   // wave-uniform
     kk = nx ? k - nk : k;
@@ -264,20 +236,8 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
     gload_a(t2, k2, s2);
     gload_b(set, t5, k5);
     mma(f);
-    if constexpr (TL) {
-      const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-      const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();
-      const unsigned t2 = (unsigned)__builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      tl_wait += t1 - t0;
-      tl_bar += t2 - t1;
-      tl_steps += 1;
-    } else {
-      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-      if (!(ABL && (rabl & 32))) __builtin_amdgcn_s_barrier();
-    }
+    asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     s0 = s1;
   };
 
@@ -307,13 +267,12 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
       step(r0, kt + 3);
     }
     // ---- epilogue
-    const unsigned tl_e0 = TL ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
     const int b = cur.b, m0 = cur.mt * P_BM + wm * 64, l0 = cur.lt * P_BN + wn * 64, v = cur.v;
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));     // (keeps the offsets below from being hoisted out of the tile loop and spilled)
     const int lhalf = lane_o >> 5, lcol = lane_o & 31;
     float s = 0.f, q = 0.f;
-    if (!(ABL && (rabl & 1)) && m0 < a.Cout) {      // (Cout % 64 == 0: a wavefront's 64 rows are in range together or not at all)
+    if (m0 < a.Cout) {      // (Cout % 64 == 0: a wavefront's 64 rows are in range together or not at all)
       __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * a.Cout * L, 0, a.Cout * L * 4, 0x00020000);
       __amdgpu_buffer_rsrc_t rrs = yrs;
       if constexpr (EPI == 1)
@@ -392,9 +351,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-    } else if (ABL) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(acc[mi][0]), "v"(acc[mi][1]));
     }
     if (EPI == 0 && a.out_sums) {
       const double ds = srf_dpp_wave_sum((double)s), dq = srf_dpp_wave_sum((double)q);
@@ -410,10 +366,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    if constexpr (TL) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      tl_epi += (unsigned)__builtin_amdgcn_s_memtime() - tl_e0;
-    }
     // every wavefront's strip reads are done before the next step's DMA overwrites that stage
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -425,16 +377,6 @@ __global__ __launch_bounds__(512, 4) void srf_pw_x3p_kernel(PwArgs a, const char
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus DMA of the pipeline tail must not outlive the block's LDS
-  if constexpr (TL) {
-    unsigned* out = reinterpret_cast<unsigned*>(const_cast<float*>(a.mul)) + ((size_t)blockIdx.x * 8 + wave) * 8;
-    if (lane == 0) {
-      out[0] = (unsigned)__builtin_amdgcn_s_memtime() - tl_begin;
-      out[1] = tl_bar;
-      out[2] = tl_wait;
-      out[3] = tl_epi;
-      out[4] = tl_steps;
-    }
-  }
 }
 
 bool srf_x3p_supported(const PwArgs& a, int pro) {
@@ -456,44 +398,21 @@ int srf_pw_x3p_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
                          (const void*)&srf_pw_x3p_kernel<2, 0>, (const void*)&srf_pw_x3p_kernel<3, 0>,
                          (const void*)&srf_pw_x3p_kernel<0, 1>, (const void*)&srf_pw_x3p_kernel<1, 1>,
                          (const void*)&srf_pw_x3p_kernel<2, 1>, (const void*)&srf_pw_x3p_kernel<3, 1>,
-                         (const void*)&srf_pw_x3p_kernel<1, 0, 0, 0, 4>, (const void*)&srf_pw_x3p_kernel<2, 1, 0, 0, 4>,
-#ifdef SRF_EXPERIMENTS
-                         (const void*)&srf_pw_x3p_kernel<0, 0, 1>, (const void*)&srf_pw_x3p_kernel<2, 1, 1>,
-                         (const void*)&srf_pw_x3p_kernel<0, 0, 0, 1>, (const void*)&srf_pw_x3p_kernel<2, 1, 0, 1>,
-#endif
-    };
+                         (const void*)&srf_pw_x3p_kernel<1, 0, 4>, (const void*)&srf_pw_x3p_kernel<2, 1, 4>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
   SRF_CHECK_ARG(ok == 1, "srf_pw_conv: cannot reserve %d bytes of LDS", P_LDS_BYTES);
   long nb = 2L * srf_device_cus();      // two resident blocks per CU
-  int abl = 0, stagger = 0;
-#ifdef SRF_EXPERIMENTS                   // lab builds: block count, ablation mask, start-up stagger, in-kernel timeline
-  if (const char* e = getenv("SRF_X3P_BLOCKS")) nb = atol(e) > 0 ? atol(e) : nb;
-  abl = getenv("SRF_X3W_ABL") ? atoi(getenv("SRF_X3W_ABL")) : 0;
-  stagger = getenv("SRF_X3P_STAGGER") ? atoi(getenv("SRF_X3P_STAGGER")) : 0;
-#endif
   nb -= nb % 8;
   if (nb > total) nb = total;
   dim3 grid((unsigned)nb), block(512);
   const bool res = a.residual != nullptr;
-#define P_GO(...) hipLaunchKernelGGL((srf_pw_x3p_kernel<__VA_ARGS__>), grid, block, P_LDS_BYTES, st, a, wpack, nMt, nLt, (int)total, a.nrm.gamma, a.nrm.beta, a.bias, abl, stagger)
-#ifdef SRF_EXPERIMENTS
-  const bool tl = getenv("SRF_X3S_TL") && atoi(getenv("SRF_X3S_TL")) && a.mul;
-  if (tl && pro == 0 && !res) {
-    P_GO(0, 0, 0, 1);
-  } else if (tl && pro == 2 && res) {
-    P_GO(2, 1, 0, 1);
-  } else if (abl && pro == 0 && !res) {
-    P_GO(0, 0, 1);
-  } else if (abl && pro == 2 && res) {
-    P_GO(2, 1, 1);
-  } else
-#endif
+#define P_GO(...) hipLaunchKernelGGL((srf_pw_x3p_kernel<__VA_ARGS__>), grid, block, P_LDS_BYTES, st, a, wpack, nMt, nLt, (int)total, a.nrm.gamma, a.nrm.beta, a.bias)
   if (pro == 1 && !res && !(srf_debug_flags() & 2)) {
-    P_GO(1, 0, 0, 0, 4);          // bottleneck
+    P_GO(1, 0, 4);                // bottleneck
   } else if (pro == 2 && res && !(srf_debug_flags() & 2)) {
-    P_GO(2, 1, 0, 0, 4);          // res_conv (debug flag 2: the plain cache policy)
+    P_GO(2, 1, 4);                // res_conv (debug flag 2: the plain cache policy)
   } else if (!res) {
     switch (pro) {
       case 0: P_GO(0, 0); break;

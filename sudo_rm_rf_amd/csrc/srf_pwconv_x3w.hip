@@ -101,8 +101,6 @@ __device__ __forceinline__ void w_split8_f16(const float (&v)[8], bf16x8& hi, bf
 //      4 = the mask epilogue FUSED with the decoder's contraction (K5): the masked values never leave the chip -- see the EPI 4
 //          block in the tile loop; bias_r = the bias again as a noalias argument (scalar loads), wdpack = the decoder weights as
 //          MFMA A fragments (srf_x3w_pack_dec_kernel), zpart = [Bt][nMt][zM][L] partial decoder frames, zM = sources x taps.
-// ABL (diagnostics, results are wrong when != 0): 1 = no activation loads, 2 = no weight DMA, 4 = no MFMAs, 8 = no GlobLN / PReLU /
-// split / ds_write, 16 = no epilogue, 32 = no fragment reads.
 // gamma / beta come again as noalias kernel arguments so that they are fetched with scalar loads.
 // Work distribution, barrier protocol and LDS images: as in round 2's kernel (file header).
 // CP: cache policy of the streamed tensors (see the launch function).
@@ -111,7 +109,7 @@ __device__ __forceinline__ void w_split8_f16(const float (&v)[8], bf16x8& hi, bf
 //     (VERDICT r2 next 4).  Same stages, DMA, swizzle and fragment reads: a k-tile then holds 16 k instead of 32 -- the "hi"
 //     image carries h (slots 0-15) and m (slots 16-31) of those 16 k, the "lo" image l (slots 0-15) -- so what was the second
 //     k-sub-step's fragment pair is the m part (srf_x3w_pack3_kernel writes the weights that way, lds_store the activations).
-template <int PRO, int EPI, int ABL = 0, int CP = 0, int NP = 2>
+template <int PRO, int EPI, int CP = 0, int NP = 2>
 __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char* __restrict__ wpack, int nMt, int nLt,
                                                             int total, int rounds, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ bias_r,
@@ -131,12 +129,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
   const int x_bytes = a.Bt * Cin * L * 4;
   constexpr bool kHasExt = EPI != 0 && EPI != 4;   // the strip epilogue reads a second tensor (residual or mask multiplier)
-  // One-off start-up stagger (diagnostics: epi_mask bits 8..11 = units of ~4K cycles, 4 phases by block id; default none)
-  {
-    const int units = (a.epi_mask >> 8) & 15;
-    const int phase = (blockIdx.x >> 3) & 3;
-    for (int i = 0; i < units * phase; ++i) __builtin_amdgcn_s_sleep(64);
-  }
 
   // ---- GlobLN statistics of every example, once per block: {mean, rstd} in LDS behind the stages.  (A vector load per tile
   // -- the round-2 form -- is waited for with vmcnt(0) right behind two k-tiles' worth of activation loads.)  Wavefront w
@@ -256,7 +248,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   };
   // A: LDS DMA through inline asm (invisible to hipcc's vmcnt bookkeeping: counted by hand, see `step`)
   auto gload_a = [&](const TileP& t, int kt, int stage) __attribute__((always_inline)) {
-    if (ABL & 2) return;
     const char* src = t.a_src + (size_t)kt * W_WTILE_BYTES + lane * 16;
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)W_LDS(smem + stage * W_STAGE + wave * 4096));
 #pragma unroll
@@ -270,33 +261,12 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     }
   };
   auto gload_b = [&](Regs& r, const TileP& t, int kt) __attribute__((always_inline)) {
-    if (ABL & 1) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(r.b[j]));
-      return;
-    }
-    if constexpr ((ABL & 512) != 0) {     // diagnostics (results wrong): the same 16 KB per k-tile as TWO 16-byte loads per thread
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const int vo = t.b_vo - (b_kg * L + (tid & 127)) * 4 + ((wave * 4 + (lane >> 5)) * L + (lane & 31) * 4) * 4;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b_rs, vo, (kt * KT + 2 * h) * L * 4, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.b[4 * h + j] = __uint_as_float(v[j]);
-      }
-      return;
-    }
 #pragma unroll
     for (int j = 0; j < (NP == 3 ? 4 : 8); ++j)
       r.b[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rs, t.b_vo, (kt * KT + j) * L * 4, (CP & 4) ? 2 : 0));
   };
   // GlobLN / PReLU / split of k-tile kt (tile t) -> B images of `stage`
   auto lds_store = [&](const Regs& r, const TileP& t, int kt, int stage) __attribute__((always_inline)) {
-    if (ABL & 8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(r.b[j]));
-      return;
-    }
     char* base = smem + stage * W_STAGE + b_lds;
     if constexpr (NP == 3) {
       float x[4];
@@ -376,11 +346,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   };
   auto read_frags = [&](Frags& f, int stage, int ks, auto full_tag) __attribute__((always_inline)) {
     constexpr int NT = decltype(full_tag)::value ? 2 : 1;
-    if (ABL & 32) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(f.ah[t]), "+v"(f.al[t]), "+v"(f.bh[t]), "+v"(f.bl[t]));
-      return;
-    }
     const char* base = smem + stage * W_STAGE;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -392,10 +357,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     }
   };
   auto mma = [&](const Frags& f, auto full_tag) __attribute__((always_inline)) {
-    if (ABL & 4) {
-      asm volatile("" ::"v"(f.ah[0]), "v"(f.al[0]), "v"(f.bh[0]), "v"(f.bl[0]));
-      return;
-    }
     constexpr int NT = decltype(full_tag)::value ? 2 : 1;
     // pass-major order: independent accumulators between two MFMAs on the same one (and the summation order of every split-bf16 kernel of the library)
     auto mf = [](const bf16x8& x, const bf16x8& y, const f32x16& c) __attribute__((always_inline)) {
@@ -477,14 +438,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     t.rstd = nx ? tn.rstd : tc.rstd;
     return t;
   };
-  // ---- in-kernel timeline (ABL & 64, diagnostics; results stay correct).  Three registers used as 64-entry arrays (entry =
-  // lane): tl_wait[kt] / tl_bar[kt] = shader cycles every wavefront spent in the step's counted wait / in its barrier, summed
-  // over the block's tiles, by k-step of the tile (kt < 32); tl_abs[3 t .. 3 t + 2] = s_memrealtime (100 MHz, one clock for the
-  // whole chip) at the start / k-loop end / epilogue end of the block's tile t (t < 20).  Written to `a.mul` at the end.
-  unsigned tl_wait = 0, tl_bar = 0, tl_abs = 0;
-  auto tl_put = [&](unsigned& arr, int idx, unsigned val, bool add) __attribute__((always_inline)) {
-    arr = (lane == idx) ? (add ? arr + val : val) : arr;
-  };
   auto step = [&](Regs& nx, int kt, auto full_tag, auto have0_tag, auto pref_tag) __attribute__((always_inline)) {
     // (NP 3: always the just-in-time flavour -- the h fragments of sub-step 0 are needed again with the m fragments)
     constexpr bool HAVE0 = NP == 3 ? false : decltype(have0_tag)::value, PREF = NP == 3 ? false : decltype(pref_tag)::value;
@@ -493,19 +446,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     const TileP t1 = pick(kt + 1, k1), t2 = pick(kt + 2, k2), t3 = pick(kt + 3, k3);
     if constexpr (!HAVE0) read_frags(f0, s0, 0, full_tag);
     if constexpr (HAVE0) read_frags(f1, s0, 1, full_tag);
-    // diagnostics / experiment (results stay correct): wavefronts 4..7 -- the SIMD partners of 0..3 -- multiply BEFORE they
-    // convert and issue their loads, so that one partner's memory-instruction queueing runs under the other's MFMAs
-    const bool mma_first = (ABL & 256) != 0 && NP != 3 && wave >= 4;
-    if (mma_first) mma(f0, full_tag);
-    if constexpr (ABL & 64) {      // how long the step sits in the activation conversion (its wait for the loads of two steps ago)
-      const unsigned ta = (unsigned)__builtin_amdgcn_s_memtime();
-      lds_store(nx, t1, k1, s1);
-      const unsigned tb = (unsigned)__builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      tl_put(tl_bar, 32 + (kt & 31), tb - ta, true);
-    } else {
-      lds_store(nx, t1, k1, s1);
-    }
+    lds_store(nx, t1, k1, s1);
     gload_a(t2, k2, s2);
     gload_b(nx, t3, k3);
     if constexpr (NP == 3) {
@@ -513,27 +454,16 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       read_frags(f1, s0, 1, full_tag);
       mma3_b(f0, f1, full_tag);
     } else {
-      if (!mma_first) mma(f0, full_tag);
+      mma(f0, full_tag);
       if constexpr (!HAVE0) {
         read_frags(f1, s0, 1, full_tag);
         mma(f1, full_tag);
       }
     }
-    if constexpr (ABL & 64) {
-      const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
-      const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();
-      const unsigned t2 = (unsigned)__builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      tl_put(tl_wait, kt & 31, t1 - t0, true);
-      tl_put(tl_bar, kt & 31, t2 - t1, true);
-    } else {
-      // (in flight behind the DMA of k-tile kt + 1: last step's activation loads, this step's DMA and activation loads)
-      if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    // (in flight behind the DMA of k-tile kt + 1: last step's activation loads, this step's DMA and activation loads)
+    if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if constexpr (PREF) read_frags(f0, s1, 0, full_tag);     // next k-tile's first half, under this one's second
     if constexpr (HAVE0) mma(f1, full_tag);
     s0 = s1;
@@ -549,10 +479,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
   tc = make_tile(cur);
   tn = nxc.v >= 0 ? make_tile(nxc) : tc;   // past the last tile the pipeline re-reads that tile (harmless)
   Regs r0, r1;
-  if (ABL & 1) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r0.b[j] = r1.b[j] = 0.5f * j + lane;
-  }
   gload_a(tc, 0, 0);
   gload_b(r0, tc, 0);                   // k-tile 0 -> stage 0 (A), r0 (B)
   gload_a(tc, 1, 1);
@@ -607,7 +533,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     // half (mi = 1) right after the last step, when the fragment registers are free -- it lands while the upper half's strips
     // are processed.  (All 64 registers two steps ahead, the round-2 form, spilled next to 64 accumulators + the fragments.)
     auto epi_issue = [&](auto half_tag) __attribute__((always_inline)) {
-      if (ABL & 16) return;
       constexpr int mi = decltype(half_tag)::value;
       {
 #pragma unroll
@@ -640,11 +565,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
         }
       }
     };
-    unsigned tl_c0 = 0;
-    if constexpr (ABL & 64) {
-      if (i < 20) tl_put(tl_abs, 3 * i, (unsigned)__builtin_amdgcn_s_memrealtime(), false);
-      tl_c0 = (unsigned)__builtin_amdgcn_s_memtime();
-    }
     // EPI 4: the encoder multiplier in the MFMA C layout (register r of accumulator tile (mi, ni) = row (r & 3) + 8 (r >> 2) +
     // 4 (lane >> 5), column lane & 31), one dword per register; upper half (mi = 0) two steps ahead, lower half after the last step
     float rxc[EPI == 4 ? 2 : 1][EPI == 4 ? 2 : 1][EPI == 4 ? 16 : 1];
@@ -713,10 +633,6 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
       k_loop(F{});
     else
       k_loop(T{});
-    if constexpr (ABL & 64) {
-      if (i < 20) tl_put(tl_abs, 3 * i + 1, (unsigned)__builtin_amdgcn_s_memrealtime(), false);
-      if (i < 20) tl_put(tl_wait, 32 + i, (unsigned)__builtin_amdgcn_s_memtime() - tl_c0, false);   // k-loop shader cycles of tile i
-    }
     // parameters of the tile after next (LDS table + integer arithmetic: no memory wait)
     TileCur nnc = nxc;
     if (i + 2 < ntile) cur_next(nnc);
@@ -854,10 +770,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     }
     float* strip = reinterpret_cast<float*>(smem + free_stage * W_STAGE) + wave * (32 * SRF_EPI_PITCH_H);
     float s = 0.f, q = 0.f;
-    if (ABL & 16) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(acc[mi][0]), "v"(acc[mi][1]));
-    } else {
+    {
       const int col = lane & 31, kh = lane >> 5;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -892,9 +805,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
               int mc, lc;
               const bool okr = epi_row(mi, ii, mc), okc = epi_col(ni, lc);
               if (okr && okc) {
-                if constexpr (ABL & 128) {
-                  asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));   // diagnostics: epilogue without its stores
-                } else if constexpr ((CP & 3) == 0) {
+                if constexpr ((CP & 3) == 0) {
                   *reinterpret_cast<float4*>(yb + mc * L + lc) = o;
                 } else {
                   // cache-policy experiment: the output tensor is written once and read by a LATER kernel -- keep it from
@@ -935,17 +846,8 @@ __global__ __launch_bounds__(512, 2) void srf_pw_x3w_kernel(PwArgs a, const char
     // strip reads done before the next step's DMA overwrites that stage
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (ABL & 64) {
-      if (i < 20) tl_put(tl_abs, 3 * i + 2, (unsigned)__builtin_amdgcn_s_memrealtime(), false);
-    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus DMA of the pipeline tail must not outlive the block's LDS
-  if constexpr (ABL & 64) {
-    unsigned* out = reinterpret_cast<unsigned*>(const_cast<float*>(a.mul)) + ((size_t)blockIdx.x * 8 + wave) * 192;
-    out[lane] = tl_wait;
-    out[64 + lane] = tl_bar;
-    out[128 + lane] = tl_abs;
-  }
 }
 
 bool srf_x3w_supported(int Bt, int pro) { return !(pro == 1 || pro == 2) || Bt <= W_MAX_STAT_EXAMPLES; }
@@ -1161,46 +1063,19 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
     const int bytes = W_NSTAGE * W_STAGE + W_MAX_STAT_EXAMPLES * (int)sizeof(float2);
     bool good = true;
     const void* fns[] = {
-        // the four forms the models launch, by cache policy
-        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 0>, (const void*)&srf_pw_x3w_kernel<0, 0, 0, 1>,
-        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 4>, (const void*)&srf_pw_x3w_kernel<0, 0, 0, 5>,
-        (const void*)&srf_pw_x3w_kernel<1, 0, 0, 0>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 1>,
-        (const void*)&srf_pw_x3w_kernel<1, 0, 0, 4>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 5>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 0>, (const void*)&srf_pw_x3w_kernel<2, 1, 0, 1>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 4>, (const void*)&srf_pw_x3w_kernel<2, 1, 0, 5>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 13>,
-        (const void*)&srf_pw_x3w_kernel<3, 2, 0, 0>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, 1>,
-        (const void*)&srf_pw_x3w_kernel<3, 2, 0, 4>, (const void*)&srf_pw_x3w_kernel<3, 2, 0, 5>,
-        (const void*)&srf_pw_x3w_kernel<3, 2, 0, 13>,
-        (const void*)&srf_pw_x3w_kernel<3, 4, 0, 0>, (const void*)&srf_pw_x3w_kernel<3, 4, 0, 4>,
-        (const void*)&srf_pw_x3w_kernel<0, 1, 0, 0>,
-        // two fp16 parts (training-forward experiment)
-        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 0, 4>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 5, 4>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 5, 4>, (const void*)&srf_pw_x3w_kernel<3, 0, 0, 5, 4>,
-        // three-part operands (training forward)
-        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 0, 3>, (const void*)&srf_pw_x3w_kernel<1, 0, 0, 5, 3>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 0, 5, 3>, (const void*)&srf_pw_x3w_kernel<3, 0, 0, 5, 3>,
+        // the forms the models launch, each with its cache policy (see the launch function)
+        (const void*)&srf_pw_x3w_kernel<0, 0, 0>, (const void*)&srf_pw_x3w_kernel<1, 0, 5>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 5>, (const void*)&srf_pw_x3w_kernel<3, 2, 5>,
+        (const void*)&srf_pw_x3w_kernel<3, 4, 4>, (const void*)&srf_pw_x3w_kernel<0, 1, 0>,
+        // two fp16 parts per operand (training forward, the default)
+        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 4>, (const void*)&srf_pw_x3w_kernel<1, 0, 5, 4>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 5, 4>, (const void*)&srf_pw_x3w_kernel<3, 0, 5, 4>,
+        // three bf16 parts per operand (training forward, debug flag 16384)
+        (const void*)&srf_pw_x3w_kernel<0, 0, 0, 3>, (const void*)&srf_pw_x3w_kernel<1, 0, 5, 3>,
+        (const void*)&srf_pw_x3w_kernel<2, 1, 5, 3>, (const void*)&srf_pw_x3w_kernel<3, 0, 5, 3>,
         // any other prologue / epilogue combination (unit tests, stand-alone srf_pw_conv callers)
         (const void*)&srf_pw_x3w_kernel<0, 3>, (const void*)&srf_pw_x3w_kernel<1, 3>,
-        (const void*)&srf_pw_x3w_kernel<2, 3>, (const void*)&srf_pw_x3w_kernel<3, 3>,
-#ifdef SRF_EXPERIMENTS
-        // diagnostics (SRF_BUILD_EXPERIMENTS=1 builds only): ablated pipelines and the in-kernel timeline (proj_1x1 / res_conv forms)
-        (const void*)&srf_pw_x3w_kernel<0, 0, 3>, (const void*)&srf_pw_x3w_kernel<0, 0, 4>,
-        (const void*)&srf_pw_x3w_kernel<0, 0, 7>, (const void*)&srf_pw_x3w_kernel<0, 0, 12>,
-        (const void*)&srf_pw_x3w_kernel<0, 0, 16>, (const void*)&srf_pw_x3w_kernel<0, 0, 19>,
-        (const void*)&srf_pw_x3w_kernel<0, 0, 20>, (const void*)&srf_pw_x3w_kernel<0, 0, 23>,
-        (const void*)&srf_pw_x3w_kernel<0, 0, 31>, (const void*)&srf_pw_x3w_kernel<0, 0, 55>,
-        (const void*)&srf_pw_x3w_kernel<0, 0, 63>, (const void*)&srf_pw_x3w_kernel<0, 0, 64>,
-        (const void*)&srf_pw_x3w_kernel<0, 0, 192>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 3>, (const void*)&srf_pw_x3w_kernel<2, 1, 4>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 16>, (const void*)&srf_pw_x3w_kernel<2, 1, 19>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 20>, (const void*)&srf_pw_x3w_kernel<2, 1, 23>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 64>,
-        (const void*)&srf_pw_x3w_kernel<0, 0, 256>, (const void*)&srf_pw_x3w_kernel<0, 0, 512>,
-        (const void*)&srf_pw_x3w_kernel<0, 0, 768>, (const void*)&srf_pw_x3w_kernel<2, 1, 256>,
-        (const void*)&srf_pw_x3w_kernel<2, 1, 512>, (const void*)&srf_pw_x3w_kernel<2, 1, 768>,
-#endif
-        (const void*)&srf_pw_x3w_kernel<0, 1, 0, 0>};
+        (const void*)&srf_pw_x3w_kernel<2, 3>, (const void*)&srf_pw_x3w_kernel<3, 3>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
@@ -1226,69 +1101,17 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
   dim3 grid((unsigned)nb), block(512);
   PwArgs ap = a;
   if (!(srf_debug_flags() & 512)) ap.epi_mask |= 1 << 12;   // quarter tiles first (flag 512: last)
-#ifdef SRF_EXPERIMENTS     // (lab builds only -- ADVICE r4: in the product build bits 22 / 23 belong to other switches)
-  ap.epi_mask |= ((srf_debug_flags() >> 22) & 3) << 8;      // diagnostics: start-up stagger units (flag bits 22-23)
-#endif
   const bool res = a.residual != nullptr, mask = !res && (a.epi_mask & 1);
-#define W_GO(P, E, A, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, A, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
-#ifdef SRF_EXPERIMENTS
-  // diagnostics: ablated pipelines.  debug flags bits 16..21 = the ABL mask (only the combinations instantiated above),
-  // 1 << 25 = in-kernel timeline (tools/gemm_timeline.py), 1 << 30 = epilogue without its stores
-  const int env_abl = getenv("SRF_X3W_ABL") ? atoi(getenv("SRF_X3W_ABL")) : 0;     // round-4 experiments: ABL bits 256 / 512
-  const int abl = ((srf_debug_flags() >> 16) & 63) | ((srf_debug_flags() & (1 << 25)) ? 64 : 0) |
-                  ((srf_debug_flags() & (1 << 30)) ? 128 : 0) | env_abl;
-  if (abl && pro == 2 && res) {
-    switch (abl) {
-      case 3: W_GO(2, 1, 3, 0); break;
-      case 4: W_GO(2, 1, 4, 0); break;
-      case 16: W_GO(2, 1, 16, 0); break;
-      case 19: W_GO(2, 1, 19, 0); break;
-      case 20: W_GO(2, 1, 20, 0); break;
-      case 23: W_GO(2, 1, 23, 0); break;
-      case 64: W_GO(2, 1, 64, 0); break;
-      case 256: W_GO(2, 1, 256, 0); break;
-      case 512: W_GO(2, 1, 512, 0); break;
-      case 768: W_GO(2, 1, 768, 0); break;
-      default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for res_conv", abl);
-    }
-    SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
-    return SRF_OK;
-  }
-  if (abl && pro == 0 && !res && !mask) {
-    switch (abl) {
-      case 3: W_GO(0, 0, 3, 0); break;
-      case 4: W_GO(0, 0, 4, 0); break;
-      case 7: W_GO(0, 0, 7, 0); break;
-      case 12: W_GO(0, 0, 12, 0); break;
-      case 16: W_GO(0, 0, 16, 0); break;
-      case 19: W_GO(0, 0, 19, 0); break;
-      case 20: W_GO(0, 0, 20, 0); break;
-      case 23: W_GO(0, 0, 23, 0); break;
-      case 31: W_GO(0, 0, 31, 0); break;
-      case 55: W_GO(0, 0, 55, 0); break;
-      case 63: W_GO(0, 0, 63, 0); break;
-      case 64: W_GO(0, 0, 64, 0); break;
-      case 192: W_GO(0, 0, 192, 0); break;
-      case 256: W_GO(0, 0, 256, 0); break;
-      case 512: W_GO(0, 0, 512, 0); break;
-      case 768: W_GO(0, 0, 768, 0); break;
-      default: SRF_CHECK_ARG(false, "srf_pw_conv: ablation %d not built for proj_1x1", abl);
-    }
-    SRF_CHECK_LAUNCH("pw_conv_x3w_ablated", st);
-    return SRF_OK;
-  }
-#endif
+#define W_GO(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, C>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
   // Cache policy (CP) of the four model forms: bit 0 = non-temporal output stores, bit 2 = non-temporal activation loads,
   // bit 3 = non-temporal residual / mask-multiplier loads.  Every CU re-reads the whole packed weight image from L2 for every
   // tile, while activations, residuals and outputs stream through once: marked non-temporal they stop displacing the weights.
   // Defaults = what measured fastest INSIDE the forward (profiles/r03_NOTES.md: isolated launches mislead -- non-temporal
   // stores looked 10 % faster on proj_1x1 alone and cost 5 % in the model, where the next kernel reads that tensor): proj_1x1
-  // plain; bottleneck, res_conv, mask non-temporal activation loads + stores.  Debug flag bits 26..29 = CP + 1 override.
-  const int cp_flag = (srf_debug_flags() >> 26) & 15;
-  static const int kDefaultCp[4] = {0, 5, 5, 5};
-  const int cp = cp_flag ? cp_flag - 1 : kDefaultCp[pro < 0 || pro > 3 ? 0 : pro];
+  // plain (CP 0); bottleneck, res_conv, mask non-temporal activation loads + stores (CP 5; the fused mask + decoder GEMM
+  // has no output tensor to mark: CP 4).
   if (np == 4) {
-#define W_GO4(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, C, 4>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
+#define W_GO4(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, C, 4>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
     SRF_CHECK_ARG(!mask && !fuse_wd && (pro == 2) == res && !(pro != 2 && res), "srf_pw_conv (fp16 two-part): form not built");
     if (pro == 0) W_GO4(0, 0, 0);
     else if (pro == 1) W_GO4(1, 0, 5);
@@ -1300,7 +1123,7 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
     return SRF_OK;
   }
   if (np == 3) {
-#define W_GO3(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, 0, C, 3>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
+#define W_GO3(P, E, C) hipLaunchKernelGGL((srf_pw_x3w_kernel<P, E, C, 3>), grid, block, lds, st, ap, wpack, nMt, nLt, (int)total, rounds, a.nrm.gamma, a.nrm.beta, a.bias, fuse_wd, fuse_z, fuse_M, mgrp)
     SRF_CHECK_ARG(!mask && !fuse_wd && (pro == 2) == res && !(pro != 2 && res), "srf_pw_conv (three-part): form not built");
     if (pro == 0) W_GO3(0, 0, 0);
     else if (pro == 1) W_GO3(1, 0, 5);
@@ -1312,26 +1135,20 @@ static int srf_pw_x3w_launch_any(const PwArgs& a, const char* wpack, int pro, co
     return SRF_OK;
   }
   if (fuse_wd) {
-    if (cp & 4) W_GO(3, 4, 0, 4);
-    else W_GO(3, 4, 0, 0);
+    W_GO(3, 4, 4);
     SRF_CHECK_LAUNCH("pw_mask_decode", st);
     return SRF_OK;
   }
-#define W_CP4(P, E) switch (cp & 7) { case 1: W_GO(P, E, 0, 1); break; case 4: W_GO(P, E, 0, 4); break; case 5: W_GO(P, E, 0, 5); break; default: W_GO(P, E, 0, 0); break; }
-#define W_CP5(P, E) switch (cp) { case 1: W_GO(P, E, 0, 1); break; case 4: W_GO(P, E, 0, 4); break; case 5: W_GO(P, E, 0, 5); break; \
-    case 13: W_GO(P, E, 0, 13); break; default: W_GO(P, E, 0, 0); break; }
   // the forms the models use are specialised on their epilogue; anything else runs the run-time-switched one
-  if (pro == 0 && !res && !mask) { W_CP4(0, 0) }
-  else if (pro == 1 && !res && !mask) { W_CP4(1, 0) }
-  else if (pro == 2 && res) { W_CP5(2, 1) }
-  else if (pro == 0 && res) W_GO(0, 1, 0, 0);      // (the backward's data-gradient GEMM of proj_1x1: W^T g + skip gradient)
-  else if (pro == 3 && mask) { W_CP5(3, 2) }
-  else if (pro == 0) W_GO(0, 3, 0, 0);
-  else if (pro == 1) W_GO(1, 3, 0, 0);
-  else if (pro == 2) W_GO(2, 3, 0, 0);
-  else W_GO(3, 3, 0, 0);
-#undef W_CP5
-#undef W_CP4
+  if (pro == 0 && !res && !mask) W_GO(0, 0, 0);
+  else if (pro == 1 && !res && !mask) W_GO(1, 0, 5);
+  else if (pro == 2 && res) W_GO(2, 1, 5);
+  else if (pro == 0 && res) W_GO(0, 1, 0);      // (the backward's data-gradient GEMM of proj_1x1: W^T g + skip gradient)
+  else if (pro == 3 && mask) W_GO(3, 2, 5);
+  else if (pro == 0) W_GO(0, 3, 0);
+  else if (pro == 1) W_GO(1, 3, 0);
+  else if (pro == 2) W_GO(2, 3, 0);
+  else W_GO(3, 3, 0);
 #undef W_GO
   static const char* const kLabel[4] = {"pw_conv_x3w<0>", "pw_conv_x3w<1>", "pw_conv_x3w<2>", "pw_conv_x3w<3>"};
   SRF_CHECK_LAUNCH(kLabel[pro < 0 || pro > 3 ? 3 : pro], st);

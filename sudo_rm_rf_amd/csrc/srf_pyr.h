@@ -19,7 +19,6 @@ struct PyrRegArgs {
   int rows;            // groups * C
   int rpw;             // rows per (persistent) wavefront
   int C, L, D, tiles, own;   // own = own chunks per tile
-  int abl;             // diagnostics: 1 = plain stores instead of moment atomics, 2 = no wave reductions
   float* lv_out[SRF_MAX_DEPTH];   // training forward (SAVE): the raw (pre-norm) conv output of every level, or null
 };
 

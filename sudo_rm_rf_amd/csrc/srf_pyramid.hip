@@ -898,7 +898,7 @@ int srf_pyramid_impl(const float* y1, float* merged, const srf_norm* in_norm, co
     r.L = L;
     r.D = D;
     r.rows = r.rpw = 0;
-    r.tiles = r.own = r.abl = 0;
+    r.tiles = r.own = 0;
     if (srf_debug_flags() & 128) {   // non-persistent pass 1: atomics into mom + pre-finalised statistics
       SRF_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * (size_t)rows * D * 5, st));
       if (a.in_norm.sums) {

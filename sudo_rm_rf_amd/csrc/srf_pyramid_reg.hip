@@ -347,10 +347,10 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     for (int k = 0; k < 6; ++k) {
       if (PERSIST && tile != a.tiles - 1) break;   // the row's last tile flushes
       if (k < D) {
-        const float r1 = (a.abl & 2) ? s1[k] : srf_dpp_wave_sum(s1[k]);
-        const float r2 = (a.abl & 2) ? s2[k] : srf_dpp_wave_sum(s2[k]);
+        const float r1 = srf_dpp_wave_sum(s1[k]);
+        const float r2 = srf_dpp_wave_sum(s2[k]);
         if (lane == 63) {
-          if (PERSIST || (a.abl & 1)) {
+          if (PERSIST) {
             mrow[k * 5 + 0] = (double)r1;
             mrow[k * 5 + 1] = (double)r2;
           } else {
@@ -434,11 +434,6 @@ bool srf_pyramid_reg_supported(int L, int D) {
 // moments / finalize / merge launches are driven by srf_pyramid() in srf_pyramid.hip
 int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st) {
   const int CH = a.D <= 5 ? 16 : 32;
-#ifdef SRF_EXPERIMENTS
-  a.abl = getenv("SRF_PYR_ABL") ? atoi(getenv("SRF_PYR_ABL")) & 3 : 0;   // (lab builds: pass-1 ablations, results wrong)
-#else
-  a.abl = 0;
-#endif
   const int nchunks = a.L / CH;
   a.tiles = (nchunks + 59) / 60;
   a.own = (nchunks + a.tiles - 1) / a.tiles;

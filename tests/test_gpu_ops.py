@@ -453,6 +453,31 @@ def test_pw_conv_fp16_split_is_loud_beyond_its_range():
     assert float((exact.double() - want2).abs().max()) <= 1e-5 * float(want2.abs().max())
 
 
+def test_pw_conv_packed3_refuses_an_image_of_the_other_format():
+    """The packed3 image's format (two fp16 parts | three bf16 parts) is fixed when it is packed; a launch under the other
+    setting of debug flag 16384 must fail with an error instead of reinterpreting the bits."""
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+    Bt, Cin, Cout, L = 16, 256, 256, 3200
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(Bt, Cin, L, generator=g, device=DEV)
+    w = torch.randn(Cout, Cin, 1, generator=g, device=DEV) * Cin ** -0.5
+    bias = torch.zeros(Cout, device=DEV)
+    packed = ops.pack3_pw_weight(w)                       # fp16 parts
+    ref = ops.pw_conv3(x, w, bias, packed)
+    try:
+        ops.set_debug_flags(16384)
+        with pytest.raises(RuntimeError, match="packed as two fp16 parts"):
+            ops.pw_conv3(x, w, bias, packed)
+        packed3 = ops.pack3_pw_weight(w)                  # re-packed under the flag: served
+        again = ops.pw_conv3(x, w, bias, packed3)
+    finally:
+        ops.set_debug_flags(0)
+    assert float((again - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    with pytest.raises(RuntimeError, match="packed as three bf16 parts"):
+        ops.pw_conv3(x, w, bias, packed3)
+
+
 # (Bt, Cin, Cout, L, prologue, epilogue): the GEMMs of BASELINE cfg 4 / cfg 5 AT BENCH BATCH that no golden reaches
 # (VERDICT r2 weak 1): bottleneck K = 2048 / 4096 (64 / 128 k-tiles), proj_1x1 / res_conv at 512 -> 512 (two M tiles,
 # statistics epilogue / residual epilogue), cfg 5's mask GEMM (Cout = S N = 8192: 32 M tiles, ReLU x encoder epilogue)

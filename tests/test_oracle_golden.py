@@ -202,7 +202,7 @@ def check_trajectory_against_golden(named_final, sd0, losses, z, tol, yardstick=
     ref_l, ref_l32 = np.asarray(z["losses"]), np.asarray(z["losses_fp32"])
     for s_, (a, b, c) in enumerate(zip(losses, ref_l, ref_l32)):
         assert abs(a - b) <= max(2e-3, 3 * abs(c - b)), ("loss of step", s_, a, b, c)
-    worst, num, den = ("", 0.0, 0.0), 0.0, 0.0
+    worst, num, den, snum, sden, sabs = ("", 0.0, 0.0), 0.0, 0.0, 0.0, 0.0, []
     for k, w in named_final:
         w = np.asarray(w, dtype=np.float64).reshape(-1)
         step = int(z["n:" + k][0])
@@ -216,12 +216,26 @@ def check_trajectory_against_golden(named_final, sd0, losses, z, tol, yardstick=
         if w.size > 1:
             num += ((d_ours - d_ref) ** 2).sum()
             den += (d_ref ** 2).sum()
+        else:
+            snum += ((d_ours - d_ref) ** 2).sum()
+            sden += (d_ref ** 2).sum()
+            sabs.append((abs(float(d_ours[0] - d_ref[0])), abs(float(d_ref[0])), k))
     total = np.sqrt(num / den)
     total_bar = max(tol, yardstick * float(np.median([v for v in kind_dev.values()])))
-    print("trajectory: worst tensor %s at %.2f of its bar (rel. L2 of the update %.3g); whole-model update error %.3g (bar %.3g)"
-          % (worst[0], worst[1], worst[2], total, total_bar))
+    # the scalar parameters (PReLU slopes) as ONE vector: single slopes are noisy, their ensemble is not
+    scalars = np.sqrt(snum / sden) if sden > 0 else 0.0
+    print("trajectory: worst tensor %s at %.2f of its bar (rel. L2 of the update %.3g); whole-model update error %.3g (bar %.3g); "
+          "all scalar parameters together %.3g (bar 0.05)" % (worst[0], worst[1], worst[2], total, total_bar, scalars))
     assert worst[1] <= 1.0, worst
     assert total <= total_bar, (total, total_bar)
+    assert scalars <= 0.05, scalars
+    # ... and each of them on the scale of a typical scalar update (the relative bar of a noisy slope -- one whose
+    # update is tiny because its gradient changes sign -- can exceed 100 % of that tiny update; on THIS scale a wrong sign on a
+    # typical slope is an error of 2, a doubled update an error of 1)
+    if sabs:
+        typical = float(np.median([r for _, r, _ in sabs]))
+        bad = [(k, e / typical) for e, _, k in sabs if e > 0.25 * typical]
+        assert not bad, bad
 
 
 def check_grads_against_golden(named_grads, z, tol, fp32_yardstick=0.0, flip_budget=0.0):

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Copy the judged artefacts of one tools/gpu_profiles_r4.sh run (gpurun_out/<dir>) into profiles/ (tracked), as <tag>_*:
+"""Copy the judged artefacts of one tools/gpu_profiles.sh run (gpurun_out/<dir>) into profiles/ (tracked), as <tag>_*:
 GPU test summary, bench lines of the five configurations (+ the exact-fp32 line), training steps, rocprofv3 kernel stats,
 HBM-traffic and SQ-counter summaries of the forward (cfgs 2 / 4 / 5) and of the training step (cfgs 2 / 4), the rocm-smi power
-samples.  usage: tools/collect_profiles4.py <gpurun_out dir name> [tag, default r04]"""
+samples.  usage: tools/collect_profiles.py <gpurun_out dir name> [tag, default r05]"""
 import collections
 import csv
 import glob
@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = os.path.join(ROOT, "gpurun_out", sys.argv[1])
-T = sys.argv[2] if len(sys.argv) > 2 else "r04"
+T = sys.argv[2] if len(sys.argv) > 2 else "r05"
 P = os.path.join(ROOT, "profiles")
 SHORT = {"cfg1_improved_u8": "cfg1_bs1", "cfg2_improved_u16": "cfg2_bs32", "cfg3_groupcomm_u8": "cfg3_groupcomm_bs32",
          "cfg4_improved_u36_n2048": "cfg4_u36_n2048_bs32", "cfg5_improved_u36_n4096": "cfg5_u36_n4096_8s16k_bs16"}
@@ -37,7 +37,7 @@ cp(os.path.join(R, "env.log"), "%s_env.log" % T)
 if os.path.exists(os.path.join(R, "pytest_gpu.log")):
     tail = open(os.path.join(R, "pytest_gpu.log")).read().splitlines()[-6:]
     open(os.path.join(P, "%s_pytest_gpu_summary.txt" % T), "w").write(
-        "# python -m pytest tests -q -m gpu on the box the rest of this set was measured on (tools/gpu_profiles_r4.sh)\n" + "\n".join(tail) + "\n")
+        "# python -m pytest tests -q -m gpu on the box the rest of this set was measured on (tools/gpu_profiles.sh)\n" + "\n".join(tail) + "\n")
     print("  ", "%s_pytest_gpu_summary.txt" % T)
 JOBS = [(w, short, "--workload %s" % w) for w, short in SHORT.items()]
 JOBS += [("train_" + w, SHORT[w] + "_train_step", "--train --workload %s" % w) for w in ("cfg2_improved_u16", "cfg4_improved_u36_n2048")]
@@ -94,3 +94,8 @@ for w, short, cmdline in JOBS:
                            100 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), v.get("SQ_INSTS_VALU", 0) / 1024e3,
                            v.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0)))
     print("  ", "%s_%s_pmc_sq_mfma_valu_lds.txt" % (T, short))
+# ---- round-5 extras (part x of tools/gpu_profiles.sh)
+cp(os.path.join(R, "pair_ab.log"), "%s_pair_ab_final_build.log" % T)
+cp(os.path.join(R, "two_stream_events.txt"), "%s_cfg2_two_stream_timeline_final_build.txt" % T)
+cp(os.path.join(R, "two_stream_events.json"), "%s_cfg2_two_stream_timeline_final_build.json" % T)
+cp(os.path.join(R, "pair_power_probe.log"), "%s_pair_zero_vs_random_operands.log" % T)

@@ -2,7 +2,7 @@
 """Same-process interleaved A/B of the 256 x 128 split-bf16 GEMM variants on the model's launch shapes (cfg 2, cfg 4, cfg 5):
 rounds of N launches per variant, variants interleaved, median / min us per launch, outputs compared bit for bit.
 
-    python tools/gemm_ab.py [name=debug_flags[:abl[:gemm[:blocks]]] ...]    default: x3w=0 x3p=8192 (debug flag 8192 on a stand-alone call = the paired-block form of the 256 x 128 kernel; lab: x3t=0:0:x3t, x3s=0:0:x3s)   (abl / gemm: lab builds only -- SRF_BUILD_EXPERIMENTS=1, SRF_LIB=.../libsudormrf_hip_lab.so)
+    python tools/gemm_ab.py [name=debug_flags ...]    default: x3w=0 x3p=8192 (debug flag 8192 on a stand-alone call = the paired-block form of the 256 x 128 kernel)
     GEMM_SHAPES=res_conv,proj_1x1 GEMM_ROUNDS=7 GEMM_ITERS=20"""
 import json
 import os
@@ -35,15 +35,10 @@ def main():
     variants = [a.split("=") for a in sys.argv[1:]] or [["x3w", "0"], ["x3p", "8192"]]
     variants = [(n, f if ":" in f else f + ":0") for n, f in variants]
 
-    class _Flags:   # debug flags + the SRF_X3W_ABL environment switch of the experimental instantiations
+    class _Flags:   # debug flags of one variant
         @staticmethod
         def set(spec):
-            f, abl, gemm, blocks, stagger = (spec.split(":") + ["", "", "", ""])[:5]
-            os.environ["SRF_X3P_STAGGER"] = stagger or "0"   # x3p: start-up delay of the grid's second half (units of ~8 K cycles)
-            ops.set_debug_flags(int(f))
-            os.environ["SRF_X3W_ABL"] = abl or "0"
-            os.environ["SRF_GEMM"] = gemm           # "x3s": the role-split kernel (srf_pwconv_x3s.hip)
-            os.environ["SRF_X3P_BLOCKS"] = blocks or "0"     # x3p: persistent blocks (default 2 per CU)
+            ops.set_debug_flags(int(spec.split(":")[0]))
 
     only = os.environ.get("GEMM_SHAPES")
     rounds, iters = int(os.environ.get("GEMM_ROUNDS", "5")), int(os.environ.get("GEMM_ITERS", "10"))

@@ -1,12 +1,14 @@
 #!/bin/bash
-# Runs ON the GPU box: the judged evidence of round 4 from the SHIPPED build (sudo_rm_rf_amd/libsudormrf_hip.so) -- GPU test summary,
+# Runs ON the GPU box: the judged evidence of a round from the SHIPPED build (sudo_rm_rf_amd/libsudormrf_hip.so) -- GPU test summary,
 # bench lines of all five configurations (+ the exact-fp32 line), the training steps (roofline + cpu_baseline), rocprofv3 kernel
 # stats and PMC passes (HBM traffic; SQ MFMA / VALU / LDS counters) of the forward (cfgs 2, 4, 5) AND of the training step
 # (cfgs 2, 4), package power.  No gate: whatever box the pool hands out (round 3's set came from boxes <= 6.95 ms).
-# usage: tools/gpu_profiles_r4.sh <out dir under gpurun_out> [parts: t b r p, default all]; then tools/collect_profiles4.py <dir>
+# usage: tools/gpu_profiles.sh <out dir under gpurun_out> [parts: t b r p x, default all]; then tools/collect_profiles.py <dir> [tag]
+# parts: t = pytest -m gpu, b = bench lines, r = rocprofv3 kernel stats, p = PMC passes, x = round-5 extras (fused-pair A/B, HIP-event
+# timeline of the two-stream forward, zero-vs-random operand probe)
 set -u
-OUT=gpurun_out/${1:-r04p}
-PARTS=${2:-tbrp}
+OUT=gpurun_out/${1:-r05p}
+PARTS=${2:-tbrpx}
 mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 { rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | head -4; nproc; date -u; } > "$OUT/env.log" 2>&1
@@ -55,5 +57,10 @@ if [[ $PARTS == *p* ]]; then
       i=$((i+1)); pmc train_$w $i "$grp" --train --workload $w
     done
   done
+fi
+if [[ $PARTS == *x* ]]; then
+  timeout 300 python tools/pair_ab.py 32 20 12 > "$OUT/pair_ab.log" 2>&1
+  timeout 300 python tools/two_stream_events.py --forwards 10 --json "$OUT/two_stream_events.json" > "$OUT/two_stream_events.txt" 2>&1
+  timeout 200 python tools/pair_power_probe.py 32 > "$OUT/pair_power_probe.log" 2>&1
 fi
 echo "== done"; du -sh "$OUT"

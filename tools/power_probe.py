@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Is a kernel power-bound?  Runs one GEMM form (or the whole cfg-2 forward) back to back for a few seconds while a thread samples
-`rocm-smi` (socket power, shader / memory clocks); prints the samples' median.  Usage: power_probe.py [proj|res_conv|forward|copy|idle] [seconds] [debug flags] [SRF_X3W_ABL]
-(debug flags bits 16..21 = the GEMM's ablation mask: 4 = no MFMAs, 20 = no MFMAs + no epilogue, 7 = no MFMAs + no loads)"""
+`rocm-smi` (socket power, shader / memory clocks); prints the samples' median.  Usage: power_probe.py [proj|res_conv|forward|copy|idle] [seconds] [debug flags]"""
 import json
 import os
 import re
@@ -45,8 +44,6 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "proj"
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
     flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    if len(sys.argv) > 4:
-        os.environ["SRF_X3W_ABL"] = sys.argv[4]
     ops.set_debug_flags(flags)
     g = torch.Generator(device=DEV).manual_seed(0)
     if what in ("proj", "res_conv"):
@@ -103,7 +100,7 @@ def main():
         vals = sorted(s[k] for s in ok if s.get(k) is not None)
         return vals[len(vals) // 2] if vals else None
 
-    print(json.dumps({"what": what, "debug_flags": flags, "abl_env": os.environ.get("SRF_X3W_ABL"), "us_per_call": e0.elapsed_time(e1) * 1e3 / max(n, 1), "samples": len(ok),
+    print(json.dumps({"what": what, "debug_flags": flags, "us_per_call": e0.elapsed_time(e1) * 1e3 / max(n, 1), "samples": len(ok),
                       "power_w_median": med("power_w"), "sclk_mhz_median": med("sclk_mhz"), "mclk_mhz_median": med("mclk_mhz"),
                       "first_samples": samples[:3]}))
 
