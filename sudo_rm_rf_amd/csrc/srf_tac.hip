@@ -399,7 +399,6 @@ __device__ __forceinline__ void tac_c_to_b(const float (&c)[8], float (&v)[8]) {
 __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_per_row, int total_tiles) {
   constexpr int NN = 16, HH = 48, G = 16;
   __shared__ tac_f16x8 s_frag[24][64];     // A fragments {hi, lo}: Wm (2 M-blocks x 3 k-steps), Wo[:, H:] (3), Wo[:, :H] (3)
-  __shared__ __attribute__((aligned(16))) float s_strip[4][16 * 36];      // per wavefront: 16 rows x 32 columns (pitch 36) for the float4 <-> operand transposition
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform for the compiler: buffer descriptors in SGPRs)
   const int t = lane & 31, h = lane >> 5;
@@ -464,46 +463,21 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
   const bool valid = col < L;
   __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * G * NN * L, 0, G * NN * L * 4, 0x00020000);
   __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(a.q + (size_t)b * G * NN * L, 0, G * NN * L * 4, 0x00020000);
-  const int col4 = l0 + (lane & 7) * 4;                            // (L % 4 == 0: a float4 is in range as a whole)
-  const int x_vo = col4 < L ? ((lane >> 3) * L + col4) * 4 : 0x7ffffff0;     // (out of range: the load returns 0, the store is dropped)
-  const int q_vo = x_vo;
+  const int x_vo = valid ? (8 * h * L + col) * 4 : 0x7ffffff0;     // (out of range: the load returns 0, the store is dropped)
+  const int q_vo = valid ? (4 * h * L + col) * 4 : 0x7ffffff0;
 
-  // x_g's B fragment (rows 8 h + e of group g at this lane's column).  Round 5: the group's 16 x 32 tile comes as TWO 16-byte
-  // loads per lane (8 rows x 128 B each), requested one group ahead, and is transposed through a wave-private LDS strip --
-  // float4 rows in, B-operand columns out -- instead of eight dword loads; the outputs leave the same way (two 16-byte stores
-  // instead of eight dword stores).  A tile costs 96 vector-memory instructions instead of 384: on this chip a wavefront's
-  // vector-memory instructions, not their bytes, are what its MFMA stream waits for (profiles/r04_NOTES.md; the same change
-  // took srf_pwconv_x3f.hip's first GEMM from 12 to 6 per step) -- at 384 the kernel sat at 97 us for a 33-us HBM floor.
+  // x_g's B fragment: 8 dword loads (rows 8 h + e of group g at this lane's column), requested one group ahead
   struct XRaw {
-    float4 v[2];
+    float v[8];
   };
-  typedef unsigned tac_u32x4 __attribute__((ext_vector_type(4)));
   auto issue_x = [&](int g, XRaw& r) __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const tac_u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(xrs, x_vo, (g * NN + it * 8) * L * 4, 0);
-      r.v[it] = make_float4(__uint_as_float(q4[0]), __uint_as_float(q4[1]), __uint_as_float(q4[2]), __uint_as_float(q4[3]));
-    }
-  };
-  float* strip = s_strip[wave];
-  const int st_row = (lane >> 3) * 36 + (lane & 7) * 4;       // float4 side: row lane >> 3 (+ 8), 4 columns
-  const int st_col = 8 * h * 36 + t;                          // operand side: rows 8 h + e of column t
-  auto wave_sync = []() __attribute__((always_inline)) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  auto stage_x = [&](const XRaw& r, float (&v)[8]) __attribute__((always_inline)) {
-    *reinterpret_cast<float4*>(strip + st_row) = r.v[0];
-    *reinterpret_cast<float4*>(strip + st_row + 8 * 36) = r.v[1];
-    wave_sync();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = strip[st_col + e * 36];
-    wave_sync();
+    for (int e = 0; e < 8; ++e) r.v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, x_vo, (g * NN + e) * L * 4, 0));
   };
   // (no fp16 range guard -- round 5, ADVICE r4: beyond fp16's range the parts become inf / NaN and poison the output, as a
   // NaN input does; rounds 3-4 clamped to +-6e4, which turned NaN into -6e4 and overflow into a plausible wrong number.  The
   // residual stream of every model we have stays below 1e3; debug flag 1 << 22 selects the fp32 VALU kernels, which have fp32's range)
+  auto clamp8 = [&](float (&v)[8]) __attribute__((always_inline)) { (void)v; };
   // 2^4 PReLU(Wi x + bi) of group g in the C layout: zA rows 0..31, zB rows 32..47 (registers 0..7)
   auto z_of = [&](const tac_f16x8& xh, const tac_f16x8& xl, tac_f32x16& zA, tac_f32x16& zB) __attribute__((always_inline)) {
     zA = tac_mma3(wi_h[0], wi_l[0], xh, xl, bi16[0]);
@@ -535,9 +509,8 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
   auto sweep1 = [&](XRaw& cur, XRaw& nxt, int g) __attribute__((always_inline)) {
     issue_x(g + 1 < G ? g + 1 : 0, nxt);             // (the last one requests group 0 again: sweep 2 starts with it)
     tac_f16x8 xh, xl;
-    float xv[8];
-    stage_x(cur, xv);
-    tac_split8(xv, xh, xl);
+    clamp8(cur.v);
+    tac_split8(cur.v, xh, xl);
     tac_f32x16 zA, zB;
     z_of(xh, xl, zA, zB);
 #pragma unroll
@@ -586,9 +559,8 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
   auto sweep2 = [&](XRaw& cur, XRaw& nxt, int g) __attribute__((always_inline)) {
     if (g + 1 < G) issue_x(g + 1, nxt);
     tac_f16x8 xh, xl;
-    float xv[8];
-    stage_x(cur, xv);
-    tac_split8(xv, xh, xl);
+    clamp8(cur.v);
+    tac_split8(cur.v, xh, xl);
     tac_f32x16 zA, zB;
     z_of(xh, xl, zA, zB);
     tac_f16x8 fh[3], fl[3];
@@ -601,19 +573,11 @@ __global__ __launch_bounds__(256) void srf_tac_mfma_kernel(TacArgs a, int tiles_
 #pragma unroll
     for (int r = 0; r < 8; ++r) {                    // rows (r & 3) + 8 (r >> 2) + 4 h = 0 .. 15
       const float v = srf_prelu(o[r] * (1.f / (TAC_WS * TAC_WS)), ao);
-      strip[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + t] = v;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), qrs, q_vo, (g * NN + (r & 3) + 8 * (r >> 2)) * L * 4, 0);
       const float vz = valid ? v : 0.f;
       ss += vz;
       sq = fmaf(vz, vz, sq);
     }
-    wave_sync();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {                 // 8 rows x 128 B per store instruction
-      const float4 o4 = *reinterpret_cast<const float4*>(strip + st_row + it * 8 * 36);
-      const tac_u32x4 ov = {__float_as_uint(o4.x), __float_as_uint(o4.y), __float_as_uint(o4.z), __float_as_uint(o4.w)};
-      __builtin_amdgcn_raw_buffer_store_b128(ov, qrs, q_vo, (g * NN + it * 8) * L * 4, 0);
-    }
-    wave_sync();
     if (a.out_sums) {      // (64 fp32 partials of 8 values each, summed in fp32 like the VALU kernel's lane sums, then fp64 buckets)
       const float fs = srf_dpp_wave_sum(ss), fq = srf_dpp_wave_sum(sq);
       if (lane == 63) {
@@ -654,7 +618,7 @@ extern "C" int srf_tac(const float* x, float* q, const float* const* params, int
   hipStream_t st = (hipStream_t)stream;
   // debug flags 1 << 22 / 24 / 25 / 26, 1024: the VALU kernels (the MFMA form serves n = 16, G = 16; 1 << 22 = just not the MFMA form)
   if (srf_kernel_mode() != 1 && n == 16 && G == 16 && !(srf_debug_flags() & ((1 << 22) | (1 << 24) | (1 << 26) | 1024)) &&
-      (long)G * n * L * 4 < (1L << 31) && L % 4 == 0 && srf_aligned16(x) && srf_aligned16(q)) {      // (16-byte rows: float4 loads / stores)
+      (long)G * n * L * 4 < (1L << 31)) {
     const int tiles_per_row = (L + 31) / 32;
     const long total = (long)Bt * tiles_per_row;
     if (total < (1L << 30)) {
