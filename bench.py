@@ -327,7 +327,7 @@ def pmc_traffic(kernel_family, workload, train=False):
     WRITE_SIZE are collected in their own runs of this same command -- tools/gpu_profiles.sh, summarised by
     tools/collect_profiles.py -- and stored under profiles/; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     for gfx950)."""
-    short = {"cfg2_improved_u16": "cfg2_bs32", "cfg4_improved_u36_n2048": "cfg4_u36_n2048_bs32",
+    short = {"cfg2_improved_u16": "cfg2_bs32", "cfg3_groupcomm_u8": "cfg3_groupcomm_bs32", "cfg4_improved_u36_n2048": "cfg4_u36_n2048_bs32",
              "cfg5_improved_u36_n4096": "cfg5_u36_n4096_8s16k_bs16"}.get(workload)
     rel = None
     for tag in ("r05", "r04", "r03"):      # the newest committed counter pass of this workload
@@ -342,7 +342,8 @@ def pmc_traffic(kernel_family, workload, train=False):
            "pw_conv_mfma": "srf_pw_mfma_kernel",
            "pyramid_moments": "srf_pyramid_reg_kernel<true", "pyramid_merge": "srf_pyramid_reg_kernel<false",
            "dwconv5_bwd": "srf_dwconv5_bwd_row_kernel", "gln_bwd_apply": "srf_gln_bwd_apply", "gln_bwd_reduce": "srf_gln_bwd_reduce",
-           "pw_wgrad": "srf_pw_wgrad_kernel"}.get(kernel_family, kernel_family)
+           "pw_wgrad": "srf_pw_wgrad_kernel", "pw_wgrad_small": "srf_pw_wgrad_small_kernel", "pw_conv_small": "srf_pw_small_kernel",
+           "tac_mfma": "srf_tac_mfma_kernel", "tac_bwd_mfma": "srf_tac_bwd_mfma_kernel"}.get(kernel_family, kernel_family)
     must = ""
     if kernel_family.startswith("pw_conv_x3w<"):
         must = ", 2>"                                        # (two-part operands: the last template argument)

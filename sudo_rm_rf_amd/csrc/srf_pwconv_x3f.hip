@@ -8,9 +8,10 @@
 // wavefronts need to issue their vector-memory instructions, and proj_1x1 re-read from HBM what res_conv had just written from
 // registers.  Here the k-loop of the second GEMM issues no activation load at all and the first GEMM's needs no LDS round trip:
 //   * a wavefront owns ALL 256 output rows of conv 1 for 32 time steps (8 accumulator tiles of 32 x 32, 128 registers).  Its B
-//     operand (the activations of its own 32 columns) is loaded straight into the MFMA B layout -- lane (n, h) holds
-//     k = 16 kt + 8 h + 0..7 of column n, eight dword loads of 2 x 128 B -- normalised / activated / split into bf16 hi | lo in
-//     registers: no ds_write, no B image, no barrier on the activation path;
+//     operand (the activations of its own 32 columns, 16 k rows per step) arrives as TWO 16-byte loads per lane and step, four
+//     steps ahead, is transposed through the wavefront's private LDS strip into the MFMA B layout -- lane (n, h) holds
+//     k = 16 kt + 8 h + 0..7 of column n -- and normalised / activated / split into bf16 hi | lo in registers, one step ahead
+//     of its use: no shared B image, no block barrier on the activation path;
 //   * after bias (+ residual) the 256 x 32 result is stored (float4 rows through a wave-private LDS strip, as srf_pwconv_x3p.hip)
 //     and read back from the strip in B-operand order, split once into bf16 hi | lo: 16 k-blocks x (4 + 4) registers = the COMPLETE
 //     K = 256 operand of conv 2 for these 32 columns, in registers;
@@ -20,8 +21,7 @@
 // stages; a stage is 256 "virtual rows" of 64 B: conv 1: the 256 output rows of one 16-k step; conv 2: two 16-k steps x 128
 // output rows (two contiguous 8-KB halves of two images).  Every step of either phase is therefore the same: one 16-KB
 // DMA (four 1-KB pieces per wavefront, two steps ahead), 16 conflict-free ds_read_b128 fragments, 24 MFMAs per wavefront, one
-// barrier.  Blocks are 4 wavefronts / 68 KB of LDS / <= 256 registers: two per CU, which run out of phase (one in its
-// load-heavy phase while the other multiplies from registers).
+// barrier.  Blocks are 4 wavefronts / 75 KB of LDS / <= 256 registers: two per CU.
 // Arithmetic and order per accumulator are those of srf_pwconv_x3p.hip / _x3w.hip (per 16 k: lo*hi, hi*lo, hi*hi; bias, then
 // residual; the split of y is the split proj_1x1's prologue would make): y AND y2 are BIT-IDENTICAL to the two separate launches;
 // the statistics (fp64 buckets of fp32 partial sums) agree to rounding.

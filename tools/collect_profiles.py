@@ -40,7 +40,7 @@ if os.path.exists(os.path.join(R, "pytest_gpu.log")):
         "# python -m pytest tests -q -m gpu on the box the rest of this set was measured on (tools/gpu_profiles.sh)\n" + "\n".join(tail) + "\n")
     print("  ", "%s_pytest_gpu_summary.txt" % T)
 JOBS = [(w, short, "--workload %s" % w) for w, short in SHORT.items()]
-JOBS += [("train_" + w, SHORT[w] + "_train_step", "--train --workload %s" % w) for w in ("cfg2_improved_u16", "cfg4_improved_u36_n2048")]
+JOBS += [("train_" + w, SHORT[w] + "_train_step", "--train --workload %s" % w) for w in ("cfg2_improved_u16", "cfg3_groupcomm_u8", "cfg4_improved_u36_n2048")]
 for w, short, cmdline in JOBS:
     stats = glob.glob(os.path.join(R, "prof_%s" % w, "**", "*kernel_stats.csv"), recursive=True)
     dur = {}

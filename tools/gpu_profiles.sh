@@ -3,7 +3,7 @@
 # bench lines of all five configurations (+ the exact-fp32 line), the training steps (roofline + cpu_baseline), rocprofv3 kernel
 # stats and PMC passes (HBM traffic; SQ MFMA / VALU / LDS counters) of the forward (cfgs 2, 4, 5) AND of the training step
 # (cfgs 2, 4), package power.  No gate: whatever box the pool hands out (round 3's set came from boxes <= 6.95 ms).
-# usage: tools/gpu_profiles.sh <out dir under gpurun_out> [parts: t b r p x, default all]; then tools/collect_profiles.py <dir> [tag]
+# usage: tools/gpu_profiles.sh <out dir under gpurun_out> [parts: t b r p x (c = completion pass, after a first collect), default tbrpx]; then tools/collect_profiles.py <dir> [tag]
 # parts: t = pytest -m gpu, b = bench lines, r = rocprofv3 kernel stats, p = PMC passes, x = round-5 extras (fused-pair A/B, HIP-event
 # timeline of the two-stream forward, zero-vs-random operand probe)
 set -u
@@ -62,5 +62,18 @@ if [[ $PARTS == *x* ]]; then
   timeout 300 python tools/pair_ab.py 32 20 12 > "$OUT/pair_ab.log" 2>&1
   timeout 300 python tools/two_stream_events.py --forwards 10 --json "$OUT/two_stream_events.json" > "$OUT/two_stream_events.txt" 2>&1
   timeout 200 python tools/pair_power_probe.py 32 > "$OUT/pair_power_probe.log" 2>&1
+fi
+if [[ $PARTS == *c* ]]; then   # completion pass: cfg-3 counters (forward + training step), cfg-4 training step WITH its CPU baseline, and the
+  # cfg-2 lines again now that profiles/ holds this round's PMC traffic (bench.py reads it from there)
+  for w in cfg3_groupcomm_u8; do
+    prof train_$w --train --workload $w
+    i=0
+    for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES,SQ_INSTS_VALU,SQ_WAIT_INST_LDS,SQ_BUSY_CYCLES,SQ_INSTS_MFMA"; do
+      i=$((i+1)); pmc $w $i "$grp" --workload $w; pmc train_$w $i "$grp" --train --workload $w
+    done
+  done
+  timeout 900 python bench.py --train --workload cfg4_improved_u36_n2048 --steps 5 --warmup 2 > "$OUT/train_cfg4_improved_u36_n2048.json" 2> "$OUT/train_cfg4.err"
+  timeout 900 python bench.py --steps 50 --warmup 10 > "$OUT/bench_cfg2_improved_u16.json" 2> "$OUT/bench_cfg2.err"
+  timeout 900 python bench.py --train --steps 10 --warmup 3 > "$OUT/train_cfg2_improved_u16.json" 2> "$OUT/train_cfg2.err"
 fi
 echo "== done"; du -sh "$OUT"
