@@ -456,6 +456,7 @@ def train_loop(step, flat_grad, steps, warmup, rank, world, dev):
     t0 = time.perf_counter()
     for _ in range(steps):
         l = step()
+    issued = time.perf_counter() - t0          # host time to ISSUE the steps: far below the step time = the GPU never waits for the host
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     mine = time.perf_counter() - t0
@@ -464,7 +465,7 @@ def train_loop(step, flat_grad, steps, warmup, rank, world, dev):
     flat = flat_grad()
     ar = D.time_allreduce(flat, repeats=10, device=dev) if flat is not None else None
     return {"seconds": dt, "ms_per_step": 1e3 * dt / steps, "per_rank_ms_per_step": per_rank, "loss": float(l.detach()),
-            "allreduce": ar}
+            "allreduce": ar, "host_issue_ms_per_step": 1e3 * issued / steps}
 
 
 def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
@@ -548,8 +549,14 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
                     kk["algorithmic_GBps"] = fam[k][0] / (ms_tot / psteps * 1e-3) / 1e9
                     kk["TFLOPs"] = fam[k][1] / (ms_tot / psteps * 1e-3) / 1e12
                     kk["algorithmic_bytes_per_launch"] = fam[k][0] / (n / psteps)
+                if k in ("pack_pw_weights_f16", "pack_pw_weights3", "pack_pw_weights", "grad_sqnorm", "pit_sisdr_stats", "zero_fill"):
+                    # an interval runs from the previous launch's completion: the first launch behind a host-side section
+                    # (step start, loss, optimizer) carries that section's host time in this INSTRUMENTED pass (events
+                    # serialise host and device; rocprofv3: pack 15-17 us, grad_sqnorm 13 us); the timed region does not wait
+                    # for the host -- see host_issue_ms_per_step
+                    kk["includes_host_gap"] = True
                 kernels[k] = kk
-            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+            dom = max((k for k in kernels if not kernels[k].get("includes_host_gap")), key=lambda k: kernels[k]["ms_per_step"])
             kd = kernels[dom]
             rl = {"kernel": dom, "avg_launch_us": kd["avg_launch_us"], "launches_per_step": kd["launches_per_step"],
                   "share_of_step": kd["ms_per_step"] / sum(v["ms_per_step"] for v in kernels.values()), "traffic": None}
@@ -593,7 +600,8 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
             "per_rank_ms_per_step": r["per_rank_ms_per_step"],
             # the step's one collective, timed on its own after the timed region (bus_GBps = 2 (N-1)/N bytes / time)
             "gradient_allreduce": dict(r["allreduce"] or {}, in_place_on_backward_buffer=bool(in_place) and all(in_place)),
-            "loss": r["loss"], "saved_activations_GB": saved / 2 ** 30, "scratch_GB": scratch / 2 ** 30,
+            "loss": r["loss"], "host_issue_ms_per_step": r.get("host_issue_ms_per_step"),
+            "saved_activations_GB": saved / 2 ** 30, "scratch_GB": scratch / 2 ** 30,
             "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30, **extra}))
 
 
