@@ -622,6 +622,7 @@ def timed_forwards(run, n_steps, dev, barrier):
         else:
             stamps.append(time.perf_counter())
         o = run()
+    timed_forwards.host_issue_s = time.perf_counter() - t0      # host time to ISSUE the steps (far below the wall time = the GPU never waits for the host)
     if cuda:
         evs[n_steps].record()
         torch.cuda.synchronize(dev)
@@ -662,7 +663,8 @@ def forward_result(args, variant, kw, T, fs, batch, n_gpus, dt, per_rank_ms, per
         "self_check": self_check,
         "step_ms": {"median": per_step_ms[len(per_step_ms) // 2], "p10": per_step_ms[int(0.1 * (len(per_step_ms) - 1))],
                     "p90": per_step_ms[int(round(0.9 * (len(per_step_ms) - 1)))], "min": per_step_ms[0],
-                    "max": per_step_ms[-1], "note": "rank 0, HIP events at the step boundaries on the launch stream"},
+                    "max": per_step_ms[-1], "note": "rank 0, HIP events at the step boundaries on the launch stream",
+                    "host_issue_ms_per_step": 1e3 * getattr(timed_forwards, "host_issue_s", 0.0) / args.steps},
         "ranks": {"world_size": n_gpus, "ms_per_step_by_rank": per_rank_ms, "backend": backend,
                   "rccl_version": rccl_version, "device": device_name},
         "forward_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void srf_gln_bwd_reduce_kernel(GlnBwdArgs a) {
 // ---- deferred parameter-gradient reductions (round 3) --------------------------------------------------------------------
 // Every GlobLN / depthwise-conv backward ends with a tiny kernel that folds its per-row partials into the parameter gradients:
 // ~190 launches of ~5 us per cfg-2 training step, each in the dependent chain of the stream.  When the caller gives every call
-// its OWN scratch slice (srf_backward does, for the blocks' norms and convs: SrfDeferScope), the partials stay valid, the call
-// only records a descriptor, and srf_defer_flush() folds them all in a handful of batched launches at the end of the backward.
+// its OWN scratch slice (srf_backward does, for the blocks' norms and convs), the partials stay valid, the call
+// only records a descriptor, and srf_bwd_ctx_flush() folds them all in a handful of batched launches at the end of the backward.
 struct GlnParamsDesc {
   const float* rowpart;
   float *dgamma, *dbeta, *dslope;
@@ -120,19 +120,20 @@ struct GlnParamsTable {
 struct DwParamsTable {
   DwParamsDesc d[SRF_PB_MAX];
 };
-struct SrfDeferCtx {
-  bool on = false;
+// What one srf_backward call carries across its kernel-level calls: the deferred reductions above, and the one-shot request
+// "fold the merge backward into the NEXT GlobLN backward's apply pass".  An explicit object owned by the caller (rounds 3-4
+// kept it in thread_local variables); the public per-kernel entry points pass none.
+struct SrfBwdCtx {
+  bool defer = false;
   std::vector<GlnParamsDesc> gln;
   std::vector<DwParamsDesc> dw;
+  float* merge_lv[SRF_MAX_DEPTH] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int merge_D = 0;
+  bool merge_taken = false;
 };
-static thread_local SrfDeferCtx g_defer;
-void srf_defer_set(bool on) { g_defer.on = on; }
-void srf_defer_clear() {   // (a backward that failed half-way must not leave its records to the next one)
-  g_defer.on = false;
-  g_defer.gln.clear();
-  g_defer.dw.clear();
-}
-bool srf_defer_on() { return g_defer.on; }
+SrfBwdCtx* srf_bwd_ctx_new() { return new SrfBwdCtx; }
+void srf_bwd_ctx_free(SrfBwdCtx* c) { delete c; }
+void srf_bwd_ctx_defer(SrfBwdCtx* c, bool on) { c->defer = on; }
 
 __device__ __forceinline__ void srf_gln_bwd_params_body(const float* __restrict__ rowpart, int groups, int C, float* dgamma,
                                                         float* dbeta, float* dslope) {
@@ -390,26 +391,22 @@ extern "C" size_t srf_gln_bwd_scratch_bytes(int groups, int C) {
 // mode bit 0 (pre-reduced): `scratch` already holds this norm's row partials and S1/S2 buckets (written by the fused
 // srf_dwconv5_bwd_impl for exactly this gout/x pair) -- no reduce pass.  mode bit 1: no apply pass (the consumer,
 // srf_dwconv5_bwd_impl in apply-on-load form, evaluates it from `scratch`; gx may be NULL).
-// One-shot request by the NEXT srf_gln_bwd_impl call on this thread: fold the merge backward (srf_merge_bwd on its output gx)
-// into its apply pass.  srf_gln_bwd_merge_taken() tells afterwards whether that happened (vectorised apply kernel, aligned
-// level buffers); if not, the caller runs srf_merge_bwd itself.
-static thread_local struct {
-  float* lv[SRF_MAX_DEPTH];
-  int D;
-  bool taken;
-} g_merge_sink = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 0, false};
-void srf_gln_bwd_merge_sink(float* const* levels, int D) {
-  g_merge_sink.D = (levels && D > 1 && D <= SRF_MAX_DEPTH) ? D : 0;
-  g_merge_sink.taken = false;
-  for (int k = 0; k < SRF_MAX_DEPTH; ++k) g_merge_sink.lv[k] = (k >= 1 && k < g_merge_sink.D) ? levels[k] : nullptr;
+// One-shot request to the NEXT srf_gln_bwd_impl call that gets this context: fold the merge backward (srf_merge_bwd on its
+// output gx) into its apply pass.  srf_bwd_ctx_merge_taken() tells afterwards whether that happened (vectorised apply kernel,
+// aligned level buffers); if not, the caller runs srf_merge_bwd itself.
+void srf_bwd_ctx_merge_sink(SrfBwdCtx* c, float* const* levels, int D) {
+  c->merge_D = (levels && D > 1 && D <= SRF_MAX_DEPTH) ? D : 0;
+  c->merge_taken = false;
+  for (int k = 0; k < SRF_MAX_DEPTH; ++k) c->merge_lv[k] = (k >= 1 && k < c->merge_D) ? levels[k] : nullptr;
 }
-bool srf_gln_bwd_merge_taken() { return g_merge_sink.taken; }
+bool srf_bwd_ctx_merge_taken(const SrfBwdCtx* c) { return c->merge_taken; }
 
 int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
                      int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch,
-                     int mode, void* stream) {
-  const int sink_D = g_merge_sink.D;      // (consumed by this call, whatever happens)
-  g_merge_sink.D = 0;
+                     int mode, void* stream, SrfBwdCtx* ctx) {
+  const int sink_D = ctx ? ctx->merge_D : 0;      // (consumed by this call, whatever happens)
+  if (ctx) ctx->merge_D = 0;
+  const bool defer = ctx && ctx->defer;
   const int pre_reduced = mode & 1, no_apply = (mode >> 1) & 1;
   SRF_CHECK_ARG(gout && x && norm && norm->sums && norm->gamma && norm->beta && (gx || no_apply) && scratch,
                 "srf_gln_bwd: null pointer");
@@ -431,7 +428,7 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
   a.L = L;
   a.accumulate = accumulate_gx;
   // (deferred mode: the caller's scratch slices are zeroed once per backward)
-  if (!pre_reduced && !g_defer.on) SRF_CHECK_HIP(hipMemsetAsync(a.bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
+  if (!pre_reduced && !defer) SRF_CHECK_HIP(hipMemsetAsync(a.bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
   const bool v4 = (L % 4) == 0 && srf_aligned16(gout) && srf_aligned16(x) && (!gx || srf_aligned16(gx)) &&
                   (!gout2 || srf_aligned16(gout2)) && srf_kernel_mode() != 1 && !(srf_debug_flags() & (1 << 30));
   const dim3 grid4((unsigned)((rows + 3) / 4));
@@ -443,8 +440,8 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
     SRF_CHECK_LAUNCH("gln_bwd_reduce", st);
   }
   if (dgamma || dbeta || (dslope && norm->prelu)) {
-    if (g_defer.on) {
-      g_defer.gln.push_back(GlnParamsDesc{a.rowpart, dgamma, dbeta, norm->prelu ? dslope : nullptr, groups, C});
+    if (defer) {
+      ctx->gln.push_back(GlnParamsDesc{a.rowpart, dgamma, dbeta, norm->prelu ? dslope : nullptr, groups, C});
     } else {
       hipLaunchKernelGGL(srf_gln_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
                          dim3(256), 0, st, a.rowpart, groups, C, dgamma, dbeta, norm->prelu ? dslope : nullptr);
@@ -454,11 +451,11 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
   if (no_apply) return SRF_OK;
   if (v4 && sink_D > 1 && (L % (1 << (sink_D - 1))) == 0 && !accumulate_gx) {
     bool ok = true;
-    for (int k = 1; k < sink_D; ++k) ok = ok && g_merge_sink.lv[k] && srf_aligned16(g_merge_sink.lv[k]);
+    for (int k = 1; k < sink_D; ++k) ok = ok && ctx->merge_lv[k] && srf_aligned16(ctx->merge_lv[k]);
     if (ok) {
       a.mD = sink_D;
-      for (int k = 1; k < sink_D; ++k) a.mlv[k] = g_merge_sink.lv[k];
-      g_merge_sink.taken = true;
+      for (int k = 1; k < sink_D; ++k) a.mlv[k] = ctx->merge_lv[k];
+      ctx->merge_taken = true;
     }
   }
   if (v4)
@@ -472,7 +469,8 @@ int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, cons
 extern "C" int srf_gln_bwd(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
                            int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope,
                            void* scratch, void* stream) {
-  return srf_gln_bwd_impl(gout, gout2, x, norm, groups, C, L, gx, accumulate_gx, dgamma, dbeta, dslope, scratch, 0, stream);
+  return srf_gln_bwd_impl(gout, gout2, x, norm, groups, C, L, gx, accumulate_gx, dgamma, dbeta, dslope, scratch, 0, stream,
+                          nullptr);
 }
 
 // =============================================================================================
@@ -1102,13 +1100,13 @@ __global__ __launch_bounds__(256) void srf_dwconv5_bwd_params_batch_kernel(DwPar
 }
 
 // Fold every recorded partial into its parameter gradients (batched launches of up to SRF_PB_MAX reductions) and clear the list.
-int srf_defer_flush(hipStream_t st) {
-  for (size_t base = 0; base < g_defer.gln.size(); base += SRF_PB_MAX) {
+int srf_bwd_ctx_flush(SrfBwdCtx* c, hipStream_t st) {
+  for (size_t base = 0; base < c->gln.size(); base += SRF_PB_MAX) {
     GlnParamsTable t;
-    const int cnt = (int)std::min<size_t>(SRF_PB_MAX, g_defer.gln.size() - base);
+    const int cnt = (int)std::min<size_t>(SRF_PB_MAX, c->gln.size() - base);
     int maxC = 0, maxG = 0;
     for (int i = 0; i < SRF_PB_MAX; ++i) {
-      t.d[i] = g_defer.gln[base + (i < cnt ? i : 0)];
+      t.d[i] = c->gln[base + (i < cnt ? i : 0)];
       if (i < cnt) {
         maxC = std::max(maxC, t.d[i].C);
         maxG = std::max(maxG, t.d[i].groups);
@@ -1118,13 +1116,13 @@ int srf_defer_flush(hipStream_t st) {
                        dim3(256), 0, st, t);
     SRF_CHECK_LAUNCH("gln_bwd_params", st);
   }
-  g_defer.gln.clear();
-  for (size_t base = 0; base < g_defer.dw.size(); base += SRF_PB_MAX) {
+  c->gln.clear();
+  for (size_t base = 0; base < c->dw.size(); base += SRF_PB_MAX) {
     DwParamsTable t;
-    const int cnt = (int)std::min<size_t>(SRF_PB_MAX, g_defer.dw.size() - base);
+    const int cnt = (int)std::min<size_t>(SRF_PB_MAX, c->dw.size() - base);
     int maxC = 0, maxG = 0;
     for (int i = 0; i < SRF_PB_MAX; ++i) {
-      t.d[i] = g_defer.dw[base + (i < cnt ? i : 0)];
+      t.d[i] = c->dw[base + (i < cnt ? i : 0)];
       if (i < cnt) {
         maxC = std::max(maxC, t.d[i].C);
         maxG = std::max(maxG, t.d[i].groups);
@@ -1134,7 +1132,7 @@ int srf_defer_flush(hipStream_t st) {
                        dim3(256), 0, st, t);
     SRF_CHECK_LAUNCH("dwconv5_bwd_params", st);
   }
-  g_defer.dw.clear();
+  c->dw.clear();
   return SRF_OK;
 }
 
@@ -1163,8 +1161,9 @@ bool srf_dwconv5_bwd_rowwise_ok(int Lin, int stride, const void* const* ptrs, in
 int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups, int C,
                          int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch, const float* gadd,
                          void* gln_scratch, int* fused, const float* ax, const srf_norm* anorm, const void* a_scratch,
-                         void* stream) {
+                         void* stream, SrfBwdCtx* ctx) {
   if (fused) *fused = 0;
+  const bool defer = ctx && ctx->defer;
   SRF_CHECK_ARG(gd && xin && w && scratch, "srf_dwconv5_bwd: null pointer");
   SRF_CHECK_ARG(groups > 0 && C > 0 && Lin > 0 && (stride == 1 || stride == 2), "srf_dwconv5_bwd: bad sizes");
   const long rows = (long)groups * C;
@@ -1206,7 +1205,7 @@ int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_n
       a.gadd = gadd;
       a.nrm_bsums = reinterpret_cast<double*>(gln_scratch);
       a.nrm_rowpart = reinterpret_cast<float*>(a.nrm_bsums + (size_t)groups * SRF_STAT_BUCKETS * 2);
-      if (!g_defer.on) SRF_CHECK_HIP(hipMemsetAsync(a.nrm_bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
+      if (!defer) SRF_CHECK_HIP(hipMemsetAsync(a.nrm_bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
       if (ax) {
         a.ax = ax;
         a.anrm = srf_norm_dev(anorm);
@@ -1243,8 +1242,8 @@ int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_n
   SRF_CHECK_LAUNCH("dwconv5_bwd", st);
   }
   if (dw || dbias) {
-    if (g_defer.on) {
-      g_defer.dw.push_back(DwParamsDesc{a.rowpart, dw, dbias, groups, C});
+    if (defer) {
+      ctx->dw.push_back(DwParamsDesc{a.rowpart, dw, dbias, groups, C});
     } else {
       hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)),
                          dim3(256), 0, st, a.rowpart, groups, C, dw, dbias);
@@ -1258,7 +1257,7 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
                                int C, int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch,
                                void* stream) {
   return srf_dwconv5_bwd_impl(gd, xin, in_norm, w, groups, C, Lin, stride, gin, dw, dbias, scratch, nullptr, nullptr,
-                              nullptr, nullptr, nullptr, nullptr, stream);
+                              nullptr, nullptr, nullptr, nullptr, stream, nullptr);
 }
 
 // =============================================================================================

@@ -18,19 +18,23 @@
 
 int srf_transpose_launch(const float* w, float* wt, int Ci, int M, hipStream_t st);
 int srf_accumulate_launch(float* dst, const float* src, long n, hipStream_t st);
+// srf_backward.hip: what one srf_backward call carries across its kernel-level calls -- the deferred parameter-gradient
+// reductions and the "merge backward rides on the next GlobLN apply" request (an explicit object; NULL = neither)
+struct SrfBwdCtx;
+SrfBwdCtx* srf_bwd_ctx_new();
+void srf_bwd_ctx_free(SrfBwdCtx* c);
+void srf_bwd_ctx_defer(SrfBwdCtx* c, bool on);
+void srf_bwd_ctx_merge_sink(SrfBwdCtx* c, float* const* levels, int D);
+bool srf_bwd_ctx_merge_taken(const SrfBwdCtx* c);
+int srf_bwd_ctx_flush(SrfBwdCtx* c, hipStream_t st);
 int srf_gln_bwd_impl(const float* gout, const float* gout2, const float* x, const srf_norm* norm, int groups, int C,
                      int L, float* gx, int accumulate_gx, float* dgamma, float* dbeta, float* dslope, void* scratch,
-                     int mode, void* stream);
+                     int mode, void* stream, SrfBwdCtx* ctx);
 bool srf_dwconv5_bwd_rowwise_ok(int Lin, int stride, const void* const* ptrs, int nptrs);
 bool srf_pyramid_reg_supported(int L, int D);
 int srf_pack_pw_weights_transposed(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n,
                                    hipStream_t st);   // srf_pwconv.hip
 bool srf_pw_packed_only(const void* w_packed, const float* x, int Bt, int Cin, int Cout, int L);   // srf_pwconv.hip
-void srf_gln_bwd_merge_sink(float* const* levels, int D);   // srf_backward.hip: merge backward folded into the next gln apply
-bool srf_gln_bwd_merge_taken();
-void srf_defer_set(bool on);          // srf_backward.hip: deferred parameter-gradient reductions
-void srf_defer_clear();
-int srf_defer_flush(hipStream_t st);
 extern "C" size_t srf_packed3_pw_weight_bytes(int Cout, int Cin);
 extern "C" int srf_pack3_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n, void* stream);
 extern "C" int srf_pw_conv_packed3(const float* x, const float* w, const void* w_packed3, const float* bias, float* y, int Bt,
@@ -46,7 +50,7 @@ int srf_pyramid_impl(const float* y1, float* merged, const srf_norm* in_norm, co
 int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_norm, const float* w, int groups, int C,
                          int Lin, int stride, float* gin, float* dw, float* dbias, void* scratch, const float* gadd,
                          void* gln_scratch, int* fused, const float* ax, const srf_norm* anorm, const void* a_scratch,
-                         void* stream);
+                         void* stream, SrfBwdCtx* ctx);
 
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -421,10 +425,11 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
   // -- the chunked fallback kernels (debug flags 1<<29 / 1<<30, rows beyond the row kernels' limits) accumulate
   // their row partials with atomicAdd and rely on zeroed slices)
   SRF_CHECK_HIP(hipMemsetAsync(sc + s.arena, 0, s.arena_bytes, st));
-  srf_defer_clear();
-  struct DeferOff {
-    ~DeferOff() { srf_defer_set(false); }
-  } defer_off_on_exit;
+  struct BwdCtxOwner {          // (freed on every exit path: a backward that fails half-way leaves nothing behind)
+    SrfBwdCtx* c = srf_bwd_ctx_new();
+    ~BwdCtxOwner() { srf_bwd_ctx_free(c); }
+  } ctx_owner;
+  SrfBwdCtx* ctx = ctx_owner.c;
 
   const int pt = p->p_tail;
   // The data-gradient GEMMs g_x = W^T g run on the 256 x 128 split-bf16 kernel with the TRANSPOSED weights pre-split into its
@@ -517,14 +522,14 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     if (rc) return rc;
     char* gln_sl = sc + s.arena + (size_t)i * ((size_t)(D + 2) * s.gln_slice + (size_t)D * s.dw_slice);   // D + 2 norm slices,
     char* dw_sl = gln_sl + (size_t)(D + 2) * s.gln_slice;                                                 // then D conv slices
-    srf_defer_set(true);
+    srf_bwd_ctx_defer(ctx, true);
     float* gn[SRF_MAX_DEPTH];
     gn[0] = gf;
     for (int k = 1; k < D; ++k) gn[k] = fp(s.gn[k]);
-    srf_gln_bwd_merge_sink(gn, D);       // the merge backward rides on the norm's apply pass (the levels' pair sums of its output)
-    rc = srf_gln_bwd(gf, nullptr, merged, &fn, Bg, nC, L, gf, 0, Gu[pf], Gu[pf + 1], Gu[pf + 2], gln_sl, stream);
+    srf_bwd_ctx_merge_sink(ctx, gn, D);  // the merge backward rides on the norm's apply pass (the levels' pair sums of its output)
+    rc = srf_gln_bwd_impl(gf, nullptr, merged, &fn, Bg, nC, L, gf, 0, Gu[pf], Gu[pf + 1], Gu[pf + 2], gln_sl, 0, stream, ctx);
     if (rc) return rc;                                       // gf now holds g_merged = g_n_0 (merge part)
-    if (!srf_gln_bwd_merge_taken()) {
+    if (!srf_bwd_ctx_merge_taken(ctx)) {
       rc = srf_merge_bwd(gf, gn, D, (long)Bg * nC, L, stream);
       if (rc) return rc;
     }
@@ -575,19 +580,19 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
       char* cur_sl = gln_sl + (size_t)pp * s.gln_slice;
       char* next_sl = cur_sl + s.gln_slice;
       rc = srf_gln_bwd_impl(gout1, gout2, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, cur_sl,
-                            (pre_reduced ? 1 : 0) | (on_load ? 2 : 0), stream);
+                            (pre_reduced ? 1 : 0) | (on_load ? 2 : 0), stream, ctx);
       if (rc) return rc;
       rc = srf_dwconv5_bwd_impl(on_load ? gout1 : gd, src, &in, Pk[0], Bg, nC, Lin, stride, gin, Gk[0], Gk[1],
                                 dw_sl + (size_t)k * s.dw_slice, gadd, next_sl, &pre_reduced, on_load ? dk : nullptr,
-                                on_load ? &nk : nullptr, on_load ? cur_sl : nullptr, stream);
+                                on_load ? &nk : nullptr, on_load ? cur_sl : nullptr, stream, ctx);
       if (rc) return rc;
       pp += 1;
     }
     // proj_1x1: y1 = W_p xin + b_p, o = PReLU(GlobLN(y1))
     srf_norm pn{slot(s0), Pu[2], Pu[3], Pu[4]};
     rc = srf_gln_bwd_impl(g_o, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], gln_sl + (size_t)pp * s.gln_slice,
-                          pre_reduced, stream);   // go = g_y1
-    srf_defer_set(false);
+                          pre_reduced, stream, ctx);   // go = g_y1
+    srf_bwd_ctx_defer(ctx, false);
     if (rc) return rc;
     rc = srf_pw_wgrad(go, xin, nullptr, Bg, nB, nC, L, Gu[0], Gu[1], 1, wg, stream);
     if (rc) return rc;
@@ -630,7 +635,7 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     if (rc) return rc;
   }
   // ---- the blocks' deferred parameter-gradient reductions, batched
-  rc = srf_defer_flush(st);
+  rc = srf_bwd_ctx_flush(ctx, st);
   if (rc) return rc;
   // ---- encoder weight                                           :247-251,286
   rc = srf_frames_gather(wav, frames, Bt, p->A, p->T, K, h, h, L, p->A * K, stream);

@@ -279,6 +279,38 @@ def test_fused_clip_adam_matches_torch(clip):
             assert ((a - b).abs() <= 1e-7 + 1e-4 * a.abs()).all(), name
 
 
+def test_fused_clip_adam_follows_moving_gradient_buffers_without_a_host_sync():
+    """The HIP training step hands the optimizer a FRESH flat gradient buffer every step, so the device table of gradient
+    pointers changes per step.  It is re-sent through pinned staging with a non-blocking copy on the launch stream (round 5; a
+    pageable copy made step() wait for the backward): several steps issued back to back WITHOUT any host synchronisation, every
+    step's gradients at new addresses, must match torch's clip_grad_norm_ + Adam -- i.e. each step's kernels read THEIR table,
+    not a later step's."""
+    from sudo_rm_rf_amd import optim
+    g = torch.Generator().manual_seed(11)
+    shapes = [(256, 128, 1), (256,), (1,), (4097,), (5, 4096)]
+    pa = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    ref = torch.optim.Adam(pa, lr=1e-2)
+    fused = optim.FusedClipAdam(pb, lr=1e-2, clip_grad_norm=1.0)
+    steps = 6
+    grads = [[torch.randn(*s, generator=g).to(DEV) * (0.3 + it) for s in shapes] for it in range(steps)]
+    hold = []                                   # (every step's gradient tensors stay alive: no address is recycled)
+    torch.cuda.synchronize()
+    for it in range(steps):                     # fused: issued back to back, nothing in this loop waits for the device
+        for q, gr in zip(pb, grads[it]):
+            q.grad = gr.clone()
+            hold.append(q.grad)
+        fused.step()
+    for it in range(steps):
+        for p, gr in zip(pa, grads[it]):
+            p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(pa, 1.0)
+        ref.step()
+    torch.cuda.synchronize()
+    for p, q in zip(pa, pb):
+        assert (p - q).abs().max().item() <= 5e-6 * max(1.0, p.abs().max().item())
+
+
 def test_data_parallel_replicas_forward_and_train():
     """run_improved_sudormrf.py:118 wraps the model in torch.nn.DataParallel: replicas hold their weights as plain
     (non-Parameter) tensors behind a Broadcast node and are called from one thread each.  Two replicas on the one
