@@ -76,4 +76,9 @@ if [[ $PARTS == *c* ]]; then   # completion pass: cfg-3 counters (forward + trai
   timeout 900 python bench.py --steps 50 --warmup 10 > "$OUT/bench_cfg2_improved_u16.json" 2> "$OUT/bench_cfg2.err"
   timeout 900 python bench.py --train --steps 10 --warmup 3 > "$OUT/train_cfg2_improved_u16.json" 2> "$OUT/train_cfg2.err"
 fi
+if [[ $PARTS == *T* ]]; then   # the three training lines again (after a change to the training step)
+  timeout 900 python bench.py --train --steps 10 --warmup 3 > "$OUT/train_cfg2_improved_u16.json" 2> "$OUT/train_cfg2.err"
+  timeout 600 python bench.py --train --workload cfg3_groupcomm_u8 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/train_cfg3_groupcomm_u8.json" 2> "$OUT/train_cfg3.err"
+  timeout 900 python bench.py --train --workload cfg4_improved_u36_n2048 --steps 5 --warmup 2 > "$OUT/train_cfg4_improved_u36_n2048.json" 2> "$OUT/train_cfg4.err"
+fi
 echo "== done"; du -sh "$OUT"
