@@ -281,6 +281,48 @@ def test_variable_length_inference_keeps_plans_and_memory_bounded():
             assert torch.equal(model(wav), want)
 
 
+@pytest.mark.parametrize("T", [32079, 20010], ids=["ragged-3216", "ragged-2016"])
+def test_fused_pairs_equal_separate_launches_on_ragged_lengths(T):
+    """Whole-model check of the fused conv pairs (round 5) away from the bench shape: a B = 256 model at batch 32 and lengths
+    whose frame count is no multiple of the pair kernel's 128-column tile (partial last tiles; the reference's zero right-pad,
+    improved_sudormrf.py:303-314, as bounds checks) and that end up with different launch sizes (832 / 512 tiles on 512 block
+    slots).  A pair's two OUTPUT TENSORS are bit-identical to the two launches it replaces (test_gpu_ops.py); its GlobLN statistics
+    -- fp64 buckets of fp32 partial sums, grouped by a different tile shape -- agree to rounding, so the whole forward with and
+    without the pairs (debug flag 1) must agree to rounding (measured 4e-6 of the output scale after three blocks; bar 2e-5), single-stream and split; the profiler
+    proves the pairs were dispatched."""
+    from oracle import weights
+    from oracle.schema import ModelConfig
+    from sudo_rm_rf_amd import ops
+    cfg = ModelConfig("improved", 256, 512, 3, 5, 21, 512, 2)
+    model = build(cfg, weights.make_state_dict(cfg, seed=31))
+    eng = model._engine()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 1, T, generator=g).to(DEV)
+    try:
+        eng.multi_stream = False
+        with torch.no_grad(), ops.kernel_trace(DEV) as tr:
+            fused = model(x)
+        assert {"pw_pair_x3f<1>", "pw_pair_x3f<2>"} <= tr.names, tr.names
+        ops.set_debug_flags(1)
+        with torch.no_grad(), ops.kernel_trace(DEV) as tr0:
+            plain = model(x)
+        assert not any(n.startswith("pw_pair") for n in tr0.names), tr0.names
+        ops.set_debug_flags(0)
+        scale = float(plain.abs().max())
+        assert torch.isfinite(fused).all() and float((fused - plain).abs().max()) <= 2e-5 * scale, float((fused - plain).abs().max()) / scale
+        eng.multi_stream = True
+        out = torch.empty_like(fused)
+        with torch.no_grad():
+            params = [p.detach() for p in model.state_dict(keep_vars=True).values()]
+            for parts in eng._split_candidates(32)[1:]:
+                with torch.cuda.device(x.device), eng._run_lock(x.device):
+                    eng._forward_split(parts, x, out, eng._param_table(params, x.device))
+                assert float((out - plain).abs().max()) <= 2e-5 * scale, parts
+    finally:
+        ops.set_debug_flags(0)
+        eng.multi_stream = True
+
+
 def test_submodule_forwards(manifest):
     """UConvBlock / TAC / GlobLN called stand-alone (as pickled sub-modules may be) match the oracle."""
     cfg, sd, wav, _ = load_case(manifest, "tiny_groupcomm")
