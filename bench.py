@@ -541,7 +541,8 @@ def train_step_bench(args, cls, variant, kw, T, fs, batch, rank, world, dev):
                 e = per.setdefault(name.value.decode(), [0.0, 0])
                 e[0] += ms.value
                 e[1] += 1
-            fam = roofline.train_family_model(Bt=batch, **dims) or {}
+            fam = roofline.train_family_model(Bt=batch, dgrad_pairs=(None if not (args.debug_flags & (1 | 4 | 8)) and args.kernel_mode == 0 else False),
+                                              **dims) or {}
             kernels = {}
             for k, (ms_tot, n) in per.items():
                 kk = {"ms_per_step": ms_tot / psteps, "launches_per_step": n / psteps, "avg_launch_us": 1e3 * ms_tot / n}

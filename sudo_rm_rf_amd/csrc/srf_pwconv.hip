@@ -252,12 +252,13 @@ extern "C" int srf_pw_conv_pair_supported(int Bt, int Cin1, int Cmid, int Cout2,
   return (long)Bt * ((L + 127) / 128) >= srf_device_cus() ? 1 : 0;
 }
 // y = W1 f(x) + bias1 (+ residual), f = in_norm (GlobLN, or GlobLN + PReLU: then the residual is required -- the two forms the
-// model has); y2 = W2 y + bias2; out_sums2 (nullable) += {sum, sumsq} of y2.  w1_packed / w2_packed: srf_pack_pw_weights.
+// model has -- or NULL: no prologue, residual required -- the backward's data-gradient pair); y2 = W2 y + bias2; out_sums2
+// (nullable) += {sum, sumsq} of y2.  w1_packed / w2_packed: srf_pack_pw_weights.
 extern "C" int srf_pw_conv_pair(const float* x, const void* w1_packed, const float* bias1, float* y, const srf_norm* in_norm,
                                 const float* residual, const void* w2_packed, const float* bias2, float* y2, double* out_sums2,
                                 int Bt, int Cin1, int Cmid, int Cout2, int L, void* stream) {
-  SRF_CHECK_ARG(x && w1_packed && bias1 && y && in_norm && w2_packed && bias2 && y2, "srf_pw_conv_pair: null pointer");
-  SRF_CHECK_ARG(in_norm->sums && in_norm->gamma && in_norm->beta, "srf_pw_conv_pair: conv 1 needs a GlobLN prologue");
+  SRF_CHECK_ARG(x && w1_packed && bias1 && y && w2_packed && bias2 && y2, "srf_pw_conv_pair: null pointer");
+  SRF_CHECK_ARG(!in_norm || (in_norm->sums && in_norm->gamma && in_norm->beta), "srf_pw_conv_pair: a prologue needs statistics, gamma and beta");
   SRF_CHECK_ARG(srf_pw_conv_pair_supported(Bt, Cin1, Cmid, Cout2, L), "srf_pw_conv_pair: unsupported shape / mode (Bt=%d %d->%d->%d L=%d)",
                 Bt, Cin1, Cmid, Cout2, L);
   SRF_CHECK_ARG(srf_aligned16(x) && srf_aligned16(y) && srf_aligned16(y2) && srf_aligned16(w1_packed) && srf_aligned16(w2_packed) &&
@@ -281,7 +282,7 @@ extern "C" int srf_pw_conv_pair(const float* x, const void* w1_packed, const flo
   a.Bt = Bt;
   a.nLt = 0;
   a.total = 0;
-  return srf_pw_x3f_launch(a, a.nrm.prelu ? 2 : 1, (hipStream_t)stream);
+  return srf_pw_x3f_launch(a, !in_norm ? 0 : (a.nrm.prelu ? 2 : 1), (hipStream_t)stream);
 }
 
 // THE predicate of the 256 x 128 dispatch for a whole launch (srf_pw_conv_packed, srf_pw_conv_packed3 and srf_pw_packed_only all

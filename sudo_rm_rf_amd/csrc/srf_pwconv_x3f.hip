@@ -52,13 +52,14 @@ __device__ __forceinline__ int f_swz(int r, int c) { return r * 64 + ((c ^ ((r >
 template <int V>
 using f_int = std::integral_constant<int, V>;
 
-// PRO: 1 = GlobLN, 2 = GlobLN + PReLU (conv 1's operand load).  EPI: 0 = bias, 1 = bias + residual (conv 1's epilogue).
+// PRO: 0 = none (the backward's data-gradient pair: W_proj^T g + skip gradient, then W_res^T of that), 1 = GlobLN,
+// 2 = GlobLN + PReLU (conv 1's operand load).  EPI: 0 = bias, 1 = bias + residual (conv 1's epilogue).
 // DRAIN: every counted wait of the DMA pipeline becomes vmcnt(0) -- the conservative form (debug flag 1 << 23), kept so that a
 // test can hold the counted waits against it bit for bit (same results, ~1.5 % slower).
 template <int PRO, int EPI, bool DRAIN>
 __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta) {
-  static_assert(PRO == 1 || PRO == 2, "conv 1 of the built pairs has a GlobLN prologue");
+  static_assert(PRO >= 0 && PRO <= 2, "conv 1's prologue: none, GlobLN, GlobLN + PReLU");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,9 +81,11 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
   // ---- per-block tables: biases, gamma / beta
   bias1_t[tid] = a.bias1[tid];
   for (int i = tid; i < C2; i += 256) bias2_t[i] = a.bias2[i];
-  for (int i = tid; i < K1; i += 256) {
-    g_tab[i] = gamma[i];
-    b_tab[i] = beta[i];
+  if constexpr (PRO != 0) {
+    for (int i = tid; i < K1; i += 256) {
+      g_tab[i] = gamma[i];
+      b_tab[i] = beta[i];
+    }
   }
   __syncthreads();
 
@@ -101,7 +104,9 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
     t.x_vo = col < L ? ((t.b * K1 + (lane >> 3)) * L + col) * 4 : x_bytes;
     // GlobLN statistics of the tile's example: every wavefront reduces the 64 fp64 buckets itself (DPP; the same sums in the
     // same order as srf_pwconv_x3p.hip's table: identical {mean, rstd})
-    srf_finalize_stats_dpp(a.nrm.sums, t.b, a.inv_count, t.mean, t.rstd);
+    t.mean = 0.f;
+    t.rstd = 1.f;
+    if constexpr (PRO != 0) srf_finalize_stats_dpp(a.nrm.sums, t.b, a.inv_count, t.mean, t.rstd);
     return t;
   };
   __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
@@ -148,8 +153,11 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
   const float* g_lane = g_tab + 8 * h;
   const float* b_lane = b_tab + 8 * h;
   auto cvt1 = [&](float xv, int kt, int j, const Tile& t, bf16x8& bh, bf16x8& bl) __attribute__((always_inline)) {
-    const float sc = g_lane[kt * 16 + j] * t.rstd;
-    float x0 = fmaf(xv, sc, b_lane[kt * 16 + j] - t.mean * sc);
+    float x0 = xv;
+    if constexpr (PRO != 0) {
+      const float sc = g_lane[kt * 16 + j] * t.rstd;
+      x0 = fmaf(xv, sc, b_lane[kt * 16 + j] - t.mean * sc);
+    }
     if (PRO == 2) x0 = srf_prelu(x0, slope);
     const __bf16 hh = (__bf16)x0;
     bh[j] = hh;
@@ -559,8 +567,9 @@ bool srf_x3f_supported(int Bt, int K1, int C2, int L) {
 int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
   PwPairArgs a = a0;
   SRF_CHECK_ARG(srf_x3f_supported(a.Bt, a.K1, a.C2, a.L), "srf_pw_conv_pair: shape not served by the fused pair kernel");
-  SRF_CHECK_ARG(pro == 1 || pro == 2, "srf_pw_conv_pair: conv 1 needs a GlobLN prologue");
-  SRF_CHECK_ARG((pro == 2) == (a.residual != nullptr), "srf_pw_conv_pair: built forms: GlobLN + PReLU with residual, GlobLN without");
+  SRF_CHECK_ARG(pro >= 0 && pro <= 2, "srf_pw_conv_pair: prologue %d", pro);
+  SRF_CHECK_ARG((pro != 1) == (a.residual != nullptr),
+                "srf_pw_conv_pair: built forms: GlobLN + PReLU with residual, GlobLN without, no prologue with residual");
   a.nLt = (a.L + 127) / 128;
   const long total = (long)a.Bt * a.nLt;
   SRF_CHECK_ARG(total < (1L << 30), "srf_pw_conv_pair: too many tiles");
@@ -569,7 +578,8 @@ int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
   const long ok = srf_device_cached(7, [](void*) -> long {
     bool good = true;
     const void* fns[] = {(const void*)&srf_pw_x3f_kernel<1, 0, false>, (const void*)&srf_pw_x3f_kernel<2, 1, false>,
-                         (const void*)&srf_pw_x3f_kernel<1, 0, true>, (const void*)&srf_pw_x3f_kernel<2, 1, true>};
+                         (const void*)&srf_pw_x3f_kernel<1, 0, true>, (const void*)&srf_pw_x3f_kernel<2, 1, true>,
+                         (const void*)&srf_pw_x3f_kernel<0, 1, false>, (const void*)&srf_pw_x3f_kernel<0, 1, true>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
@@ -586,11 +596,15 @@ int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
   if (pro == 1) {
     if (drain) F_GO(1, 0, true);
     else F_GO(1, 0, false);
-  } else {
+  } else if (pro == 2) {
     if (drain) F_GO(2, 1, true);
     else F_GO(2, 1, false);
+  } else {
+    if (drain) F_GO(0, 1, true);
+    else F_GO(0, 1, false);
   }
 #undef F_GO
-  SRF_CHECK_LAUNCH(pro == 1 ? "pw_pair_x3f<1>" : "pw_pair_x3f<2>", st);
+  static const char* const kLabel[3] = {"pw_pair_x3f<0>", "pw_pair_x3f<1>", "pw_pair_x3f<2>"};
+  SRF_CHECK_LAUNCH(kLabel[pro], st);
   return SRF_OK;
 }

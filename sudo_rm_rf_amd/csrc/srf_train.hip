@@ -500,6 +500,7 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
   float* gf = fp(s.gf);
   float* go = fp(s.go);
   float* gd = fp(s.gd);
+  bool gf_ready = false;      // block i's g_f was produced by block i + 1's data-gradient pair
   for (int i = U - 1; i >= 0; --i) {
     const int pb = p->p_block0 + i * p->p_block_stride;
     const int pu = pb + p->p_ublock_off;
@@ -515,11 +516,14 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     srf_norm fn{slot(s0 + 1 + D), Pu[pf], Pu[pf + 1], Pu[pf + 2]};
     rc = srf_pw_wgrad(gx, merged, &fn, Bg, nC, nB, L, Gu[pf + 3], Gu[pf + 4], 1, wg, stream);
     if (rc) return rc;
-    if (!srf_pw_packed_only(pkT_res[i], gx, Bg, nB, nC, L))
-      rc = srf_transpose_launch(Pu[pf + 3], wt, nB, nC, st);    // [nB][nC] -> [nC][nB]
-    if (rc) return rc;
-    rc = srf_pw_conv_packed(gx, wt, pkT_res[i], zeros, gf, Bg, nB, nC, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
-    if (rc) return rc;
+    if (!gf_ready) {        // (else: block i + 1's data-gradient pair below already left g_f = W_r^T g_x here)
+      if (!srf_pw_packed_only(pkT_res[i], gx, Bg, nB, nC, L))
+        rc = srf_transpose_launch(Pu[pf + 3], wt, nB, nC, st);    // [nB][nC] -> [nC][nB]
+      if (rc) return rc;
+      rc = srf_pw_conv_packed(gx, wt, pkT_res[i], zeros, gf, Bg, nB, nC, L, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
+    gf_ready = false;
     char* gln_sl = sc + s.arena + (size_t)i * ((size_t)(D + 2) * s.gln_slice + (size_t)D * s.dw_slice);   // D + 2 norm slices,
     char* dw_sl = gln_sl + (size_t)(D + 2) * s.gln_slice;                                                 // then D conv slices
     srf_bwd_ctx_defer(ctx, true);
@@ -596,11 +600,22 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
     if (rc) return rc;
     rc = srf_pw_wgrad(go, xin, nullptr, Bg, nB, nC, L, Gu[0], Gu[1], 1, wg, stream);
     if (rc) return rc;
-    if (!srf_pw_packed_only(pkT_proj[i], go, Bg, nC, nB, L))
-      rc = srf_transpose_launch(Pu[0], wt, nC, nB, st);          // [nC][nB] -> [nB][nC]
-    if (rc) return rc;
-    rc = srf_pw_conv_packed(go, wt, pkT_proj[i], zeros, gx_other, Bg, nC, nB, L, nullptr, gx, nullptr, 0, nullptr, 0, stream);   // + skip
-    if (rc) return rc;
+    // Data gradients back to back (round 5; srf_pwconv_x3f.hip, no prologue): g_x(i) = W_p^T g_y1 + g_x(i + 1) -- the block's
+    // input gradient, skip included -- and, from registers, block i - 1's g_f = W_r^T g_x(i): one launch, bit-identical to the
+    // two it replaces (the B = 256 Improved models, launches of at least one tile per CU; debug flag 1 = without).
+    if (i > 0 && !gc && pkT_proj[i] && pkT_res[i - 1] && srf_pw_conv_pair_supported(Bg, nC, nB, nC, L) &&
+        srf_pw_packed_only(pkT_proj[i], go, Bg, nC, nB, L) && srf_pw_packed_only(pkT_res[i - 1], gx, Bg, nB, nC, L)) {
+      rc = srf_pw_conv_pair(go, pkT_proj[i], zeros, gx_other, nullptr, gx, pkT_res[i - 1], zeros, gf, nullptr, Bg, nC, nB, nC, L,
+                            stream);
+      if (rc) return rc;
+      gf_ready = true;
+    } else {
+      if (!srf_pw_packed_only(pkT_proj[i], go, Bg, nC, nB, L))
+        rc = srf_transpose_launch(Pu[0], wt, nC, nB, st);          // [nC][nB] -> [nB][nC]
+      if (rc) return rc;
+      rc = srf_pw_conv_packed(go, wt, pkT_proj[i], zeros, gx_other, Bg, nC, nB, L, nullptr, gx, nullptr, 0, nullptr, 0, stream);   // + skip
+      if (rc) return rc;
+    }
     float* tmp = gx;
     gx = gx_other;
     gx_other = tmp;

@@ -265,7 +265,7 @@ def _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A):
     return fam
 
 
-def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
+def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, dgrad_pairs=None):
     """{profiler family: (algorithmic bytes per step, FLOPs per step)} of srf_forward_train + the loss + srf_backward + the
     optimizer for the IMPROVED model (csrc/srf_train.hip is the launch sequence this mirrors; launches per step come from the
     in-library profiler, so per-launch figures = these totals / the launches counted).  Bytes = tensors a kernel family must read
@@ -277,6 +277,12 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
     if variant == "groupcomm":
         return _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A)
     L = frames(T, K, D)
+    # round 5: the B = 256 models' data gradients of proj_1x1(i) and res_conv(i - 1) run as ONE launch (srf_pwconv_x3f.hip without
+    # prologue) when a launch has at least one 128-column tile per CU -- U - 1 pairs; the first res_conv gradient and the last
+    # proj_1x1 gradient stay launches of their own.  dgrad_pairs=None: decide from the shape as srf_backward does.
+    if dgrad_pairs is None:
+        dgrad_pairs = B == 256 and C % 128 == 0 and C <= 512 and Bt * ((L + 127) // 128) >= 256
+    npair = (U - 1) if dgrad_pairs else 0
     f = 4.0 * Bt
     SN, SK = S * A * N, S * A * K
     P = n_params(variant, B, C, U, D, K, N, S, G, A)
@@ -315,14 +321,16 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1):
     add("prelu_bwd", f * 3 * B * L, 2.0 * Bt * B * L)
     # ---- backward: U blocks
     add("pw_wgrad", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)                   # res_conv weight (prologue re-applied on load)
-    add("pw_conv_x3w<0>", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)             # res_conv data gradient
+    add("pw_conv_x3w<0>", (U - npair) * f * L * (B + C), (U - npair) * 2.0 * Bt * B * C * L)     # res_conv data gradient (un-paired)
     add("gln_bwd_reduce", U * f * C * 2 * (L + lv[-1]), U * 4.0 * Bt * C * (L + lv[-1]))      # final_norm + the deepest level
     add("gln_bwd_apply", U * f * C * (3 * L + (lev_sum - L)) + U * f * C * 3 * L, U * 16.0 * Bt * C * L)   # final_norm (+ merge sink) + proj norm
     # per level: the conv backward reads g_out, d_k (its own norm's apply on load), the conv input, the merge part and writes g_in
     dwb = 4 * L + sum(2 * lv[k] + 3 * lv[k - 1] for k in range(1, D))        # (level 0 has no merge part to add)
     add("dwconv5_bwd", U * f * C * dwb, U * 2.0 * 15 * Bt * C * lev_sum)
     add("pw_wgrad", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)                   # proj_1x1 weight
-    add("pw_conv_x3w<0>", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L)         # proj_1x1 data gradient + skip
+    add("pw_conv_x3w<0>", (U - npair) * f * L * (C + 2 * B), (U - npair) * 2.0 * Bt * B * C * L)   # proj_1x1 data gradient + skip (un-paired)
+    if npair:        # g_y1 and the skip gradient in, g_x(i) out, g_f(i - 1) out: the 256-channel g_x is not re-read
+        add("pw_pair_x3f<0>", npair * f * L * (C + 2 * B + C), npair * 2 * 2.0 * Bt * B * C * L)
     # ---- backward: head
     add("pw_wgrad", f * L * (B + N), 2.0 * Bt * B * N * L)
     add("pw_conv_x3w<0>", f * L * (B + N), 2.0 * Bt * B * N * L)                     # bottleneck data gradient

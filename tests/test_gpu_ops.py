@@ -215,13 +215,14 @@ def test_pw_conv_persistent_variants(Bt, Cin, Cout, L, pro):
                                              (12, 512, 512, 3200),      # a sub-batch of the stream split: one round, blocks with one tile
                                              (24, 256, 384, 1604),      # ragged last tile (L % 128 = 68), three passes of conv 2, K1 = 256
                                              (40, 128, 128, 1000)])     # shortest k loop (8 steps), one pass, ragged
-@pytest.mark.parametrize("pro", [1, 2])
+@pytest.mark.parametrize("pro", [0, 1, 2])
 def test_pw_conv_pair_is_bitwise_the_two_launches(Bt, Cin1, Cout2, L, pro):
     """srf_pw_conv_pair (round 5: res_conv / bottleneck + the next block's proj_1x1 in one launch, the 256-channel tensor handed
     over in registers) against the two srf_pw_conv_packed launches it replaces -- BIT FOR BIT on both outputs -- against an fp64
     reference, its statistics against the fp64 sums; the form with full-drain waits (flag 1 << 23) must agree bitwise too (a
     difference = a miscounted vmcnt in the DMA pipeline), and so must the persistent-block form (flag 1 << 21: several tiles per
-    block, the operand pipeline running across tile boundaries -- what launches beyond 16 rounds of the chip get)."""
+    block, the operand pipeline running across tile boundaries -- what launches beyond 16 rounds of the chip get).
+    pro 0 = no prologue, with residual: the backward's data-gradient pair (W_proj^T g + skip gradient, then W_res^T of it)."""
     from sudo_rm_rf_amd import ops
     ops.set_kernel_mode(0)
     Cmid = 256
@@ -230,11 +231,13 @@ def test_pw_conv_pair_is_bitwise_the_two_launches(Bt, Cin1, Cout2, L, pro):
     x = dev32(rnd(Bt, Cin1, L, seed=50, scale=1.3, shift=0.2))
     w1, b1 = dev32(rnd(Cmid, Cin1, 1, seed=51, scale=Cin1 ** -0.5)), dev32(rnd(Cmid, seed=52, scale=0.2))
     w2, b2 = dev32(rnd(Cout2, Cmid, 1, seed=53, scale=Cmid ** -0.5)), dev32(rnd(Cout2, seed=54, scale=0.2))
-    res = dev32(rnd(Bt, Cmid, L, seed=55)) if pro == 2 else None
+    res = dev32(rnd(Bt, Cmid, L, seed=55)) if pro != 1 else None
     gamma, beta = rnd(Cin1, seed=56, scale=0.3, shift=1.0), rnd(Cin1, seed=57, scale=0.3)
     xin = x.double().cpu()
-    kw = dict(in_sums=sums64(xin).to(DEV), in_gamma=dev32(gamma), in_beta=dev32(beta))
-    xin = gln64(xin, gamma, beta)
+    kw = dict(in_sums=None, in_gamma=None, in_beta=None)
+    if pro != 0:
+        kw = dict(in_sums=sums64(xin).to(DEV), in_gamma=dev32(gamma), in_beta=dev32(beta))
+        xin = gln64(xin, gamma, beta)
     slope = None
     if pro == 2:
         slope = dev32(torch.tensor([0.17], dtype=torch.float64))

@@ -217,6 +217,43 @@ def test_fast_training_forward_flag():
     assert (num / den) ** 0.5 <= 2e-2          # whole-gradient relative error (measured 3e-3)
 
 
+def test_backward_data_gradient_pairs_are_bitwise_the_separate_launches():
+    """Round 5: in the B = 256 Improved models srf_backward runs the data gradients of proj_1x1(i) and res_conv(i - 1) as ONE
+    launch (srf_pw_conv_pair without prologue: g_x(i) = W_p^T g_y1 + g_x(i + 1), then W_r^T g_x(i) from registers).  Both of its
+    output tensors are bit-identical to the two GEMM launches, nothing else on the step changes: every parameter gradient TENSOR must
+    be bit-identical with and without the pairs (debug flag 1; the scalar PReLU-slope gradients are atomic sums over a whole launch
+    and only reproduce to rounding in any two runs); the profiler proves U - 1 pairs ran."""
+    import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib
+    from sudo_rm_rf_amd import ops
+    cfg = ModelConfig("improved", 256, 512, 3, 4, 21, 256, 2)
+    sd = weights.make_state_dict(cfg, seed=77)
+    g = torch.Generator().manual_seed(3)
+    tgt = torch.randn(12, 2, 32000, generator=g)
+    mix = tgt.sum(1, keepdim=True)
+    mix = ((mix - mix.mean(-1, keepdim=True)) / (mix.std(-1, keepdim=True) + 1e-8)).to(DEV)
+    tgt = tgt.to(DEV)
+    loss_fn = sisdr_lib.PITLossWrapper(sisdr_lib.PairwiseNegSDR("sisdr"), pit_from='pw_mtx')
+    grads = {}
+    try:
+        for flags in (0, 1):
+            model = build(cfg, sd).train()
+            ops.set_debug_flags(flags)
+            with ops.kernel_trace(DEV) as tr:
+                loss_fn(model(mix), tgt).backward()
+            npair = sum(1 for k, _ in tr.launches if k == "pw_pair_x3f<0>")
+            assert npair == (cfg.num_blocks - 1 if flags == 0 else 0), (flags, npair, sorted(tr.names))
+            grads[flags] = {k: p.grad.clone() for k, p in model.state_dict(keep_vars=True).items()}
+    finally:
+        ops.set_debug_flags(0)
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert torch.isfinite(a).all(), k
+        if a.numel() > 1:
+            assert torch.equal(a, b), k
+        else:       # PReLU slopes: one scalar summed by atomics over every block of a launch -- not bit-reproducible run to run
+            assert abs(float(a) - float(b)) <= 2e-5 * max(abs(float(b)), 1e-6), (k, float(a), float(b))
+
+
 def test_fused_clip_adam_state_dict_round_trips_with_torch_adam():
     """A torch.optim.Adam state_dict (float-tensor `step`) loads into FusedClipAdam mid-run and the next steps agree; the
     device pointer table is rebuilt for the replaced state tensors (stale table after load_state_dict)."""
