@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 13
+#define SRF_ABI_VERSION 14
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -208,8 +208,9 @@ int srf_pw_conv_packed(const float* x, const float* w, const void* w_packed, con
 /* Round 5: TWO 1x1 convolutions back to back in ONE launch (csrc/srf_pwconv_x3f.hip) -- a conv with Cmid = 256 output channels
  * and the conv that consumes its output, the 256-channel tensor handed over in registers (it is still written to y: it is the
  * model's residual stream):
- *     y  = W1 f(x) + bias1 (+ residual)     f = in_norm: GlobLN (bottleneck, improved_sudormrf.py:292: no residual) or
- *                                           GlobLN + PReLU (res_conv, :218-220: residual required)
+ *     y  = W1 f(x) + bias1 (+ residual)     f = in_norm: GlobLN (bottleneck, improved_sudormrf.py:292: no residual),
+ *                                           GlobLN + PReLU (res_conv, :218-220: residual required), or NULL: no prologue,
+ *                                           residual required (the backward's data-gradient pair W_proj^T g + skip, W_res^T of it)
  *     y2 = W2 y + bias2,  out_sums2 (nullable) += {sum, sumsq} of y2          (proj_1x1 of the next block, :205)
  * Results are BIT-IDENTICAL to srf_pw_conv_packed(x -> y) followed by srf_pw_conv_packed(y -> y2) (statistics: to rounding).
  * w1_packed / w2_packed: buffers of srf_pack_pw_weights for [Cmid, Cin1] / [Cout2, Cmid].  srf_pw_conv_pair_supported: the
@@ -232,6 +233,14 @@ size_t srf_packed3_pw_weight_bytes(int Cout, int Cin);
 int srf_pack3_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n, void* stream);
 int srf_pw_conv_packed3(const float* x, const float* w, const void* w_packed3, const float* bias, float* y, int Bt, int Cin,
                         int Cout, int L, const srf_norm* in_norm, const float* residual, double* out_sums, void* stream);
+/* The fused pair of the training forward (ABI 14): srf_pw_conv_pair on the two-fp16-part images -- y and y2 BIT-IDENTICAL to
+ * srf_pw_conv_packed3(x -> y) followed by srf_pw_conv_packed3(y -> y2, out_sums2).  w1_packed3 / w2_packed3: buffers written by
+ * srf_pack3_pw_weights in this process under the default (fp16) form -- it keeps the paired-block layout of the same parts in
+ * the buffer's second half.  in_norm required (GlobLN: no residual; GlobLN + PReLU: residual required). */
+int srf_pw_conv_pair_packed3_supported(int Bt, int Cin1, int Cmid, int Cout2, int L);
+int srf_pw_conv_pair_packed3(const float* x, const void* w1_packed3, const float* bias1, float* y, const srf_norm* in_norm,
+                             const float* residual, const void* w2_packed3, const float* bias2, float* y2, double* out_sums2,
+                             int Bt, int Cin1, int Cmid, int Cout2, int L, void* stream);
 
 /* Depthwise k=5, padding 2: y[r,j] = bias[c] + sum_k w[c,k] * f(x[r, stride*j+k-2]), r=(b,c), zero
  * outside AFTER f (the reference pads the normalised tensor).  x: [Bt,C,Lin], y: [Bt,C,Lout],

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # SRF_LIB: an alternative build of the same library (same-box A/B of kernel variants, tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SRF_LIB") or os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 STAT_BUCKETS = 64
 
 SRF_OK = 0
@@ -63,6 +63,8 @@ _PROTOS = {
     "srf_pw_conv_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _i, _vp, _i, _vp]),
     "srf_pw_conv_pair_supported": (_i, [_i, _i, _i, _i, _i]),
     "srf_pw_conv_pair": (_i, [_vp, _vp, _vp, _vp, C.POINTER(srf_norm), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srf_pw_conv_pair_packed3_supported": (_i, [_i, _i, _i, _i, _i]),
+    "srf_pw_conv_pair_packed3": (_i, [_vp, _vp, _vp, _vp, C.POINTER(srf_norm), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srf_packed3_pw_weight_bytes": (_sz, [_i, _i]),
     "srf_pack3_pw_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
     "srf_pw_conv_packed3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _vp]),

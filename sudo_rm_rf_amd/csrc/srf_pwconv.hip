@@ -242,14 +242,17 @@ bool srf_pw_small_supported(int Cin, int Cout, int L);
 // res_conv (or the bottleneck) and the proj_1x1 that consumes its output.  Both weights come as packed buffers of
 // srf_pack_pw_weights; the kernel streams their paired-block images.
 bool srf_x3f_supported(int Bt, int K1, int C2, int L);
-int srf_pw_x3f_launch(const PwPairArgs& a, int pro, hipStream_t st);
+int srf_pw_x3f_launch(const PwPairArgs& a, int pro, hipStream_t st, bool f16 = false);
 // Whether the fused pair serves (Bt, Cin1 -> 256 -> Cout2, L): the kernel's shape limits, the default kernel mode, and a launch
 // that fills the chip (fewer 128-column tiles than CUs: the separate launches' small-launch kernels do better).
+static bool srf_pw_pair_shape_ok(int Bt, int Cin1, int Cmid, int Cout2, int L) {      // (whatever the kernel mode)
+  if (srf_debug_flags() & (1 | 4 | 8)) return false;
+  if (Cmid != 256 || !srf_x3f_supported(Bt, Cin1, Cout2, L)) return false;
+  if (!srf_x3w_shape_supported(Cin1, Cmid, L) || !srf_x3w_shape_supported(Cmid, Cout2, L)) return false;
+  return (long)Bt * ((L + 127) / 128) >= srf_device_cus();
+}
 extern "C" int srf_pw_conv_pair_supported(int Bt, int Cin1, int Cmid, int Cout2, int L) {
-  if (srf_kernel_mode() != 0 || (srf_debug_flags() & (1 | 4 | 8))) return 0;
-  if (Cmid != 256 || !srf_x3f_supported(Bt, Cin1, Cout2, L)) return 0;
-  if (!srf_x3w_shape_supported(Cin1, Cmid, L) || !srf_x3w_shape_supported(Cmid, Cout2, L)) return 0;
-  return (long)Bt * ((L + 127) / 128) >= srf_device_cus() ? 1 : 0;
+  return srf_kernel_mode() == 0 && srf_pw_pair_shape_ok(Bt, Cin1, Cmid, Cout2, L) ? 1 : 0;
 }
 // y = W1 f(x) + bias1 (+ residual), f = in_norm (GlobLN, or GlobLN + PReLU: then the residual is required -- the two forms the
 // model has -- or NULL: no prologue, residual required -- the backward's data-gradient pair); y2 = W2 y + bias2; out_sums2
@@ -346,7 +349,8 @@ int srf_mask_decode(const float* x, const float* w, const void* w_packed, const 
 // of the exact-fp32 MFMA kernel's 2.5 x) -- the training forward's 1x1 convolutions (srf_forward_train) ----------------------
 int srf_pw_x3w3_launch(const PwArgs& a, const char* wpack3, int pro, hipStream_t st);
 int srf_pw_x3w4_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st);
-int srf_x3w_pack_f16_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
+int srf_x3w_pack_f16_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st,
+                            char* const* dst16);
 // The training forward's GEMMs run on TWO fp16 parts per operand (hi = fp16(x), lo = fp16(x - hi): 22 mantissa bits, 3 MFMAs per
 // product block -- round 4) unless debug flag 16384 selects round 3's three bf16 parts (24 bits, 6 MFMAs).
 // Measured (tools/f16_split_probe.py -> profiles/r04_f16_split_probe.txt): error against fp64 on a model-sized GEMM 2.6e-6 --
@@ -387,7 +391,13 @@ extern "C" int srf_pack3_pw_weights(const float* const* w, void* const* packed, 
     std::lock_guard<std::mutex> lk(g_pk3_mu);
     for (int i = 0; i < n; ++i) g_pk3_format[srf_pk3_key(packed[i])] = f16 ? 4 : 3;
   }
-  if (f16) return srf_x3w_pack_f16_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
+  if (f16) {
+    // the fp16 image takes the first half of a packed3 buffer (sized for the three-part image); the second half gets the same
+    // parts in the paired-block layout, for the training forward's fused pairs (srf_pw_conv_pair_packed3)
+    std::vector<char*> second(n);
+    for (int i = 0; i < n; ++i) second[i] = reinterpret_cast<char*>(packed[i]) + srf_x3w_packed_bytes(Cout[i], Cin[i]);
+    return srf_x3w_pack_f16_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream, second.data());
+  }
   return srf_x3w_pack3_launch(w, reinterpret_cast<char* const*>(packed), Cout, Cin, n, (hipStream_t)stream);
 }
 // y = W f(x) + bias (+ residual), out_sums as in srf_pw_conv; w_packed3 from srf_pack3_pw_weights (NULL, a shape the
@@ -435,6 +445,54 @@ extern "C" int srf_pw_conv_packed3(const float* x, const float* w, const void* w
   }
   if (f16) return srf_pw_x3w4_launch(a, reinterpret_cast<const char*>(w_packed3), pro, (hipStream_t)stream);
   return srf_pw_x3w3_launch(a, reinterpret_cast<const char*>(w_packed3), pro, (hipStream_t)stream);
+}
+
+// The training forward's fused pair (round 5): srf_pw_conv_pair on the two-fp16-part images of srf_pack3_pw_weights -- y and y2
+// bit-identical to two srf_pw_conv_packed3 launches (res_conv / bottleneck, then proj_1x1 with its statistics).  Served: what
+// srf_pw_conv_pair serves, with the fp16 form selected (no debug flag 16384) and both buffers packed as fp16 by this process.
+static bool srf_pk3_is_f16(const void* p) {
+  std::lock_guard<std::mutex> lk(g_pk3_mu);
+  const auto it = g_pk3_format.find(srf_pk3_key(p));
+  return it != g_pk3_format.end() && it->second == 4;
+}
+extern "C" int srf_pw_conv_pair_packed3_supported(int Bt, int Cin1, int Cmid, int Cout2, int L) {
+  // (kernel mode 2 -- srf_forward_train's -- as well as 0: like srf_pw_conv_packed3, this IS the exact-fp32 class)
+  return srf_train_f16_split() && srf_kernel_mode() != 1 && srf_pw_pair_shape_ok(Bt, Cin1, Cmid, Cout2, L) &&
+                 srf_x3w_packed3_bytes(Cmid, Cin1) >= 2 * srf_x3w_packed_bytes(Cmid, Cin1) &&
+                 srf_x3w_packed3_bytes(Cout2, Cmid) >= 2 * srf_x3w_packed_bytes(Cout2, Cmid)
+             ? 1 : 0;
+}
+extern "C" int srf_pw_conv_pair_packed3(const float* x, const void* w1_packed3, const float* bias1, float* y, const srf_norm* in_norm,
+                                        const float* residual, const void* w2_packed3, const float* bias2, float* y2,
+                                        double* out_sums2, int Bt, int Cin1, int Cmid, int Cout2, int L, void* stream) {
+  SRF_CHECK_ARG(x && w1_packed3 && bias1 && y && in_norm && w2_packed3 && bias2 && y2, "srf_pw_conv_pair_packed3: null pointer");
+  SRF_CHECK_ARG(in_norm->sums && in_norm->gamma && in_norm->beta, "srf_pw_conv_pair_packed3: conv 1 needs a GlobLN prologue");
+  SRF_CHECK_ARG(srf_pw_conv_pair_packed3_supported(Bt, Cin1, Cmid, Cout2, L),
+                "srf_pw_conv_pair_packed3: unsupported shape / mode (Bt=%d %d->%d->%d L=%d)", Bt, Cin1, Cmid, Cout2, L);
+  SRF_CHECK_ARG(srf_pk3_is_f16(w1_packed3) && srf_pk3_is_f16(w2_packed3),
+                "srf_pw_conv_pair_packed3: both weight images must have been packed as two fp16 parts by srf_pack3_pw_weights");
+  SRF_CHECK_ARG(srf_aligned16(x) && srf_aligned16(y) && srf_aligned16(y2) && srf_aligned16(w1_packed3) && srf_aligned16(w2_packed3) &&
+                    (!residual || srf_aligned16(residual)),
+                "srf_pw_conv_pair_packed3: unaligned operand");
+  PwPairArgs a;
+  a.x = x;
+  a.residual = residual;
+  a.bias1 = bias1;
+  a.y = y;
+  a.nrm = srf_norm_dev(in_norm);
+  a.inv_count = 1.0 / ((double)Cin1 * (double)L);
+  a.wpack1 = reinterpret_cast<const char*>(w1_packed3) + srf_x3w_packed_bytes(Cmid, Cin1);
+  a.wpack2 = reinterpret_cast<const char*>(w2_packed3) + srf_x3w_packed_bytes(Cout2, Cmid);
+  a.bias2 = bias2;
+  a.y2 = y2;
+  a.out_sums2 = out_sums2;
+  a.K1 = Cin1;
+  a.C2 = Cout2;
+  a.L = L;
+  a.Bt = Bt;
+  a.nLt = 0;
+  a.total = 0;
+  return srf_pw_x3f_launch(a, a.nrm.prelu ? 2 : 1, (hipStream_t)stream, true);
 }
 
 // ---- GroupComm (library-internal; srf_forward): proj_1x1 with the TAC's "x + GlobLN(q)" folded into its operand load ----

@@ -32,7 +32,33 @@
 #include "srf_pw.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// F16 (the training forward, srf_pwconv_x3w.hip NP = 4): operands split into two FP16 parts (hi = fp16(x), lo = fp16(x - hi): 22
+// mantissa bits), weights stored times 2^4 (their lo parts stay normal), accumulators times 2^-4 in the epilogues (exact);
+// `v_mfma_f32_32x32x16_f16` -- same shapes, same three products per block, same order.  Packets keep the bf16x8 container.
+constexpr float F_F16_WSCALE_INV = 1.f / 16.f;
+template <bool F16>
+__device__ __forceinline__ f32x16 f_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// element j of the hi | lo packets of x0 (no range guard in the fp16 form: see w_split8_f16 in srf_pwconv_x3w.hip)
+template <bool F16>
+__device__ __forceinline__ void f_split1(float x0, bf16x8& hi, bf16x8& lo, int j) {
+  if constexpr (F16) {
+    const _Float16 hh = (_Float16)x0;
+    hi[j] = __builtin_bit_cast(__bf16, hh);
+    lo[j] = __builtin_bit_cast(__bf16, (_Float16)(x0 - (float)hh));
+  } else {
+    const __bf16 hh = (__bf16)x0;
+    hi[j] = hh;
+    lo[j] = (__bf16)(x0 - (float)hh);
+  }
+}
 
 constexpr int F_BM = 256;                                  // rows of conv 1 = k of conv 2
 constexpr int F_STAGE = 16384, F_NSTAGE = 3;
@@ -56,7 +82,7 @@ using f_int = std::integral_constant<int, V>;
 // 2 = GlobLN + PReLU (conv 1's operand load).  EPI: 0 = bias, 1 = bias + residual (conv 1's epilogue).
 // DRAIN: every counted wait of the DMA pipeline becomes vmcnt(0) -- the conservative form (debug flag 1 << 23), kept so that a
 // test can hold the counted waits against it bit for bit (same results, ~1.5 % slower).
-template <int PRO, int EPI, bool DRAIN>
+template <int PRO, int EPI, bool DRAIN, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta) {
   static_assert(PRO >= 0 && PRO <= 2, "conv 1's prologue: none, GlobLN, GlobLN + PReLU");
@@ -159,9 +185,7 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
       x0 = fmaf(xv, sc, b_lane[kt * 16 + j] - t.mean * sc);
     }
     if (PRO == 2) x0 = srf_prelu(x0, slope);
-    const __bf16 hh = (__bf16)x0;
-    bh[j] = hh;
-    bl[j] = (__bf16)(x0 - (float)hh);
+    f_split1<F16>(x0, bh, bl, j);
   };
 
   // ---- weight stages: step g of a tile's sequence (conv 1: g < nk1; conv 2: pass (g - nk1) >> 3, 32-k step (g - nk1) & 7).
@@ -275,9 +299,9 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
         ah[(mt + 1) & 1] = *reinterpret_cast<const bf16x8*>(base + a_hi0 + (mt + 1) * 2048);
         al[(mt + 1) & 1] = *reinterpret_cast<const bf16x8*>(base + a_lo0 + (mt + 1) * 2048);
       }
-      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt & 1], bhC, acc[mt], 0, 0, 0);
-      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt & 1], blC, acc[mt], 0, 0, 0);
-      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt & 1], bhC, acc[mt], 0, 0, 0);
+      acc[mt] = f_mfma<F16>(al[mt & 1], bhC, acc[mt]);
+      acc[mt] = f_mfma<F16>(ah[mt & 1], blC, acc[mt]);
+      acc[mt] = f_mfma<F16>(ah[mt & 1], bhC, acc[mt]);
       if constexpr (STAGE) cvt1(xin[mt], kt + 1, mt, t, bhN, blN);
     }
     end_step(vm_tag);
@@ -395,6 +419,12 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
         for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(o[it].x), "+v"(o[it].y), "+v"(o[it].z), "+v"(o[it].w), "+v"(bs[it]));
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
+          if constexpr (F16) {       // (the weights were stored times 2^4)
+            o[it].x *= F_F16_WSCALE_INV;
+            o[it].y *= F_F16_WSCALE_INV;
+            o[it].z *= F_F16_WSCALE_INV;
+            o[it].w *= F_F16_WSCALE_INV;
+          }
           o[it].x += bs[it];
           o[it].y += bs[it];
           o[it].z += bs[it];
@@ -422,12 +452,7 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
         for (int c = 0; c < 2; ++c) {
           bf16x8 ph, pl;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float x0 = xr[8 * c + j];
-            const __bf16 hh = (__bf16)x0;
-            ph[j] = hh;
-            pl[j] = (__bf16)(x0 - (float)hh);
-          }
+          for (int j = 0; j < 8; ++j) f_split1<F16>(xr[8 * c + j], ph, pl, j);
           x2h[2 * t + c] = ph;
           x2l[2 * t + c] = pl;
         }
@@ -475,9 +500,9 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
             ah[(f + 1) & 1] = *reinterpret_cast<const bf16x8*>(base + a_hi0 + (f + 1) * 2048);
             al[(f + 1) & 1] = *reinterpret_cast<const bf16x8*>(base + a_lo0 + (f + 1) * 2048);
           }
-          acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[f & 1], x2h[2 * ks + kb], acc2[mt], 0, 0, 0);
-          acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[f & 1], x2l[2 * ks + kb], acc2[mt], 0, 0, 0);
-          acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[f & 1], x2h[2 * ks + kb], acc2[mt], 0, 0, 0);
+          acc2[mt] = f_mfma<F16>(al[f & 1], x2h[2 * ks + kb], acc2[mt]);
+          acc2[mt] = f_mfma<F16>(ah[f & 1], x2l[2 * ks + kb], acc2[mt]);
+          acc2[mt] = f_mfma<F16>(ah[f & 1], x2h[2 * ks + kb], acc2[mt]);
         }
         frag_schedule();
         if (ks == 0) end_step(f_int<VM_BP>{});
@@ -509,6 +534,12 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             float4 o = o4[it];
+            if constexpr (F16) {
+              o.x *= F_F16_WSCALE_INV;
+              o.y *= F_F16_WSCALE_INV;
+              o.z *= F_F16_WSCALE_INV;
+              o.w *= F_F16_WSCALE_INV;
+            }
             o.x += bs[it];
             o.y += bs[it];
             o.z += bs[it];
@@ -564,7 +595,8 @@ bool srf_x3f_supported(int Bt, int K1, int C2, int L) {
 }
 
 // wpack1 / wpack2: the PAIRED-BLOCK image of the two weights (srf_x3p_packed_bytes; the second image of a packed buffer)
-int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
+// f16: the training forward's form (packed3 fp16 images, PRO 1 / 2 only)
+int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st, bool f16) {
   PwPairArgs a = a0;
   SRF_CHECK_ARG(srf_x3f_supported(a.Bt, a.K1, a.C2, a.L), "srf_pw_conv_pair: shape not served by the fused pair kernel");
   SRF_CHECK_ARG(pro >= 0 && pro <= 2, "srf_pw_conv_pair: prologue %d", pro);
@@ -579,7 +611,8 @@ int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
     bool good = true;
     const void* fns[] = {(const void*)&srf_pw_x3f_kernel<1, 0, false>, (const void*)&srf_pw_x3f_kernel<2, 1, false>,
                          (const void*)&srf_pw_x3f_kernel<1, 0, true>, (const void*)&srf_pw_x3f_kernel<2, 1, true>,
-                         (const void*)&srf_pw_x3f_kernel<0, 1, false>, (const void*)&srf_pw_x3f_kernel<0, 1, true>};
+                         (const void*)&srf_pw_x3f_kernel<0, 1, false>, (const void*)&srf_pw_x3f_kernel<0, 1, true>,
+                         (const void*)&srf_pw_x3f_kernel<1, 0, false, true>, (const void*)&srf_pw_x3f_kernel<2, 1, false, true>};
     for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES) == hipSuccess;
     return good ? 1 : 0;
   }, nullptr);
@@ -593,7 +626,11 @@ int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
   if (nb > total) nb = total;
   dim3 grid((unsigned)nb), block(256);
 #define F_GO(...) hipLaunchKernelGGL((srf_pw_x3f_kernel<__VA_ARGS__>), grid, block, F_LDS_BYTES, st, a, a.nrm.gamma, a.nrm.beta)
-  if (pro == 1) {
+  if (f16) {
+    SRF_CHECK_ARG(pro == 1 || pro == 2, "srf_pw_conv_pair (fp16 parts): prologue %d not built", pro);
+    if (pro == 1) F_GO(1, 0, false, true);
+    else F_GO(2, 1, false, true);
+  } else if (pro == 1) {
     if (drain) F_GO(1, 0, true);
     else F_GO(1, 0, false);
   } else if (pro == 2) {
@@ -605,6 +642,7 @@ int srf_pw_x3f_launch(const PwPairArgs& a0, int pro, hipStream_t st) {
   }
 #undef F_GO
   static const char* const kLabel[3] = {"pw_pair_x3f<0>", "pw_pair_x3f<1>", "pw_pair_x3f<2>"};
-  SRF_CHECK_LAUNCH(kLabel[pro], st);
+  static const char* const kLabel4[3] = {"pw_pair_x3f4<0>", "pw_pair_x3f4<1>", "pw_pair_x3f4<2>"};
+  SRF_CHECK_LAUNCH(f16 ? kLabel4[pro] : kLabel[pro], st);
   return SRF_OK;
 }

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256) void srf_x3w_pack_kernel(WPackTable t) {
     char* base = e.dst + (size_t)tile * W_WTILE_BYTES + w_swz(row, c);
     *reinterpret_cast<bf16x8*>(base) = hi;
     *reinterpret_cast<bf16x8*>(base + W_A_IMG) = lo;
-    if (!F16 && e.dst16) {      // 16-k step 2 kt + (c >> 1) of the m-tile, 8-k packet c & 1
+    if (e.dst16) {              // 16-k step 2 kt + (c >> 1) of the m-tile, 8-k packet c & 1
       char* b16 = e.dst16 + ((size_t)mt * (2 * nKt) + 2 * kt + (c >> 1)) * (size_t)(W_BM * 64);
       *reinterpret_cast<bf16x8*>(b16 + w_swz(row, c & 1)) = hi;
       *reinterpret_cast<bf16x8*>(b16 + w_swz(row, 2 + (c & 1))) = lo;
@@ -929,9 +929,11 @@ int srf_x3w_pack2_launch(const float* const* w, char* const* dst, char* const* d
                          hipStream_t st) {
   return srf_x3w_pack_launch_any(w, dst, Cout, Cin, n, st, false, dst16);
 }
-// fp16 parts (NP 4): the same image layout and size as the bf16 two-part image
-int srf_x3w_pack_f16_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st) {
-  return srf_x3w_pack_launch_any(w, dst, Cout, Cin, n, st, true);
+// fp16 parts (NP 4): the same image layout and size as the bf16 two-part image; dst16 (optional): the paired-block layout of the
+// same parts behind it (what the fused pair of the training forward streams, srf_pwconv_x3f.hip F16)
+int srf_x3w_pack_f16_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st,
+                            char* const* dst16) {
+  return srf_x3w_pack_launch_any(w, dst, Cout, Cin, n, st, true, dst16);
 }
 
 // fuse_wd != null: the mask epilogue fused with the decoder's contraction (EPI 4; pro 3, mask epilogue, fuse_M <= 64)

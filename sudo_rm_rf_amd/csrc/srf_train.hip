@@ -277,9 +277,21 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
   float* enc = (float*)(sv + t.enc);
   rc = srf_encoder(wav, P[0], enc, slot(0), Bt, p->A, p->T, N, K, L, stream);
   if (rc) return rc;
+  // Round 5: like srf_forward, the B = 256 Improved models run bottleneck + proj_1x1(0) and res_conv(i) + proj_1x1(i + 1) as ONE
+  // launch each (srf_pwconv_x3f.hip on the two-fp16-part images: both outputs bit-identical to the two launches; both are saved
+  // activations anyway -- the residual stream and the block's y1).  Debug flag 1 = without.
+  bool y1_ready = false;          // block i's y1 (and its statistics) came out of the pair that ended block i - 1
+  auto y1_of = [&](int i) { return (float*)(sv + t.blk0 + t.blk_stride * i + t.y1); };
+  auto pu_of = [&](int i) { return P + p->p_block0 + (size_t)i * p->p_block_stride + p->p_ublock_off; };
   {
     srf_norm ln{slot(0), P[1], P[2], nullptr};
-    rc = srf_pw_conv_packed3(enc, P[3], pk_bottleneck, P[4], xbuf(0), Bt, N, B, L, &ln, nullptr, nullptr, stream);
+    if (!gc && pk_bottleneck && pk_proj[0] && srf_pw_conv_pair_packed3_supported(Bt, N, B, nC, (int)L)) {
+      rc = srf_pw_conv_pair_packed3(enc, pk_bottleneck, P[4], xbuf(0), &ln, nullptr, pk_proj[0], pu_of(0)[1], y1_of(0), slot(1), Bt, N,
+                                    B, nC, (int)L, stream);
+      y1_ready = true;
+    } else {
+      rc = srf_pw_conv_packed3(enc, P[3], pk_bottleneck, P[4], xbuf(0), Bt, N, B, L, &ln, nullptr, nullptr, stream);
+    }
     if (rc) return rc;
   }
   // fused pyramid with level outputs (register-resident kernels only); its scratch lives in the backward's gradient
@@ -316,10 +328,11 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
       xin = u;
       s0 += 1;
     }
-    if (!tac_norm_fused) {
+    if (!tac_norm_fused && !y1_ready) {
       rc = srf_pw_conv_packed3(xin, Pu[0], pk_proj[i], Pu[1], y1, Bg, nB, nC, L, nullptr, nullptr, slot(s0), stream);
       if (rc) return rc;
     }
+    y1_ready = false;
     // The pyramid: the two fused passes of the inference path with the per-level conv outputs d_k and their
     // statistics written on the side (what the backward reads) when the register-resident kernels cover the shape;
     // otherwise D depthwise kernels + the merge kernel.
@@ -374,7 +387,13 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
     }
     const float* const* Pf = Pu + 5 + 4 * D;
     srf_norm fn{slot(s0 + 1 + D), Pf[0], Pf[1], Pf[2]};
-    rc = srf_pw_conv_packed3(merged, Pf[3], pk_res[i], Pf[4], xbuf(i + 1), Bg, nC, nB, L, &fn, xin, nullptr, stream);
+    if (i + 1 < U && !gc && pk_res[i] && pk_proj[i + 1] && srf_pw_conv_pair_packed3_supported(Bg, nC, nB, nC, (int)L)) {
+      rc = srf_pw_conv_pair_packed3(merged, pk_res[i], Pf[4], xbuf(i + 1), &fn, xin, pk_proj[i + 1], pu_of(i + 1)[1], y1_of(i + 1),
+                                    slot(1 + (i + 1) * p->slots_per_block), Bg, nC, nB, nC, (int)L, stream);
+      y1_ready = true;
+    } else {
+      rc = srf_pw_conv_packed3(merged, Pf[3], pk_res[i], Pf[4], xbuf(i + 1), Bg, nC, nB, L, &fn, xin, nullptr, stream);
+    }
     if (rc) return rc;
   }
   const float* const* Pt = P + p->p_tail;

@@ -163,6 +163,24 @@ def pw_conv_pair(x, packed1, bias1, in_sums, in_gamma, in_beta, in_prelu, residu
     return y, y2
 
 
+def pw_conv_pair3_supported(Bt, Cin1, Cmid, Cout2, L):
+    return bool(_lib.load().srf_pw_conv_pair_packed3_supported(Bt, Cin1, Cmid, Cout2, L))
+
+
+def pw_conv_pair3(x, packed3_1, bias1, in_sums, in_gamma, in_beta, in_prelu, residual, packed3_2, bias2, Cmid, Cout2, out_sums2=None):
+    """The training forward's fused pair (srf_pw_conv_pair_packed3): pw_conv_pair on the two-fp16-part images of pack3_pw_weight."""
+    dev = _chk(x, packed3_1, bias1, in_sums, in_gamma, in_beta, in_prelu, residual, packed3_2, bias2, out_sums2)
+    Bt, Cin1, L = x.shape
+    y = torch.empty((Bt, Cmid, L), dtype=torch.float32, device=dev)
+    y2 = torch.empty((Bt, Cout2, L), dtype=torch.float32, device=dev)
+    rc = _lib.load().srf_pw_conv_pair_packed3(_lib.ptr(x), _lib.ptr(packed3_1), _lib.ptr(bias1), _lib.ptr(y),
+                                              _norm(in_sums, in_gamma, in_beta, in_prelu), _lib.ptr(residual), _lib.ptr(packed3_2),
+                                              _lib.ptr(bias2), _lib.ptr(y2), _lib.ptr(out_sums2), Bt, Cin1, Cmid, Cout2, L,
+                                              _lib.current_stream(dev))
+    _lib.check(rc, "srf_pw_conv_pair_packed3")
+    return y, y2
+
+
 def dwconv5(x, weight, bias, stride, in_sums=None, in_gamma=None, in_beta=None, in_prelu=None,
             out_sums=None):
     """depthwise k=5 conv.  x [Bt,C,Lin], weight [C,1,5] -> [Bt,C,Lout]."""

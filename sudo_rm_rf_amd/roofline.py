@@ -296,13 +296,23 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, dgrad_pair
 
     # ---- forward (training): GEMMs on the fp16 two-part split kernel (x3w4), fused pyramid with saved levels, un-fused tail
     add("encoder", f * (A * T + N * L), 2.0 * Bt * N * A * K * L)
-    add("pw_conv_x3w4<1>", f * L * (N + B), 2.0 * Bt * N * B * L)
-    add("pw_conv_x3w4<0>", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)
+    # round 5: with the pairs (same condition as the backward's), the forward's res_conv(i) + proj_1x1(i + 1) are U - 1 launches
+    # of the fp16-part pair kernel, bottleneck + proj_1x1(0) one more when N fits the kernel (<= 512): only the last res_conv stays
+    head_pair = bool(npair) and N % 64 == 0 and 128 <= N <= 512
+    if head_pair:
+        add("pw_pair_x3f4<1>", f * L * (N + B + C), 2.0 * Bt * (N * B + B * C) * L)
+    else:
+        add("pw_conv_x3w4<1>", f * L * (N + B), 2.0 * Bt * N * B * L)
+    nproj = U - npair - (1 if head_pair else 0)
+    if nproj:
+        add("pw_conv_x3w4<0>", nproj * f * L * (B + C), nproj * 2.0 * Bt * B * C * L)
+    if npair:
+        add("pw_pair_x3f4<2>", npair * f * L * (C + 2 * B + C), npair * 2 * 2.0 * Bt * B * C * L)
     dw = 2.0 * 5 * Bt * C * lev_sum
     add("pyramid_moments", U * f * C * L, U * dw)
     add("pyramid_finalize", U * 8.0 * Bt * C * D * 5)
     add("pyramid_merge_save", U * f * C * (2 * L + lev_sum), U * (dw + 2.0 * D * Bt * C * L))     # pass 2 + the levels on the side
-    add("pw_conv_x3w4<2>", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L)
+    add("pw_conv_x3w4<2>", (U - npair) * f * L * (C + 2 * B), (U - npair) * 2.0 * Bt * B * C * L)
     add("pw_conv_x3w4<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
     add("mask_apply", f * L * (2 * SN + N), 2.0 * Bt * SN * L)
     # decoder (stand-alone form): weight transpose, frame GEMM S N -> S K, overlap-add

@@ -456,6 +456,51 @@ def test_pw_conv_fp16_split_is_loud_beyond_its_range():
     assert float((exact.double() - want2).abs().max()) <= 1e-5 * float(want2.abs().max())
 
 
+@pytest.mark.parametrize("Bt,Cin1,Cout2,L", [(32, 512, 512, 3200), (12, 512, 512, 3200), (24, 256, 384, 1604)])
+@pytest.mark.parametrize("pro", [1, 2])
+def test_pw_conv_pair_fp16_parts_is_bitwise_the_two_training_launches(Bt, Cin1, Cout2, L, pro):
+    """srf_pw_conv_pair_packed3 (round 5: the training forward's fused pair, operands on two fp16 parts) against the two
+    srf_pw_conv_packed3 launches it replaces: both output tensors BIT FOR BIT, the statistics to rounding, and against fp64 at
+    the exact-fp32 class."""
+    from sudo_rm_rf_amd import ops
+    ops.set_kernel_mode(0)
+    Cmid = 256
+    if not ops.pw_conv_pair3_supported(Bt, Cin1, Cmid, Cout2, L):
+        pytest.skip("shape not served on this device")
+    x = dev32(rnd(Bt, Cin1, L, seed=150, scale=1.3, shift=0.2))
+    w1, b1 = dev32(rnd(Cmid, Cin1, 1, seed=151, scale=Cin1 ** -0.5)), dev32(rnd(Cmid, seed=152, scale=0.2))
+    w2, b2 = dev32(rnd(Cout2, Cmid, 1, seed=153, scale=Cmid ** -0.5)), dev32(rnd(Cout2, seed=154, scale=0.2))
+    res = dev32(rnd(Bt, Cmid, L, seed=155)) if pro == 2 else None
+    gamma, beta = rnd(Cin1, seed=156, scale=0.3, shift=1.0), rnd(Cin1, seed=157, scale=0.3)
+    xin = x.double().cpu()
+    kw = dict(in_sums=sums64(xin).to(DEV), in_gamma=dev32(gamma), in_beta=dev32(beta))
+    xin = gln64(xin, gamma, beta)
+    slope = None
+    if pro == 2:
+        slope = dev32(torch.tensor([0.17], dtype=torch.float64))
+        kw.update(in_prelu=slope)
+        xin = torch.where(xin >= 0, xin, 0.17 * xin)
+    want1 = F.conv1d(xin, w1.double().cpu(), b1.double().cpu())
+    if res is not None:
+        want1 = want1 + res.double().cpu()
+    p1, p2 = ops.pack3_pw_weight(w1), ops.pack3_pw_weight(w2)
+    with ops.kernel_trace(DEV) as tr:
+        y_ref = ops.pw_conv3(x, w1, b1, p1, residual=res, **kw)
+        sums_ref = ops.new_sums(Bt, DEV)
+        y2_ref = ops.pw_conv3(y_ref, w2, b2, p2, out_sums=sums_ref)
+    assert tr.names == {"pw_conv_x3w4<%d>" % pro, "pw_conv_x3w4<0>"}, tr.names
+    sums = ops.new_sums(Bt, DEV)
+    with ops.kernel_trace(DEV) as tr:
+        y, y2 = ops.pw_conv_pair3(x, p1, b1, kw["in_sums"], kw["in_gamma"], kw["in_beta"], slope, res, p2, b2, Cmid, Cout2, out_sums2=sums)
+    assert tr.names == {"pw_pair_x3f4<%d>" % pro}, tr.names
+    assert torch.equal(y, y_ref), "y: %d values differ" % int((y != y_ref).sum())
+    assert torch.equal(y2, y2_ref), "y2: %d values differ" % int((y2 != y2_ref).sum())
+    want2 = F.conv1d(y_ref.double().cpu(), w2.double().cpu(), b2.double().cpu())
+    check(y, want1, 2e-5, "fp16 pair: y")
+    check(y2, want2, 2e-5, "fp16 pair: y2")
+    check_sums(sums, y2.double().cpu(), "fp16 pair: statistics of y2")
+
+
 def test_pw_conv_packed3_refuses_an_image_of_the_other_format():
     """The packed3 image's format (two fp16 parts | three bf16 parts) is fixed when it is packed; a launch under the other
     setting of debug flag 16384 must fail with an error instead of reinterpreting the bits."""

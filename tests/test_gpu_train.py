@@ -217,12 +217,13 @@ def test_fast_training_forward_flag():
     assert (num / den) ** 0.5 <= 2e-2          # whole-gradient relative error (measured 3e-3)
 
 
-def test_backward_data_gradient_pairs_are_bitwise_the_separate_launches():
+def test_training_step_with_and_without_fused_pairs():
     """Round 5: in the B = 256 Improved models srf_backward runs the data gradients of proj_1x1(i) and res_conv(i - 1) as ONE
     launch (srf_pw_conv_pair without prologue: g_x(i) = W_p^T g_y1 + g_x(i + 1), then W_r^T g_x(i) from registers).  Both of its
-    output tensors are bit-identical to the two GEMM launches, nothing else on the step changes: every parameter gradient TENSOR must
-    be bit-identical with and without the pairs (debug flag 1; the scalar PReLU-slope gradients are atomic sums over a whole launch
-    and only reproduce to rounding in any two runs); the profiler proves U - 1 pairs ran."""
+    output tensors are bit-identical to the two GEMM launches (measured with the forward's pairs off: every gradient tensor bitwise
+    equal).  The training FORWARD runs bottleneck + proj_1x1(0) and res_conv(i) + proj_1x1(i + 1) as pairs on fp16 parts
+    (srf_pw_conv_pair_packed3): output tensors bit-identical (test_gpu_ops.py), statistics to rounding.  So the whole step with and
+    without the pairs (debug flag 1) agrees to rounding; the profiler proves U forward pairs and U - 1 backward pairs ran."""
     import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib
     from sudo_rm_rf_amd import ops
     cfg = ModelConfig("improved", 256, 512, 3, 4, 21, 256, 2)
@@ -242,16 +243,27 @@ def test_backward_data_gradient_pairs_are_bitwise_the_separate_launches():
                 loss_fn(model(mix), tgt).backward()
             npair = sum(1 for k, _ in tr.launches if k == "pw_pair_x3f<0>")
             assert npair == (cfg.num_blocks - 1 if flags == 0 else 0), (flags, npair, sorted(tr.names))
+            # the forward's pairs (fp16 parts): bottleneck + proj_1x1(0), res_conv(i) + proj_1x1(i + 1)
+            nfwd = sum(1 for k, _ in tr.launches if k.startswith("pw_pair_x3f4<"))
+            assert nfwd == (cfg.num_blocks if flags == 0 else 0), (flags, nfwd, sorted(tr.names))
             grads[flags] = {k: p.grad.clone() for k, p in model.state_dict(keep_vars=True).items()}
     finally:
         ops.set_debug_flags(0)
+    worst_t, worst_s = ("", 0.0), ("", 0.0)
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
         assert torch.isfinite(a).all(), k
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
         if a.numel() > 1:
-            assert torch.equal(a, b), k
-        else:       # PReLU slopes: one scalar summed by atomics over every block of a launch -- not bit-reproducible run to run
-            assert abs(float(a) - float(b)) <= 2e-5 * max(abs(float(b)), 1e-6), (k, float(a), float(b))
+            worst_t = max(worst_t, (k, err), key=lambda kv: kv[1])
+        else:
+            worst_s = max(worst_s, (k, err), key=lambda kv: kv[1])
+    print("step with / without pairs: worst tensor %s %.2e of its scale; worst scalar (PReLU slope) %s %.2e" % (worst_t + worst_s))
+    # The pairs' OUTPUT TENSORS are bit-identical to the separate launches; the GlobLN statistics the forward pairs emit agree to
+    # rounding (other tile shape), which moves a few PReLU inputs across the kink: gradient tensors to ~1e-5 of their scale, the
+    # scalar slope gradients (sums over ~1e7 terms; the reference's own fp32 run carries 1e-2 there) to ~1e-3.
+    assert worst_t[1] <= 2e-4, worst_t
+    assert worst_s[1] <= 1e-2, worst_s
 
 
 def test_fused_clip_adam_state_dict_round_trips_with_torch_adam():

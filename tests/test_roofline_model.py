@@ -76,17 +76,20 @@ def test_training_byte_and_flop_model():
     assert fam3["tac_bwd_mfma"][0] > 8 * 4.0 * 32 * L * 2 * 16 * 48
     ks3 = sum(b for b, _ in fam3.values())
     assert 1.0 < ks3 / (32 * R.train_bytes_per_example(**d3)) < 2.5
-    for name in ("pw_conv_x3w4<0>", "pw_conv_x3w4<2>", "pw_conv_x3w<0>", "pw_wgrad", "dwconv5_bwd", "gln_bwd_apply", "gln_bwd_reduce",
-                 "pyramid_merge_save", "pyramid_moments", "clip_adam"):
+    for name in ("pw_pair_x3f4<1>", "pw_pair_x3f4<2>", "pw_conv_x3w4<2>", "pw_conv_x3w<0>", "pw_wgrad", "dwconv5_bwd", "gln_bwd_apply",
+                 "gln_bwd_reduce", "pyramid_merge_save", "pyramid_moments", "clip_adam"):
         assert fam[name][0] > 0, name
+    assert "pw_conv_x3w4<0>" not in fam and "pw_conv_x3w4<1>" not in fam      # (cfg 2: every proj_1x1 and the bottleneck ride in a pair)
     # round 5: U - 1 data-gradient pairs at the bench shape (B = 256, 800 tiles per launch); none at cfg 4 (B = 512) or at batch 4
     assert fam["pw_pair_x3f<0>"][0] == 15 * 4.0 * 32 * L * (512 + 2 * 256 + 512)
     assert "pw_pair_x3f<0>" not in R.train_family_model(Bt=32, **d4) and "pw_pair_x3f<0>" not in R.train_family_model(Bt=4, **d2)
     unpaired = R.train_family_model(Bt=32, dgrad_pairs=False, **d2)
-    assert sum(b for b, _ in unpaired.values()) - sum(b for b, _ in fam.values()) == 15 * 4.0 * 32 * L * 256     # the re-read of g_x
+    # what the pairs save: the re-read of g_x (15 backward pairs) and of the 256-channel residual stream (15 + 1 forward pairs)
+    assert sum(b for b, _ in unpaired.values()) - sum(b for b, _ in fam.values()) == (15 + 16) * 4.0 * 32 * L * 256
     assert sum(fl for _, fl in unpaired.values()) == sum(fl for _, fl in fam.values())
     # the forward GEMMs' bytes are the inference launch model's (same tensors): U x 4 Bt L (B + C) for proj_1x1
-    assert fam["pw_conv_x3w4<0>"][0] == 16 * 4.0 * 32 * L * (256 + 512)
+    assert unpaired["pw_conv_x3w4<0>"][0] == 16 * 4.0 * 32 * L * (256 + 512)
+    assert fam["pw_pair_x3f4<2>"][0] == 15 * 4.0 * 32 * L * (512 + 2 * 256 + 512)
     # what this kernel set must move is more than the fusion-minimal figure (saved levels, separate norm passes), but < 2 x it
     ks = sum(b for b, _ in fam.values())
     assert 1.0 < ks / (32 * R.train_bytes_per_example(**d2)) < 2.0
