@@ -27,6 +27,9 @@
 // the statistics (fp64 buckets of fp32 partial sums) agree to rounding.
 // Shapes: conv 1 Cout = 256 (one m-tile: the block holds every k row of conv 2), K1 % 64 == 0, 128 <= K1 <= 512; conv 2
 // C2 % 128 == 0, C2 <= 512; L % 4 == 0; Bt <= 512; the activation tensor within 32-bit buffer reach.
+// Three users: srf_forward (PRO 1 / 2, bf16 parts: bottleneck / res_conv + the next proj_1x1), srf_forward_train (the same pairs
+// on two fp16 parts, F16: bit-identical to srf_pwconv_x3w.hip NP = 4) and srf_backward (PRO 0, bf16 parts: the data gradients
+// W_proj^T g + skip gradient, then W_res^T of it).
 #include <type_traits>
 
 #include "srf_pw.h"

@@ -943,7 +943,7 @@ int srf_pw_x3w_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t s
   return srf_pw_x3w_launch_any(a, wpack, pro, nullptr, nullptr, 0, st);
 }
 // three-part operands, six MFMAs per product block (the training forward); wpack3: srf_x3w_pack3_launch's image
-// two fp16 parts, three MFMAs per product block (experiment for the training forward); wpack: srf_x3w_pack_f16_launch's image
+// two fp16 parts, three MFMAs per product block (the training forward's default); wpack: srf_x3w_pack_f16_launch's image
 int srf_pw_x3w4_launch(const PwArgs& a, const char* wpack, int pro, hipStream_t st) {
   return srf_pw_x3w_launch_any(a, wpack, pro, nullptr, nullptr, 0, st, 4);
 }
