@@ -127,6 +127,7 @@ int srf_profile_timeline(int i, const char** name, float* t_ms, int* stream_inde
  *   1<<23    fused conv pair with every counted wait of its DMA pipeline as a full drain (bisection aid, same results)
  *   1<<22    TAC forward / backward on the VALU kernels instead of the MFMA forms (n = 16, G = 16)
  *   1<<24    TAC forward on the generic kernel (no lane-per-time-step form)      1<<26   its lane form with four tiles per block
+ *   1<<25    weight-gradient partials folded by one chain per output (rounds 3-4) instead of four groups per output (round 5)
  *   1<<27    64-bit pointer loads in the 128 x 128 GEMM (no buffer loads)
  *   1<<28    training forward on the split-bf16 GEMMs (faster; gradients then differ from the reference by ~3e-3)
  *   1<<29 / 1<<30  chunked depthwise-backward / scalar GlobLN-backward kernels and no backward fusion

@@ -375,6 +375,67 @@ __global__ __launch_bounds__(256) void srf_wgrad_reduce2_kernel(const float* __r
   }
 }
 
+// The same fold with four times the parallelism (round 5): a 256 x 512 gradient is 32 K float4 outputs = 129 blocks of the kernel
+// above, every thread walking all P = 64 partials of its output one dependent-latency load after the other -- 18-21 us for 33 MB
+// (1.7 TB/s), 36 times per cfg-2 step.  Here a block is 4 groups x 64 outputs: group g sums the partials [g P/4, (g + 1) P/4) of
+// its output, the groups' sums are folded through LDS in group order (deterministic; the summation ORDER differs from the
+// kernel above: ((p0..p15) + (p16..p31)) + ... instead of p0 + p1 + ...).
+__global__ __launch_bounds__(256) void srf_wgrad_reduce2g_kernel(const float* __restrict__ part, float* __restrict__ out, int rows,
+                                                                 int cols, int cols_out, int ld_out,
+                                                                 const float* __restrict__ bias_part, float* __restrict__ bias_out,
+                                                                 int P, float beta) {
+  __shared__ float4 red[3][64];
+  const int grp = threadIdx.x >> 6, o = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 64 + o;
+  const int cv = cols_out / 4;
+  const long nw = (long)rows * cv;
+  const int per = (P + 3) >> 2;
+  const int p0 = grp * per, p1 = min(p0 + per, P);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  size_t dst = 0;
+  const bool is_w = i < nw, is_b = !is_w && i < nw + rows;
+  if (is_w) {
+    const int m = (int)(i / cv), n = (int)(i - (long)m * cv) * 4;
+    const size_t src = (size_t)m * cols + n, stride = (size_t)rows * cols;
+    dst = (size_t)m * ld_out + n;
+#pragma unroll 8
+    for (int p = p0; p < p1; ++p) {
+      const float4 t = *reinterpret_cast<const float4*>(part + (size_t)p * stride + src);
+      s.x += t.x;
+      s.y += t.y;
+      s.z += t.z;
+      s.w += t.w;
+    }
+  } else if (is_b) {
+    const int m = (int)(i - nw);
+#pragma unroll 8
+    for (int p = p0; p < p1; ++p) s.x += bias_part[(size_t)p * rows + m];
+  }
+  if (grp) red[grp - 1][o] = s;
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const float4 t = red[g][o];
+      s.x += t.x;
+      s.y += t.y;
+      s.z += t.z;
+      s.w += t.w;
+    }
+    if (is_w) {
+      float4* op = reinterpret_cast<float4*>(out + dst);
+      if (beta != 0.f) {
+        const float4 c = *op;
+        s = make_float4(fmaf(beta, c.x, s.x), fmaf(beta, c.y, s.y), fmaf(beta, c.z, s.z), fmaf(beta, c.w, s.w));
+      }
+      *op = s;
+    } else if (is_b) {
+      const int m = (int)(i - nw);
+      bias_out[m] = beta != 0.f ? fmaf(beta, bias_out[m], s.x) : s.x;
+    }
+  }
+}
+
 // dst [rows][ld] <- sum over P partials [P][rows][cols] (first cols_out columns)
 static int wg_reduce_launch(const float* part, float* out, int rows, int cols, int cols_out, int ld_out, int P,
                             int accumulate, hipStream_t st) {
@@ -494,7 +555,10 @@ extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* i
   if (dbias && !(a.P >= 64 && (long)Cout * dw_cols * 4 <= 65536)) {   // (large outputs: no partial split, one launch for both)
     const bool v4 = (Cin % 4 == 0) && (dw_cols % 4 == 0) && (dw_ld % 4 == 0) && srf_aligned16(a.part) && srf_aligned16(dw);
     const long n = (long)Cout * (dw_cols / (v4 ? 4 : 1)) + Cout;
-    if (v4)
+    if (v4 && a.P >= 16 && !(srf_debug_flags() & (1 << 25)))       // (debug flag 1 << 25: the one-chain fold, A/B)
+      hipLaunchKernelGGL(srf_wgrad_reduce2g_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, dw, Cout, Cin,
+                         dw_cols, dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
+    else if (v4)
       hipLaunchKernelGGL(srf_wgrad_reduce2_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin,
                          dw_cols, dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
     else
