@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-_MAX_PLANS = 8                     # per device (an auto-tuned split forward holds up to 5: whole, two halves, 5:3)
+_MAX_PLANS = 10                    # per device (an auto-tuned split forward holds up to 7: whole, halves, 5:3, 9:7)
 # total bytes of cached workspaces per device: variable-length inference meets a new T on every call, and a cfg-2
 # workspace is 1.6 GB -- the least recently used plans go first once the cap is exceeded (the plan in use never does)
 _MAX_WORKSPACE_BYTES = int(os.environ.get("SRF_MAX_WORKSPACE_GB", "24")) << 30
@@ -424,6 +424,8 @@ class ModelEngine:
             return [(batch,)]
         half = (batch - batch // 2, batch // 2)
         skew = (batch - (3 * batch) // 8, (3 * batch) // 8)
+        mild = (batch - (7 * batch) // 16, (7 * batch) // 16)       # 9 : 7 (round 5: best or equal-best on cfgs 2 and 3,
+        #                                                             profiles/r05_stream_split_sweep.txt)
         if _SPLIT_MODE == "half":
             return [half]
         if ":" in _SPLIT_MODE:          # explicit weights, e.g. "5:3" or "1:1:1" (experiments)
@@ -434,7 +436,11 @@ class ModelEngine:
                 parts.append(min(n, left - (len(wts) - 1 - i)))
                 left -= parts[-1]
             return [tuple(parts)]
-        return [(batch,), half, skew] if skew != half else [(batch,), half]
+        out = [(batch,), half]
+        for c in (skew, mild):
+            if c not in out and min(c) > 0:
+                out.append(c)
+        return out
 
     def _forward_split(self, parts, x, out, table):
         dev = x.device
@@ -468,7 +474,7 @@ class ModelEngine:
             return choice
         cands = self._split_candidates(batch)
         if len(cands) > 1 and _SPLIT_MODE == "auto":
-            # The tune costs 9 extra forwards, a host sync and up to 4 more workspaces: only worth it for a shape that
+            # The tune costs 20 extra forwards, a host sync and up to 6 more workspaces: only worth it for a shape that
             # keeps coming back (a training / benchmark loop), not for variable-length inference where every call
             # brings a new T.  Until a shape has been seen _TUNE_AFTER times it runs un-split on the caller's stream.
             seen = self._seen.get(key, 0) + 1
@@ -485,12 +491,13 @@ class ModelEngine:
                 self._forward_split(parts, x, out, table)          # warm-up (plan creation, first-touch)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(2):
+                for _ in range(4):
                     self._forward_split(parts, x, out, table)
                 e1.record()
                 e1.synchronize()
                 ms = e0.elapsed_time(e1)
-                if best is None or ms < best[0] * 0.985:            # a split must win by > 1.5 % to be chosen
+                # a split must beat the un-split forward by > 1.5 % to be chosen, another split by > 0.5 %
+                if best is None or ms < best[0] * (0.985 if len(best[1]) == 1 else 0.995):
                     best = (ms, parts)
             choice = best[1]
         self._split_choice[key] = choice

@@ -162,7 +162,7 @@ def test_bench_batch_examples_match_reference_golden(manifest, case, batch, fami
         assert sum(v for k, v in count.items() if k.startswith("pw_conv_bf16x3") or k == "pw_conv_mfma") == 0, count
         assert "pw_conv_x3w<3>" not in count and "transpose" not in count, count
         eng.multi_stream = True
-        for parts in eng._split_candidates(batch)[1:]:        # the explicit splits: halves and 5 : 3
+        for parts in eng._split_candidates(batch)[1:]:        # the explicit splits: halves, 5 : 3 and 9 : 7
             out = torch.empty_like(out)
             with torch.no_grad():
                 params = [p.detach() for p in model.state_dict(keep_vars=True).values()]
