@@ -76,6 +76,15 @@ if [[ $PARTS == *c* ]]; then   # completion pass: cfg-3 counters (forward + trai
   timeout 900 python bench.py --steps 50 --warmup 10 > "$OUT/bench_cfg2_improved_u16.json" 2> "$OUT/bench_cfg2.err"
   timeout 900 python bench.py --train --steps 10 --warmup 3 > "$OUT/train_cfg2_improved_u16.json" 2> "$OUT/train_cfg2.err"
 fi
+if [[ $PARTS == *R* ]]; then   # the training step's kernel stats and counter passes again (after a change to its kernel set)
+  for w in cfg2_improved_u16 cfg4_improved_u36_n2048; do
+    prof train_$w --train --workload $w
+    i=0
+    for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES,SQ_INSTS_VALU,SQ_WAIT_INST_LDS,SQ_BUSY_CYCLES,SQ_INSTS_MFMA"; do
+      i=$((i+1)); pmc train_$w $i "$grp" --train --workload $w
+    done
+  done
+fi
 if [[ $PARTS == *T* ]]; then   # the three training lines again (after a change to the training step)
   timeout 900 python bench.py --train --steps 10 --warmup 3 > "$OUT/train_cfg2_improved_u16.json" 2> "$OUT/train_cfg2.err"
   timeout 600 python bench.py --train --workload cfg3_groupcomm_u8 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/train_cfg3_groupcomm_u8.json" 2> "$OUT/train_cfg3.err"

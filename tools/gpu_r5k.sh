@@ -1,4 +1,5 @@
 #!/bin/bash
+# (tools/gpu_r5k.sh: the debug switch it toggles -- paired-block GEMM with one tile per block, 1 << 20 -- was a one-line experiment, not kept)
 set -u
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 for w in cfg4_improved_u36_n2048 cfg5_improved_u36_n4096; do for rep in 1 2; do for fl in 0 1048576; do
