@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256) void srf_wgrad_reduce2_kernel(const float* __r
 // (1.7 TB/s), 36 times per cfg-2 step.  Here a block is 4 groups x 64 outputs: group g sums the partials [g P/4, (g + 1) P/4) of
 // its output, the groups' sums are folded through LDS in group order (deterministic; the summation ORDER differs from the
 // kernel above: ((p0..p15) + (p16..p31)) + ... instead of p0 + p1 + ...).
+// ALIGNED_OUT = false: `out` rows are not 16-byte aligned (a gradient view at an odd offset of the flat gradient buffer: half of
+// a model's weights sit behind a one-element PReLU slope) -- the partials are still read as float4, the result goes out as four
+// dword stores.
+template <bool ALIGNED_OUT>
 __global__ __launch_bounds__(256) void srf_wgrad_reduce2g_kernel(const float* __restrict__ part, float* __restrict__ out, int rows,
                                                                  int cols, int cols_out, int ld_out,
                                                                  const float* __restrict__ bias_part, float* __restrict__ bias_out,
@@ -423,12 +427,21 @@ __global__ __launch_bounds__(256) void srf_wgrad_reduce2g_kernel(const float* __
       s.w += t.w;
     }
     if (is_w) {
-      float4* op = reinterpret_cast<float4*>(out + dst);
-      if (beta != 0.f) {
-        const float4 c = *op;
-        s = make_float4(fmaf(beta, c.x, s.x), fmaf(beta, c.y, s.y), fmaf(beta, c.z, s.z), fmaf(beta, c.w, s.w));
+      if constexpr (ALIGNED_OUT) {
+        float4* op = reinterpret_cast<float4*>(out + dst);
+        if (beta != 0.f) {
+          const float4 c = *op;
+          s = make_float4(fmaf(beta, c.x, s.x), fmaf(beta, c.y, s.y), fmaf(beta, c.z, s.z), fmaf(beta, c.w, s.w));
+        }
+        *op = s;
+      } else {
+        float* op = out + dst;
+        if (beta != 0.f) s = make_float4(fmaf(beta, op[0], s.x), fmaf(beta, op[1], s.y), fmaf(beta, op[2], s.z), fmaf(beta, op[3], s.w));
+        op[0] = s.x;
+        op[1] = s.y;
+        op[2] = s.z;
+        op[3] = s.w;
       }
-      *op = s;
     } else if (is_b) {
       const int m = (int)(i - nw);
       bias_out[m] = beta != 0.f ? fmaf(beta, bias_out[m], s.x) : s.x;
@@ -553,12 +566,18 @@ extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* i
   }
   int rc;
   if (dbias && !(a.P >= 64 && (long)Cout * dw_cols * 4 <= 65536)) {   // (large outputs: no partial split, one launch for both)
-    const bool v4 = (Cin % 4 == 0) && (dw_cols % 4 == 0) && (dw_ld % 4 == 0) && srf_aligned16(a.part) && srf_aligned16(dw);
-    const long n = (long)Cout * (dw_cols / (v4 ? 4 : 1)) + Cout;
-    if (v4 && a.P >= 16 && !(srf_debug_flags() & (1 << 25)))       // (debug flag 1 << 25: the one-chain fold, A/B)
-      hipLaunchKernelGGL(srf_wgrad_reduce2g_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, dw, Cout, Cin,
-                         dw_cols, dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
-    else if (v4)
+    const bool p4 = (Cin % 4 == 0) && (dw_cols % 4 == 0) && srf_aligned16(a.part);      // float4 reads of the partials
+    const bool v4 = p4 && (dw_ld % 4 == 0) && srf_aligned16(dw);                          // ... and float4 stores of the result
+    const bool four_groups = p4 && a.P >= 16 && !(srf_debug_flags() & (1 << 25));        // (debug flag 1 << 25: the one-chain fold, A/B)
+    const long n = (long)Cout * (dw_cols / ((v4 || four_groups) ? 4 : 1)) + Cout;
+    if (four_groups) {
+      if (v4)
+        hipLaunchKernelGGL(srf_wgrad_reduce2g_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, dw, Cout, Cin,
+                           dw_cols, dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
+      else
+        hipLaunchKernelGGL(srf_wgrad_reduce2g_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, dw, Cout, Cin,
+                           dw_cols, dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
+    } else if (v4)
       hipLaunchKernelGGL(srf_wgrad_reduce2_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, dw, Cout, Cin,
                          dw_cols, dw_ld, a.bias_part, dbias, a.P, accumulate ? 1.f : 0.f);
     else
