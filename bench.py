@@ -807,7 +807,10 @@ def main():
         out, dt_local, per_step_ms = timed(args.steps)
     per_rank_ms = [1e3 * t / args.steps for t in D.gather_over_ranks(dt_local, dev)]
     dt = D.max_over_ranks(dt_local, dev)
-    assert out.shape == (batch, kw["num_sources"], T) and bool(torch.isfinite(out).all())
+    # SRF_BENCH_TIMING_ONLY=1: for timing-only kernel variants (debug flags that knowingly compute wrong values, e.g. pyramid pass 1
+    # without one half of its moments): no output checks, and the line says so -- such a line is an A/B instrument, never a result
+    timing_only = os.environ.get("SRF_BENCH_TIMING_ONLY") == "1"
+    assert out.shape == (batch, kw["num_sources"], T) and (timing_only or bool(torch.isfinite(out).all()))
     # Self-check (untimed, product kernels only): the timed forward's outputs against (a) the same forward on one stream
     # and (b) the shape-agnostic generic kernels (kernel mode 1: no MFMA, no fusion, different code everywhere) on the
     # first and last example.  A throughput measured on wrong outputs is worthless; the parity proper is tests/.
@@ -828,7 +831,7 @@ def main():
     self_check = {"max_abs_vs_single_stream": d_single, "max_abs_vs_generic_kernels": d_generic, "output_abs_max": scale}
     self_check["ok"] = not (d_single > 1e-5 * max(scale, 1.0) or d_generic > 1e-3 * max(scale, 1e-3))
     # every rank takes the same branch below (the re-timing contains collectives)
-    any_bad = D.max_over_ranks(0.0 if self_check["ok"] else 1.0, dev) > 0.5
+    any_bad = (not timing_only) and D.max_over_ranks(0.0 if self_check["ok"] else 1.0, dev) > 0.5
     any_generic_bad = D.max_over_ranks(0.0 if d_generic <= 1e-3 * max(scale, 1e-3) else 1.0, dev) > 0.5
     if any_bad and was_multi and not any_generic_bad:
         # the split forward disagrees with the single-stream one: time the single-stream forward instead (its outputs
@@ -845,7 +848,9 @@ def main():
             dt = D.max_over_ranks(dt_local, dev)
             d2 = float((torch.cat([out[:1], out[-1:]]) - generic).abs().max())
         self_check.update(retimed_single_stream=True, max_abs_vs_generic_kernels=d2, ok=d2 <= 1e-3 * max(scale, 1e-3))
-    if D.max_over_ranks(0.0 if self_check["ok"] else 1.0, dev) > 0.5:
+    if timing_only:
+        self_check = {"ok": None, "timing_only": "SRF_BENCH_TIMING_ONLY=1: outputs NOT checked (A/B instrument, not a result)"}
+    elif D.max_over_ranks(0.0 if self_check["ok"] else 1.0, dev) > 0.5:
         raise SystemExit("bench.py self-check failed: %s" % json.dumps(self_check))
     result, dims, ms_per_step, value = forward_result(
         args, variant, kw, T, fs, batch, n_gpus, dt, per_rank_ms, per_step_ms, self_check,

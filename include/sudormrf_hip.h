@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SRF_ABI_VERSION 14
+#define SRF_ABI_VERSION 15
 
 /* GlobLN statistics layout: "sums" = fp64 [groups][SRF_STAT_BUCKETS][2] {sum, sum of squares}; the
  * statistic of a group is the total over its buckets (producers spread their atomics over buckets). */
@@ -416,6 +416,12 @@ int srf_forward_train(const srf_plan* plan, const float* const* params, int num_
 int srf_backward(const srf_plan* plan, const float* const* params, float* const* grads, int num_params,
                  const float* wav, const float* grad_out, const void* saved, size_t saved_bytes, void* scratch,
                  size_t scratch_bytes, void* stream);
+/* srf_backward plus the gradient w.r.t. the INPUT waveform (ABI 15): grad_wav [Bt, in_audio_channels, T], overwritten --
+ * what torch autograd over the reference's forward returns for a mixture that requires grad (improved_sudormrf.py:283-301;
+ * the encoder's Conv1d :247-251 transposed, applied to the encoder-output gradient the backward forms anyway). */
+int srf_backward_wav(const srf_plan* plan, const float* const* params, float* const* grads, int num_params,
+                     const float* wav, const float* grad_out, const void* saved, size_t saved_bytes, void* scratch,
+                     size_t scratch_bytes, float* grad_wav, void* stream);
 
 /* On-GPU online remix augmentation of the training loop (experiments/run_improved_sudormrf.py:150-164): new source j
  * of example b = clean[src_b[j][b], src_s[j]] re-scaled to the energy of clean[b, j]; mix = normalize(sum_j),

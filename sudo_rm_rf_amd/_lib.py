@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first so the extension bi
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # SRF_LIB: an alternative build of the same library (same-box A/B of kernel variants, tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SRF_LIB") or os.path.join(_PKG, "libsudormrf_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 STAT_BUCKETS = 64
 
 SRF_OK = 0
@@ -92,6 +92,7 @@ _PROTOS = {
     "srf_train_scratch_bytes": (_sz, [_vp]),
     "srf_forward_train": (_i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "srf_backward": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "srf_backward_wav": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "srf_tac_bwd_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "srf_tac_bwd": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "srf_online_remix_scratch_bytes": (_sz, [_i, _i]),

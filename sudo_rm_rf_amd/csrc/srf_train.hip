@@ -409,9 +409,27 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
   return srf_decoder(v, Pt[3], out, Bt, p->SA * N, p->SA, K, L, p->T, (float*)(sc + s.dec), stream);
 }
 
+static int backward_impl(const srf_plan* p, const float* const* P, float* const* G, int num_params, const float* wav,
+                         const float* grad_out, const void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                         float* grad_wav, void* stream);
 extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* const* G, int num_params, const float* wav,
                             const float* grad_out, const void* saved, size_t saved_bytes, void* scratch,
                             size_t scratch_bytes, void* stream) {
+  return backward_impl(p, P, G, num_params, wav, grad_out, saved, saved_bytes, scratch, scratch_bytes, nullptr, stream);
+}
+// ... and the gradient w.r.t. the input waveform on top (ABI 15; the reference's autograd produces it when the caller's
+// mixture requires grad, improved_sudormrf.py:283-301 is plain ATen): grad_wav [Bt, in_audio_channels, T] (overwritten) =
+// the encoder's transposed convolution (:247-251,286; the right zero-pad of :303-314 is a crop) of the gradient w.r.t.
+// the encoder output, which the backward forms anyway (mask path + GlobLN path).
+extern "C" int srf_backward_wav(const srf_plan* p, const float* const* P, float* const* G, int num_params, const float* wav,
+                                const float* grad_out, const void* saved, size_t saved_bytes, void* scratch,
+                                size_t scratch_bytes, float* grad_wav, void* stream) {
+  SRF_CHECK_ARG(grad_wav, "srf_backward_wav: null grad_wav");
+  return backward_impl(p, P, G, num_params, wav, grad_out, saved, saved_bytes, scratch, scratch_bytes, grad_wav, stream);
+}
+static int backward_impl(const srf_plan* p, const float* const* P, float* const* G, int num_params, const float* wav,
+                         const float* grad_out, const void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                         float* grad_wav, void* stream) {
   SRF_CHECK_ARG(p && P && G && wav && grad_out && saved && scratch, "srf_backward: null pointer");
   SRF_CHECK_ARG(num_params == p->n_params, "srf_backward: expected %d parameter tensors, got %d", p->n_params, num_params);
   int rc = train_check(p, "srf_backward");
@@ -674,5 +692,9 @@ extern "C" int srf_backward(const srf_plan* p, const float* const* P, float* con
   // ---- encoder weight                                           :247-251,286
   rc = srf_frames_gather(wav, frames, Bt, p->A, p->T, K, h, h, L, p->A * K, stream);
   if (rc) return rc;
-  return srf_pw_wgrad(genc, frames, nullptr, Bt, p->A * K, N, L, G[0], nullptr, 1, wg, stream);
+  rc = srf_pw_wgrad(genc, frames, nullptr, Bt, p->A * K, N, L, G[0], nullptr, 1, wg, stream);
+  if (rc || !grad_wav) return rc;
+  // ---- input waveform: g_wav[b,a,t] = sum_{n,l,k: h l + k - h = t} W_e[n,a,k] g_enc[b,n,l]   (the decoder's arithmetic with
+  // the encoder's weight [N, A, K] in ConvTranspose1d layout; its scratch fits the forward decoder's: N <= S A N, A <= S A)
+  return srf_decoder(genc, P[0], grad_wav, Bt, N, p->A, K, L, p->T, fp(s.dec), stream);
 }

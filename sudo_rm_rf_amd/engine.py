@@ -117,7 +117,8 @@ class _TrainStep(torch.autograd.Function):
     """SuDORMRF.forward under autograd: srf_forward_train keeps the activations the backward needs in one
     `saved` buffer, srf_backward turns d loss / d output into all parameter gradients (one flat buffer, returned
     as per-parameter views).  Replaces torch autograd over the reference's ~1.8 k ATen nodes
-    (run_improved_sudormrf.py:167-172)."""
+    (run_improved_sudormrf.py:167-172).  A mixture that requires grad also gets its gradient (srf_backward_wav: the encoder's
+    transposed convolution of the encoder-output gradient), as the reference's autograd would return it."""
 
     @staticmethod
     def forward(ctx, engine, out_ch, wav, *params):
@@ -136,6 +137,7 @@ class _TrainStep(torch.autograd.Function):
                                        saved_bytes, _lib.ptr(scratch), scratch_bytes, _lib.current_stream(dev))
             _lib.check(rc, "srf_forward_train")
         ctx.plan, ctx.saved_buf, ctx.x, ctx.engine = plan, saved, x, engine
+        ctx.wav_dtype = wav.dtype
         ctx.save_for_backward(*params)
         engine.last_plan = plan
         return out
@@ -157,12 +159,21 @@ class _TrainStep(torch.autograd.Function):
             scratch = plan.train_scratch()
             ptab = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
             gtab = (C.c_void_p * len(params))(*[t.data_ptr() for t in grads])
-            rc = lib.srf_backward(plan.handle, ptab, gtab, len(params), _lib.ptr(x), _lib.ptr(g), _lib.ptr(saved),
-                                  saved.numel(), _lib.ptr(scratch), scratch.numel(), _lib.current_stream(dev))
+            gwav = None
+            if ctx.needs_input_grad[2]:
+                gwav = torch.empty_like(x)
+                rc = lib.srf_backward_wav(plan.handle, ptab, gtab, len(params), _lib.ptr(x), _lib.ptr(g), _lib.ptr(saved),
+                                          saved.numel(), _lib.ptr(scratch), scratch.numel(), _lib.ptr(gwav),
+                                          _lib.current_stream(dev))
+            else:
+                rc = lib.srf_backward(plan.handle, ptab, gtab, len(params), _lib.ptr(x), _lib.ptr(g), _lib.ptr(saved),
+                                      saved.numel(), _lib.ptr(scratch), scratch.numel(), _lib.current_stream(dev))
             _lib.check(rc, "srf_backward")
         ctx.saved_buf = None
         ctx.engine.last_flat_grad = flat      # (autograd adopts the views below as the .grad tensors: this IS the gradient)
-        return (None, None, None) + tuple(grads)
+        if gwav is not None and gwav.dtype != ctx.wav_dtype:
+            gwav = gwav.to(ctx.wav_dtype)
+        return (None, None, gwav) + tuple(grads)
 
 
 def _weights(module):
@@ -280,10 +291,6 @@ class ModelEngine:
                 raise _lib.SrfError("all parameters must be contiguous float32 on %s" % wav.device)
         if wav.shape[0] == 0 or wav.shape[-1] == 0:
             raise RuntimeError("empty input %s" % (tuple(wav.shape),))
-        if wav.requires_grad:
-            # srf_backward produces the parameter gradients only; returning None here would be a silent zero
-            raise NotImplementedError("the HIP training step does not produce the gradient w.r.t. the input waveform "
-                                      "(no runner of the reference needs it): detach the input")
         return _TrainStep.apply(self, module.num_sources * expected_channels, wav, *params)
 
     def run(self, module, wav, expected_channels):

@@ -71,6 +71,11 @@ def main():
                 return f
 
             variants = {"two_x3w": two(0), "two_x3p": two(8192), "pair": pair(0), "pair_drain": pair(1 << 23)}
+            # PAIR_FLAGS="name=flags,...": extra variants of the pair under diagnostic flags (round 6: 1 << 18 the CU's second
+            # block at s_setprio 1, 1 << 19 / 1 << 20 that block half a k-step / half a tile late)
+            for item in filter(None, os.environ.get("PAIR_FLAGS", "").split(",")):
+                nm, fl = item.split("=")
+                variants["pair_" + nm] = pair(int(fl, 0))
             ref = variants["two_x3w"]()
             equal = {}
             for name, fn in variants.items():
