@@ -941,8 +941,9 @@ def main():
         rl["measured"] = ("avg_launch_us, achieved, frac and the `kernels` table: per-kernel durations from a SINGLE-STREAM "
                           "instrumented pass of the whole batch (SRF_STREAM_SPLIT=off equivalent); value / ms_per_step / "
                           "forward_roofline: the timed region, which runs the auto-tuned two-stream split " +
-                          str(result["config"].get("stream_split")) + " (per-kernel durations under that co-residency: "
-                          "profiles/r05_cfg2_two_stream_timeline.txt, tools/two_stream_events.py)")
+                          str(result["config"].get("stream_split")) + " (per-kernel durations under co-residency are measured by "
+                          "tools/two_stream_events.py for whatever split IT times; committed runs: profiles/*two_stream_timeline*.txt, "
+                          "each stating its split)")
         rl["share_of_forward"] = kd["ms_per_forward"] / sum(v["ms_per_forward"] for v in kernels.values())
         result["roofline"] = rl
         result["kernels"] = kernels

@@ -215,7 +215,7 @@ int srf_pw_conv_packed(const float* x, const float* w, const void* w_packed, con
  *     y2 = W2 y + bias2,  out_sums2 (nullable) += {sum, sumsq} of y2          (proj_1x1 of the next block, :205)
  * Results are BIT-IDENTICAL to srf_pw_conv_packed(x -> y) followed by srf_pw_conv_packed(y -> y2) (statistics: to rounding).
  * w1_packed / w2_packed: buffers of srf_pack_pw_weights for [Cmid, Cin1] / [Cout2, Cmid].  srf_pw_conv_pair_supported: the
- * shapes served (Cmid = 256, Cin1 % 64 == 0, 128 <= Cin1 <= 512, Cout2 % 128 == 0, Cout2 <= 512, L % 4 == 0, Bt <= 512, at least as
+ * shapes served (Cmid = 256, Cin1 % 64 == 0, 128 <= Cin1 <= 512, Cout2 % 128 == 0, Cout2 <= 512, L % 4 == 0, at least as
  * many 128-column tiles as CUs) under the default kernel mode; srf_forward uses the pair wherever this says 1. */
 int srf_pw_conv_pair_supported(int Bt, int Cin1, int Cmid, int Cout2, int L);
 int srf_pw_conv_pair(const float* x, const void* w1_packed, const float* bias1, float* y, const srf_norm* in_norm,
@@ -232,6 +232,10 @@ int srf_pw_conv_pair(const float* x, const void* w1_packed, const float* bias1, 
  * prologue (the res_conv form).  w_packed3 = NULL or a shape / launch size the kernel does not take: exactly srf_pw_conv. */
 size_t srf_packed3_pw_weight_bytes(int Cout, int Cin);
 int srf_pack3_pw_weights(const float* const* w, void* const* packed, const int* Cout, const int* Cin, int n, void* stream);
+/* The library remembers, per (device, address), in which of the two forms a packed3 image was written (so that a launch under
+ * the other setting of flag 16384 is refused instead of reading a foreign layout).  A pack replaces every record its extent
+ * overlaps; srf_pack3_forget drops the record of a buffer the caller frees or re-uses for other data (ABI 15). */
+void srf_pack3_forget(const void* packed);
 int srf_pw_conv_packed3(const float* x, const float* w, const void* w_packed3, const float* bias, float* y, int Bt, int Cin,
                         int Cout, int L, const srf_norm* in_norm, const float* residual, double* out_sums, void* stream);
 /* The fused pair of the training forward (ABI 14): srf_pw_conv_pair on the two-fp16-part images -- y and y2 BIT-IDENTICAL to

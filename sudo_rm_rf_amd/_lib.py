@@ -67,6 +67,7 @@ _PROTOS = {
     "srf_pw_conv_pair_packed3": (_i, [_vp, _vp, _vp, _vp, C.POINTER(srf_norm), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srf_packed3_pw_weight_bytes": (_sz, [_i, _i]),
     "srf_pack3_pw_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
+    "srf_pack3_forget": (None, [_vp]),
     "srf_pw_conv_packed3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp, _vp]),
     "srf_pit_sisdr_work_bytes": (_sz, [_i, _i]),
     "srf_perm_inv_sisdr_work_bytes": (_sz, [_i, _i]),

@@ -19,8 +19,9 @@
 #include "srf_common.h"
 
 #include "srf_pw.h"
+#include <iterator>
+#include <map>
 #include <mutex>
-#include <unordered_map>
 #include <vector>
 
 // ---------------------------------------------------------------------------------------------
@@ -367,11 +368,33 @@ static bool srf_train_f16_split() { return (srf_debug_flags() & 16384) == 0; }
 // with the buffer it is handed is refused with SRF_EINVAL instead of reinterpreting the bits.  (A buffer this process never
 // packed -- e.g. a device-to-device copy of one -- is not in the table and is taken as what the caller says it is.)
 static std::mutex g_pk3_mu;
-static std::unordered_map<unsigned long long, int> g_pk3_format;     // key: device << 56 | address; value: 4 = fp16 x 2, 3 = bf16 x 3
+struct Pk3Entry {
+  int format;       // 4 = fp16 x 2, 3 = bf16 x 3
+  size_t bytes;     // the image's extent: a later pack that overlaps it replaces it
+};
+static std::map<unsigned long long, Pk3Entry> g_pk3_format;          // key: device << 56 | address (ordered: range queries)
 static unsigned long long srf_pk3_key(const void* p) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   return ((unsigned long long)dev << 56) | ((unsigned long long)(size_t)p & ((1ull << 56) - 1));
+}
+// Round 6: entries no longer live for ever.  A pack drops every recorded image its own extent overlaps (an
+// allocator that re-uses a freed address hands it to the next pack or to something else; in the first case the stale record
+// is replaced here), and srf_pack3_forget drops the record of a buffer the caller is about to free or re-use for other data.
+static void srf_pk3_record(const void* p, size_t bytes, int format) {     // (g_pk3_mu held)
+  const unsigned long long k0 = srf_pk3_key(p), k1 = k0 + bytes;
+  auto it = g_pk3_format.lower_bound(k0);
+  if (it != g_pk3_format.begin()) {
+    auto prev = std::prev(it);
+    if (prev->first + prev->second.bytes > k0) it = prev;
+  }
+  while (it != g_pk3_format.end() && it->first < k1) it = g_pk3_format.erase(it);
+  g_pk3_format[k0] = Pk3Entry{format, bytes};
+}
+extern "C" void srf_pack3_forget(const void* packed) {
+  if (!packed) return;
+  std::lock_guard<std::mutex> lk(g_pk3_mu);
+  g_pk3_format.erase(srf_pk3_key(packed));
 }
 size_t srf_x3w_packed3_bytes(int Cout, int Cin);
 int srf_x3w_pack3_launch(const float* const* w, char* const* dst, const int* Cout, const int* Cin, int n, hipStream_t st);
@@ -389,7 +412,7 @@ extern "C" int srf_pack3_pw_weights(const float* const* w, void* const* packed, 
   const bool f16 = srf_train_f16_split();
   {
     std::lock_guard<std::mutex> lk(g_pk3_mu);
-    for (int i = 0; i < n; ++i) g_pk3_format[srf_pk3_key(packed[i])] = f16 ? 4 : 3;
+    for (int i = 0; i < n; ++i) srf_pk3_record(packed[i], srf_packed3_pw_weight_bytes(Cout[i], Cin[i]), f16 ? 4 : 3);
   }
   if (f16) {
     // the fp16 image takes the first half of a packed3 buffer (sized for the three-part image); the second half gets the same
@@ -439,9 +462,9 @@ extern "C" int srf_pw_conv_packed3(const float* x, const float* w, const void* w
   {
     std::lock_guard<std::mutex> lk(g_pk3_mu);
     const auto it = g_pk3_format.find(srf_pk3_key(w_packed3));
-    SRF_CHECK_ARG(it == g_pk3_format.end() || it->second == (f16 ? 4 : 3),
+    SRF_CHECK_ARG(it == g_pk3_format.end() || it->second.format == (f16 ? 4 : 3),
                   "srf_pw_conv_packed3: the weight image was packed as %s but debug flag 16384 now asks for %s -- pack again",
-                  it->second == 4 ? "two fp16 parts" : "three bf16 parts", f16 ? "two fp16 parts" : "three bf16 parts");
+                  it->second.format == 4 ? "two fp16 parts" : "three bf16 parts", f16 ? "two fp16 parts" : "three bf16 parts");
   }
   if (f16) return srf_pw_x3w4_launch(a, reinterpret_cast<const char*>(w_packed3), pro, (hipStream_t)stream);
   return srf_pw_x3w3_launch(a, reinterpret_cast<const char*>(w_packed3), pro, (hipStream_t)stream);
@@ -453,7 +476,7 @@ extern "C" int srf_pw_conv_packed3(const float* x, const float* w, const void* w
 static bool srf_pk3_is_f16(const void* p) {
   std::lock_guard<std::mutex> lk(g_pk3_mu);
   const auto it = g_pk3_format.find(srf_pk3_key(p));
-  return it != g_pk3_format.end() && it->second == 4;
+  return it != g_pk3_format.end() && it->second.format == 4;
 }
 extern "C" int srf_pw_conv_pair_packed3_supported(int Bt, int Cin1, int Cmid, int Cout2, int L) {
   // (kernel mode 2 -- srf_forward_train's -- as well as 0: like srf_pw_conv_packed3, this IS the exact-fp32 class)

@@ -26,7 +26,7 @@
 // residual; the split of y is the split proj_1x1's prologue would make): y AND y2 are BIT-IDENTICAL to the two separate launches;
 // the statistics (fp64 buckets of fp32 partial sums) agree to rounding.
 // Shapes: conv 1 Cout = 256 (one m-tile: the block holds every k row of conv 2), K1 % 64 == 0, 128 <= K1 <= 512; conv 2
-// C2 % 128 == 0, C2 <= 512; L % 4 == 0; Bt <= 512; the activation tensor within 32-bit buffer reach.
+// C2 % 128 == 0, C2 <= 512; L % 4 == 0; the activation tensors within 32-bit buffer reach (srf_x3f_supported).
 // Three users: srf_forward (PRO 1 / 2, bf16 parts: bottleneck / res_conv + the next proj_1x1), srf_forward_train (the same pairs
 // on two fp16 parts, F16: bit-identical to srf_pwconv_x3w.hip NP = 4) and srf_backward (PRO 0, bf16 parts: the data gradients
 // W_proj^T g + skip gradient, then W_res^T of it).
@@ -593,7 +593,8 @@ __global__ __launch_bounds__(256, 2) void srf_pw_x3f_kernel(PwPairArgs a, const 
 bool srf_x3f_supported(int Bt, int K1, int C2, int L) {
   if (K1 % 64 || K1 < 128 || K1 > F_MAX_K1 || C2 % 128 || C2 < 128 || C2 > F_MAX_C2 || L % 4) return false;
   if (Bt < 1) return false;
-  if ((long)Bt * K1 * L * 4 >= (1L << 31) || (long)C2 * L * 4 >= (1L << 31)) return false;
+  // 32-bit buffer reach: x as one resource over the batch; y / the residual (256 rows) and y2 (C2 rows) as one resource per example
+  if ((long)Bt * K1 * L * 4 >= (1L << 31) || (long)C2 * L * 4 >= (1L << 31) || (long)F_BM * L * 4 >= (1L << 31)) return false;
   return true;
 }
 

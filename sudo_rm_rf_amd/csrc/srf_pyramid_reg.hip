@@ -74,18 +74,12 @@ __device__ __forceinline__ void srf_affine_mask(float (&v)[N], float a, float c,
   for (int i = 0; i < N; ++i) v[i] = fmaf(v[i], am, cm);
 }
 
-// SKIP (timing-only instantiations of pass 1, debug flags 1 << 16 / 1 << 17 -- WRONG statistics, for the A/B that prices the
-// two halves of the moments inside the timed forward): 1 = no sum of squares, 2 = no sum
-template <int N, int SKIP = 0>
+template <int N>
 __device__ __forceinline__ void srf_acc_moments(const float (&v)[N], float& s, float& q) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    if constexpr (!(SKIP & 2)) s += v[i];
-    if constexpr (!(SKIP & 1)) q = fmaf(v[i], v[i], q);
-  }
-  if constexpr (SKIP != 0) {   // keep the level's values alive: one of them enters the moments
-    if constexpr (SKIP & 2) s += v[0];
-    if constexpr (SKIP & 1) q = fmaf(v[0], v[0], q);
+    s += v[i];
+    q = fmaf(v[i], v[i], q);
   }
 }
 
@@ -152,7 +146,7 @@ __device__ __forceinline__ void srf_pyr_store_level(float* dst, const float (&v)
 // SAVE (pass 2 only): also write every level's raw conv output d_k -- what the training backward needs -- so the
 // training forward is the same two fused passes instead of D depthwise kernels + a merge kernel (7.75 -> 4.94 C*L of
 // traffic per block).
-template <bool MOMENTS, int CH, bool PERSIST = MOMENTS, bool SAVE = false, int SKIP = 0>
+template <bool MOMENTS, int CH, bool PERSIST = MOMENTS, bool SAVE = false>
 // (no occupancy attribute: pinning 6 wavefronts per SIMD made the persistent pass 1 spill VGPRs to scratch memory)
 __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   __shared__ float4 pyr_strip[MOMENTS ? 1 : 4 * 60 * (CH / 4 + 1)];   // pass 2: store transposition
@@ -297,7 +291,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
   }
   double* mrow = a.mom + (size_t)row * D * 5;
   if (MOMENTS && own) {
-    srf_acc_moments<CH, SKIP>(x0, s1[0], s2[0]);
+    srf_acc_moments<CH>(x0, s1[0], s2[0]);
     srf_pyr_edges<CH>(mrow, x0, ci, nchunks);
   }
   if (D > 1) {
@@ -305,7 +299,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     if (SAVE && own) srf_pyr_store_level<CH / 2>(a.lv_out[1] + (size_t)row * (L >> 1) + (size_t)ci * (CH / 2), x1);
     srf_affine_mask<CH / 2>(x1, lc[1].a, lc[1].c, valid);
     if (MOMENTS && own) {
-      srf_acc_moments<CH / 2, SKIP>(x1, s1[1], s2[1]);
+      srf_acc_moments<CH / 2>(x1, s1[1], s2[1]);
       srf_pyr_edges<CH / 2>(mrow + 5, x1, ci, nchunks);
     }
   }
@@ -314,7 +308,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     if (SAVE && own) srf_pyr_store_level<CH / 4>(a.lv_out[2] + (size_t)row * (L >> 2) + (size_t)ci * (CH / 4), x2);
     srf_affine_mask<CH / 4>(x2, lc[2].a, lc[2].c, valid);
     if (MOMENTS && own) {
-      srf_acc_moments<CH / 4, SKIP>(x2, s1[2], s2[2]);
+      srf_acc_moments<CH / 4>(x2, s1[2], s2[2]);
       srf_pyr_edges<CH / 4>(mrow + 10, x2, ci, nchunks);
     }
   }
@@ -323,7 +317,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     if (SAVE && own) srf_pyr_store_level<CH / 8>(a.lv_out[3] + (size_t)row * (L >> 3) + (size_t)ci * (CH / 8), x3);
     srf_affine_mask<CH / 8>(x3, lc[3].a, lc[3].c, valid);
     if (MOMENTS && own) {
-      srf_acc_moments<CH / 8, SKIP>(x3, s1[3], s2[3]);
+      srf_acc_moments<CH / 8>(x3, s1[3], s2[3]);
       srf_pyr_edges<CH / 8>(mrow + 15, x3, ci, nchunks);
     }
   }
@@ -332,7 +326,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
     if (SAVE && own) srf_pyr_store_level<CH / 16>(a.lv_out[4] + (size_t)row * (L >> 4) + (size_t)ci * (CH / 16), x4);
     srf_affine_mask<CH / 16>(x4, lc[4].a, lc[4].c, valid);
     if (MOMENTS && own) {
-      srf_acc_moments<CH / 16, SKIP>(x4, s1[4], s2[4]);
+      srf_acc_moments<CH / 16>(x4, s1[4], s2[4]);
       srf_pyr_edges<CH / 16>(mrow + 20, x4, ci, nchunks);
     }
   }
@@ -342,7 +336,7 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
       if (SAVE && own) srf_pyr_store_level<CH / 32>(a.lv_out[5] + (size_t)row * (L >> 5) + (size_t)ci * (CH / 32), x5);
       srf_affine_mask<CH / 32>(x5, lc[5].a, lc[5].c, valid);
       if (MOMENTS && own) {
-        srf_acc_moments<CH / 32, SKIP>(x5, s1[5], s2[5]);
+        srf_acc_moments<CH / 32>(x5, s1[5], s2[5]);
         srf_pyr_edges<CH / 32>(mrow + 25, x5, ci, nchunks);
       }
     }
@@ -474,15 +468,8 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
   if (save)
     for (int k = 0; k < a.D; ++k)
       SRF_CHECK_ARG(a.lv_out[k] && srf_aligned16(a.lv_out[k]), "srf_pyramid: level output %d missing / unaligned", k);
-  const int skip = (srf_debug_flags() >> 16) & 3;
   if (CH == 16) {
-    if (moments && persist && skip == 1)
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, true, false, 1>), grid, dim3(256), 0, st, a);
-    else if (moments && persist && skip == 2)
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, true, false, 2>), grid, dim3(256), 0, st, a);
-    else if (moments && persist && skip == 3)
-      hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, true, false, 3>), grid, dim3(256), 0, st, a);
-    else if (moments && persist)
+    if (moments && persist)
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, true>), grid, dim3(256), 0, st, a);
     else if (moments)
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, false>), grid, dim3(256), 0, st, a);

@@ -6,8 +6,9 @@ an iterator over ``(mixtures [B, T], sources [B, S, T])`` float32 tensors ON THE
 (csrc/srf_feeder.hip) reads and crops the batch's WAV files into pinned buffers, one asynchronous copy moves the raw batch,
 and one kernel applies the Dataset's normalisation recipe there; with one process per GPU every rank's feeder deals itself a
 disjoint shard of each global batch (``rank`` / ``world_size``).  ``Dataset[i]`` (the reference's ``__getitem__``: one example,
-CPU tensors) is a batch of one through the same native reader and device kernel.  ``normalize_tensor_wav`` / ``safe_pad``
-only mirror the reference's public helpers; nothing on the feeder's path calls them."""
+CPU tensors) is a batch of one through the same native reader and device kernel -- or, on a host without a GPU, the native
+reader plus the recipe on the host (``normalize_tensor_wav`` / ``safe_pad``, the mirrors of the reference's public helpers);
+nothing on the batch feeder's path calls those two."""
 import ctypes as C
 import glob
 import os
@@ -141,13 +142,11 @@ class Dataset(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         """One example, wham.py:171-217: (mixture [T], sources [S, T]) float32 CPU tensors like the reference returns them.
-        A batch of one through the product path -- the native reader (srf_feeder_read_example) and the device kernel of the
-        batch feeder (srf_feeder_normalize) on the current MI355X -- so it needs the GPU like everything else here; the
-        operation-for-operation CPU restatement of the reference's recipe lives in oracle/feeder_oracle.py (test
-        infrastructure).  The random crop start is drawn like the reference's (time-seeded numpy generator, :173-186)."""
-        if not torch.cuda.is_available():
-            raise _lib.SrfError("Dataset[i] normalises on an MI355X (srf_feeder_normalize); no GPU is visible and there is "
-                                "deliberately no CPU path (use get_generator(...) / this call on a GPU box)")
+        With an MI355X visible: a batch of one through the batch feeder's path -- the native reader (srf_feeder_read_example)
+        and its device kernel (srf_feeder_normalize).  On a host WITHOUT a GPU (round 6; the reference's Dataset is pure host
+        code and is used that way, e.g. to inspect or pre-process a corpus): the same native reader and the recipe's
+        arithmetic on the host (`_getitem_host`) -- data-loader glue, not the model's hot path, which has no CPU form.
+        The random crop start is drawn like the reference's (time-seeded numpy generator, :173-186)."""
         if self.augment:
             np.random.seed(int(np.modf(time())[0] * 100000000))
         paths = self.paths_of(idx)
@@ -155,6 +154,8 @@ class Dataset(torch.utils.data.Dataset):
         rand_start = 0
         if self.augment and max_len > self.time_samples:
             rand_start = np.random.randint(0, max_len - self.time_samples)
+        if not torch.cuda.is_available():
+            return self._getitem_host(idx, rand_start)
         # what the reference's safe_pad leaves: time_samples with zero_pad, else at most the samples the file has (:157-166)
         T = self.time_samples if self.zero_pad else max(1, min(self.time_samples, max_len - rand_start))
         S1 = len(paths)
@@ -173,6 +174,30 @@ class Dataset(torch.utils.data.Dataset):
                                             C.c_float(EPS), mix.data_ptr(), src.data_ptr(), _lib.current_stream(dev)),
                    "srf_feeder_normalize")
         return mix[0].cpu(), src[0].cpu()
+
+    def _getitem_host(self, idx, rand_start=0):
+        """Dataset[i] without a GPU: files through the native reader, then the reference's recipe in its order
+        (wham.py:183-217): the mixture is cropped only when augmenting a longer file (:183-186; else normalised over the
+        WHOLE file and truncated afterwards), every source is read as [rand_start, rand_start + T) (:201), each stream is
+        normalised over its own samples and padded (:189-191, :205-207), then everything is re-normalised with the
+        POPULATION std of the padded mixture (:211-215)."""
+        paths, T = self.paths_of(idx), self.time_samples
+        crop = self.augment and self.file_frames[idx] > T
+        mix = torch.from_numpy(wav_read(paths[0], rand_start, T) if crop else wav_read(paths[0]))
+        if self.normalize_audio:
+            mix = normalize_tensor_wav(mix)
+        mix = self.safe_pad(mix)
+        srcs = []
+        for p in paths[1:]:
+            s = torch.from_numpy(wav_read(p, rand_start, T))
+            if self.normalize_audio:
+                s = normalize_tensor_wav(s)
+            srcs.append(self.safe_pad(s))
+        if self.normalize_audio:
+            mix_std = mix.numpy().std()
+            mix = normalize_tensor_wav(mix, std=mix_std)
+            srcs = [normalize_tensor_wav(s, std=mix_std) for s in srcs]
+        return mix, torch.stack(srcs, dim=0)
 
     def get_generator(self, batch_size=4, shuffle=True, num_workers=4, device=None, prefetch=3, seed=0, drop_last=True,
                       rank=None, world_size=None):

@@ -5,6 +5,7 @@ tensors.  GlobLN statistics travel as float64 ``sums`` tensors of shape [groups,
 ({sum, sum of squares}); producers accumulate into them, so pass zero-initialised tensors.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -109,6 +110,9 @@ def pack3_pw_weight(weight):
     _lib.check(lib.srf_pack3_pw_weights((C.c_void_p * 1)(weight.data_ptr()), (C.c_void_p * 1)(packed.data_ptr()),
                                         (C.c_int * 1)(Cout), (C.c_int * 1)(Cin), 1, _lib.current_stream(dev)),
                "srf_pack3_pw_weights")
+    # the library keeps a (device, address) -> format record of every packed3 image; it goes when the buffer does (the caching
+    # allocator will hand the address to something else)
+    weakref.finalize(packed, lib.srf_pack3_forget, packed.data_ptr())
     return packed
 
 

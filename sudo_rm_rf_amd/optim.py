@@ -2,11 +2,14 @@
 ``torch.nn.utils.clip_grad_norm_(model.parameters(), clip); opt.step()`` (run_improved_sudormrf.py:172-176), as two
 HIP launches over every parameter at once (csrc/srf_optim.hip), without the host sync clip_grad_norm_ needs."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
 
 from . import _lib
+
+_CHECK_FINITE = os.environ.get("SRF_CHECK_FINITE") == "1"   # check_finite() after every step (one host sync per step)
 
 
 class FusedClipAdam(torch.optim.Optimizer):
@@ -44,9 +47,22 @@ class FusedClipAdam(torch.optim.Optimizer):
         for i, p in enumerate(plist):
             st = self.state[p]
             desc[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), sizes[i])
+        # The table is overwritten IN PLACE: safe while every step's copy and kernel are ordered on one stream.  A caller that
+        # moves the optimizer to another stream makes the new stream wait for the old one first.
+        cur = torch.cuda.current_stream(dev)
+        if cached.get("stream") is not None and cached["stream"] != cur:
+            cur.wait_stream(cached["stream"])
+        cached["stream"] = cur
         if cached["desc"] is None or not np.array_equal(cached["desc"], desc):
-            staging = torch.from_numpy(desc).pin_memory()       # (torch's caching host allocator recycles it once the copy ran)
-            cached["tens"].copy_(staging, non_blocking=True)
+            # one persistent pinned staging buffer per group; the event says when its previous copy has left the host
+            if cached.get("staging") is None:
+                cached["staging"] = torch.empty((len(plist), 5), dtype=torch.int64).pin_memory()
+                cached["staged"] = torch.cuda.Event()
+            else:
+                cached["staged"].synchronize()
+            cached["staging"].copy_(torch.from_numpy(desc))
+            cached["tens"].copy_(cached["staging"], non_blocking=True)
+            cached["staged"].record(cur)
             cached["desc"] = desc
         return cached["tens"], cached["chs"], cached["buckets"], cached["norm"]
 
@@ -85,7 +101,20 @@ class FusedClipAdam(torch.optim.Optimizer):
                                             _lib.current_stream(dev))
             _lib.check(rc, "srf_clip_adam_step")
             self.last_grad_norm = norm
+        if _CHECK_FINITE:
+            self.check_finite()
         return loss
+
+    def check_finite(self):
+        """Host check of the last step's total gradient norm (ONE synchronising read; off the hot path unless
+        SRF_CHECK_FINITE=1 asks for it after every step).  The HIP training forward runs its 1x1 convolutions on two FP16 parts
+        per operand: an activation beyond fp16's range (|x| >= 65520), where the fp32 reference would still be finite, turns the
+        step non-finite instead of being silently clamped -- this is where that becomes a clear error."""
+        if self.last_grad_norm is not None and not bool(torch.isfinite(self.last_grad_norm).all()):
+            raise _lib.SrfError(
+                "FusedClipAdam: the gradient norm of the last step is not finite.  If the loss itself is finite in the fp32 "
+                "reference, an operand of the training forward's GEMMs left fp16's range (|x| >= 65520): re-run with the "
+                "three-bf16-part training GEMMs (sudo_rm_rf_amd.ops.set_debug_flags(16384)), which keep fp32's exponent range")
 
     def load_state_dict(self, state_dict):
         """Accepts torch.optim.Adam's state_dict as well: its param groups carry no clip_grad_norm (this optimizer's own

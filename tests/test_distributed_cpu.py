@@ -300,6 +300,11 @@ def test_bench_end_to_end_on_cpu_stub(train):
         assert len(d["per_rank_ms_per_step"]) == 2
         ar = d["gradient_allreduce"]
         assert ar["world"] == 2 and ar["bytes"] > 0 and ar["ms"] > 0 and ar["bus_GBps"] > 0
+        # weak-scaling arithmetic: the line's value is BOTH ranks' examples over the slowest rank's step time,
+        # i.e. 2 x the per-rank figure -- a first real SCALE run cannot report a per-rank number as the aggregate
+        per_rank = 4 * (2000 / 8000) / (d["ms_per_step"] * 1e-3)
+        assert d["value"] == pytest.approx(2 * per_rank, rel=1e-6)
+        assert d["ms_per_step"] == pytest.approx(max(d["per_rank_ms_per_step"]), rel=0.25)
     else:
         assert len(d["ranks"]["ms_per_step_by_rank"]) == 2 and d["config"]["global_batch"] == 2 * 4
         # whole-job aggregate: both ranks' examples over the slowest rank's time

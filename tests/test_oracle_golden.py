@@ -332,13 +332,17 @@ def test_training_gradients_oracle_matches_reference_golden(name):
     from oracle import loss_oracle, torch_oracle
     cfg, sd, mix, tgt, z = train_case(name)
     sd64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd.items()}
-    rec = torch_oracle.forward(cfg, sd64, mix.double())
+    mix64 = mix.double().requires_grad_("gwav" in z.files)
+    rec = torch_oracle.forward(cfg, sd64, mix64)
     if cfg.variant == "groupcomm":
-        rec = rec + (mix.double() - rec.sum(1, keepdim=True)) / rec.shape[1]     # mixture_consistency.py:14-36
+        rec = rec + (mix64 - rec.sum(1, keepdim=True)) / rec.shape[1]     # mixture_consistency.py:14-36
     l, _, _, _ = loss_oracle.pit_sisdr_loss(rec, tgt.double())
     l.backward()
     assert abs(float(l.detach()) - float(z["loss"])) <= 1e-3
     check_grads_against_golden([(k, v.grad.numpy()) for k, v in sd64.items()], z, 5e-3)
+    if "gwav" in z.files:      # round 6: the gradient w.r.t. the input waveform (the small fixtures carry the reference's)
+        want = z["gwav"].astype(np.float64)
+        assert np.abs(mix64.grad.numpy() - want).max() <= 5e-3 * np.abs(want).max()
 
 
 @pytest.mark.parametrize("name", ["train_improved_mfma_traj"])

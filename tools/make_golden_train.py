@@ -93,6 +93,11 @@ def main():
             model = model.double()
             model.pad_to_appropriate_length = lambda x: x
             mix, tgt = mix.double(), tgt.double()
+        # the small cases also pin the gradient w.r.t. the INPUT waveform (round 6: srf_backward_wav), which the reference's
+        # autograd returns for a mixture that requires grad -- through the model and, for GroupComm, the mixture-consistency term
+        want_gwav = not f64
+        if want_gwav:
+            mix.requires_grad_()
         rec = model(mix)
         assert rec.dtype == (torch.float64 if f64 else torch.float32)
         if cfg.variant == "groupcomm":
@@ -100,6 +105,9 @@ def main():
         l = torch.clamp(loss_fn(rec, tgt), min=-30.0, max=30.0)
         l.backward()
         arrays = {"loss": np.float32(l.item())}
+        if want_gwav:
+            arrays["gwav"] = mix.grad.numpy().astype(np.float32)
+            mix = mix.detach()
         g32 = None
         if f64:
             # the same step by the reference in its native fp32: how far its OWN gradients are from the fp64 ones, per
