@@ -1261,6 +1261,217 @@ extern "C" int srf_dwconv5_bwd(const float* gd, const float* xin, const srf_norm
 }
 
 // =============================================================================================
+// Round 6: the HEAD of a block's pyramid backward in two passes over {G_0, y1} instead of 7 C*L of traffic.
+//   forward   o = PReLU(GlobLN_p(y1))          proj_1x1's norm + activation      improved_sudormrf.py:174-175,:205
+//             d_0 = conv_0(o)  (k = 5, s = 1)   n_0 = GlobLN_0(d_0)               :178-189,:206
+//   backward  G_0 = d loss / d n_0 (complete: merge part + what level 1 sent down; written by level 1's kernel, which
+//             also leaves norm 0's reduced sums S1 / S2)
+//             g_d0 = GlobLN_0'(G_0; d_0),   g_o = conv_0^T(g_d0),   g_y1 = (GlobLN_p + PReLU)'(g_o; y1)
+// Before: the level-0 conv kernel read G_0, d_0, y1 and wrote g_o (4 C*L) while reducing norm p's sums, then norm p's apply
+// pass read g_o, y1 and wrote g_y1 (3 C*L).  g_o is needed twice only because norm p's sums must be complete before its
+// apply -- but g_o is cheap to RE-COMPUTE, and so is d_0 (five FMAs per element from y1, which both passes read anyway):
+//   pass A (reduce): read G_0, y1 -> conv 0's parameter sums, norm p's row partials and S1 / S2 buckets.  Writes no tensor.
+//   pass B (apply) : read G_0, y1 -> g_y1.                                         Together 5 C*L, and d_0 is not read at all.
+// One wavefront per row; a trip covers 64 consecutive float4 of the row = 62 own + one halo float4 on either side: g_o at
+// an own position needs g_d0 at +-2, which the neighbouring LANE holds (DPP shifts); a halo lane's g_d0 is only needed at
+// its two positions next to the own range, and those need o at +-2 of THEM -- inside the trip's 64 float4 on both sides.
+// So everything is lane-local or one DPP shift away; no LDS, no barrier, every access a full 1-KB line run.
+// The recomputed d_0 is the forward's d_0 bit for bit (same expressions in the same order as srf_pyramid_reg.hip).
+// =============================================================================================
+struct L0pArgs {
+  const float* G0;
+  const float* y1;
+  float* gy1;               // pass B
+  SrfNormDev pn;            // proj_1x1's norm (+ PReLU): statistics of y1
+  double pn_inv;
+  SrfNormDev n0;            // level 0's norm: statistics of d_0
+  double n0_inv;
+  const double* n0_bsums;   // S1 / S2 of norm 0 (level 1's kernel reduced them)
+  double* pn_bsums;         // S1 / S2 of norm p: pass A accumulates, pass B reads
+  float* pn_rowpart;        // [rows][4] pass A
+  const float* w;           // conv 0 [C][5]
+  const float* bias;        // conv 0 [C]
+  float* dw_rowpart;        // [rows][8] pass A
+  int C, L;
+};
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void srf_bwd_l0p_kernel(L0pArgs a, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;   // wave-uniform
+  const int c = (int)(row % a.C);
+  const long g = row / a.C;
+  const int L4 = a.L >> 2;
+  const float* yr = a.y1 + row * (long)a.L;
+  const float* gr = a.G0 + row * (long)a.L;
+  // the first trip's operands travel while the statistics are finalised
+  auto f_of = [&](int f0) { return f0 - 1 + lane; };
+  auto ld = [&](const float* base, int f) { return srf_ld4<SRF_BWD_NT>(base + 4 * (size_t)min(max(f, 0), L4 - 1)); };
+  float4 xv = ld(yr, f_of(0)), gv = ld(gr, f_of(0));
+  float pmean, prstd, zmean, zrstd;
+  srf_finalize_stats(a.pn.sums, g, a.pn_inv, pmean, prstd);
+  srf_finalize_stats(a.n0.sums, g, a.n0_inv, zmean, zrstd);
+  const double2 bk0 = reinterpret_cast<const double2*>(a.n0_bsums)[g * SRF_STAT_BUCKETS + lane];
+  const float zm1 = (float)(srf_wave_sum(bk0.x) * a.n0_inv), zm2 = (float)(srf_wave_sum(bk0.y) * a.n0_inv);
+  float pm1 = 0.f, pm2 = 0.f;
+  if (APPLY) {
+    const double2 bkp = reinterpret_cast<const double2*>(a.pn_bsums)[g * SRF_STAT_BUCKETS + lane];
+    pm1 = (float)(srf_wave_sum(bkp.x) * a.pn_inv);
+    pm2 = (float)(srf_wave_sum(bkp.y) * a.pn_inv);
+  }
+  const float pgam = a.pn.gamma[c], pbet = a.pn.beta[c], zgam = a.n0.gamma[c];
+  const float psc = pgam * prstd, psh = pbet - pmean * psc;          // (the forward's expressions: srf_pyramid_reg.hip)
+  const bool act = a.pn.prelu != nullptr;
+  const float slope = act ? a.pn.prelu[0] : 1.f;
+  float w[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) w[t] = a.w[c * 5 + t];
+  const float b0 = a.bias[c];
+  float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  for (int f0 = 0; f0 < L4; f0 += 62) {
+    const int f = f_of(f0);
+    const bool inrow = f >= 0 && f < L4;
+    const bool own = inrow && lane >= 1 && lane <= 62;
+    const float4 xc = xv, gc = gv;
+    if (f0 + 62 < L4) {      // next trip's operands
+      xv = ld(yr, f_of(f0 + 62));
+      gv = ld(gr, f_of(f0 + 62));
+    }
+    const float xe[4] = {xc.x, xc.y, xc.z, xc.w};
+    const float ge[4] = {gc.x, gc.y, gc.z, gc.w};
+    // ---- o = PReLU(GlobLN_p(y1)) on positions 4 f - 2 .. 4 f + 5 (zero outside the row: the conv pads o)
+    const float scm = inrow ? psc : 0.f, shm = inrow ? psh : 0.f;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = fmaf(xe[e], scm, shm);
+      if (act) v = srf_prelu(v, slope);
+      o[e + 2] = v;
+    }
+    o[0] = srf_lane_up(o[4]);
+    o[1] = srf_lane_up(o[5]);
+    o[6] = srf_lane_down(o[2]);
+    o[7] = srf_lane_down(o[3]);
+    // ---- d_0 (the forward's FMA chain), norm 0's backward on load: g_d0 (zero outside the row)
+    float gw[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d0 = fmaf(w[4], o[e + 4], fmaf(w[3], o[e + 3], fmaf(w[2], o[e + 2], fmaf(w[1], o[e + 1], fmaf(w[0], o[e], b0)))));
+      const float xh = (d0 - zmean) * zrstd;
+      const float gd = zrstd * (zgam * ge[e] - zm1 - xh * zm2);
+      gw[e + 2] = inrow ? gd : 0.f;
+    }
+    gw[0] = srf_lane_up(gw[4]);
+    gw[1] = srf_lane_up(gw[5]);
+    gw[6] = srf_lane_down(gw[2]);
+    gw[7] = srf_lane_down(gw[3]);
+    // ---- conv 0: parameter sums (pass A) and the input gradient g_o
+    float gi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!APPLY) {
+        const float gd = own ? gw[e + 2] : 0.f;
+        p[5] += gd;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) p[t] = fmaf(gd, o[e + t], p[t]);
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) acc = fmaf(w[t], gw[e + 4 - t], acc);
+      gi[e] = acc;
+    }
+    // ---- norm p (+ PReLU) backward: reduce (pass A) or apply (pass B)
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xh, gz;
+      srf_gln_bwd_elem(own ? gi[e] : 0.f, xe[e], pmean, prstd, pgam, pbet, act, slope, xh, gz, n2);
+      if (APPLY) {
+        r[e] = prstd * (pgam * gz - pm1 - xh * pm2);
+      } else {
+        n0 += gz;
+        n1 = fmaf(gz, xh, n1);
+      }
+    }
+    if (APPLY && own) *reinterpret_cast<float4*>(a.gy1 + row * (long)a.L + 4 * (size_t)f) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  if (!APPLY) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p[k] = srf_dpp_wave_sum(p[k]);
+    n0 = srf_dpp_wave_sum(n0);
+    n1 = srf_dpp_wave_sum(n1);
+    n2 = srf_dpp_wave_sum(n2);
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a.dw_rowpart[row * 8 + k] = p[k];
+      float* rp = a.pn_rowpart + row * 4;
+      rp[0] = n0;
+      rp[1] = n1;
+      rp[2] = n2;
+      double* dst = srf_stat_slot(a.pn_bsums, g, c);
+      atomicAdd(dst, (double)pgam * (double)n0);
+      atomicAdd(dst + 1, (double)pgam * (double)n1);
+    }
+  }
+}
+
+// G0: [groups,C,L] complete gradient w.r.t. n_0; y1: the block's proj_1x1 conv output; pn / n0: the two norms (pn with its PReLU
+// slope); w0 / b0: conv 0; n0_scratch: norm 0's REDUCED scratch slice (srf_gln_bwd layout: buckets, then row partials);
+// pn_scratch: norm p's slice -- pass A writes it (buckets zeroed by the caller: the deferred mode's arena), pass B reads it;
+// dw_scratch: conv 0's row-partial slice.  dw / dbias: conv 0's parameter gradients (deferred through ctx, or reduced here).
+// gy1 must not alias G0 (halo lanes re-read what a neighbouring trip's own lanes would have overwritten).
+bool srf_bwd_level0_proj_ok(int L, const void* const* ptrs, int nptrs) {
+  if ((L % 4) != 0 || L < 8 || srf_kernel_mode() == 1 || (srf_debug_flags() & ((1 << 16) | (1 << 29) | (1 << 30)))) return false;
+  for (int i = 0; i < nptrs; ++i)
+    if (!ptrs[i] || !srf_aligned16(ptrs[i])) return false;
+  return true;
+}
+int srf_bwd_level0_proj(const float* G0, const float* y1, const srf_norm* pn, const srf_norm* n0, const float* w0, const float* b0,
+                        const void* n0_scratch, void* pn_scratch, void* dw_scratch, float* dw, float* dbias, float* gy1,
+                        int groups, int C, int L, void* stream, SrfBwdCtx* ctx) {
+  SRF_CHECK_ARG(G0 && y1 && pn && n0 && w0 && b0 && n0_scratch && pn_scratch && dw_scratch && gy1 && gy1 != G0,
+                "srf_bwd_level0_proj: bad pointers");
+  SRF_CHECK_ARG(pn->sums && pn->gamma && pn->beta && n0->sums && n0->gamma && n0->beta, "srf_bwd_level0_proj: incomplete norms");
+  const long rows = (long)groups * C;
+  SRF_CHECK_ARG(groups > 0 && C > 0 && rows < (1L << 31), "srf_bwd_level0_proj: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  L0pArgs a;
+  a.G0 = G0;
+  a.y1 = y1;
+  a.gy1 = gy1;
+  a.pn = srf_norm_dev(pn);
+  a.n0 = srf_norm_dev(n0);
+  a.pn_inv = a.n0_inv = 1.0 / ((double)C * (double)L);
+  a.n0_bsums = reinterpret_cast<const double*>(n0_scratch);
+  a.pn_bsums = reinterpret_cast<double*>(pn_scratch);
+  a.pn_rowpart = reinterpret_cast<float*>(a.pn_bsums + (size_t)groups * SRF_STAT_BUCKETS * 2);
+  a.w = w0;
+  a.bias = b0;
+  a.dw_rowpart = reinterpret_cast<float*>(dw_scratch);
+  a.C = C;
+  a.L = L;
+  const bool defer = ctx && ctx->defer;
+  if (!defer) SRF_CHECK_HIP(hipMemsetAsync(a.pn_bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
+  const dim3 grid4((unsigned)((rows + 3) / 4));
+  hipLaunchKernelGGL(srf_bwd_l0p_kernel<false>, grid4, dim3(256), 0, st, a, rows);
+  SRF_CHECK_LAUNCH("bwd_l0p_reduce", st);
+  if (dw || dbias) {
+    if (defer) {
+      ctx->dw.push_back(DwParamsDesc{a.dw_rowpart, dw, dbias, groups, C});
+    } else {
+      hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)), dim3(256),
+                         0, st, a.dw_rowpart, groups, C, dw, dbias);
+      SRF_CHECK_LAUNCH("dwconv5_bwd_params", st);
+    }
+  }
+  hipLaunchKernelGGL(srf_bwd_l0p_kernel<true>, grid4, dim3(256), 0, st, a, rows);
+  SRF_CHECK_LAUNCH("bwd_l0p_apply", st);
+  return SRF_OK;
+}
+
+// =============================================================================================
 // Mask application and its backward (improved_sudormrf.py:296-298): v[b, s N + n, l] = relu(m[b, s N + n, l]) * e[b, n, l]
 // The inference path fuses this into the mask GEMM's epilogue; training needs the pre-activation m afterwards,
 // so the training forward writes m and applies the mask here.

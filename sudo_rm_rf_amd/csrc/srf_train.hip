@@ -52,6 +52,11 @@ int srf_dwconv5_bwd_impl(const float* gd, const float* xin, const srf_norm* in_n
                          void* gln_scratch, int* fused, const float* ax, const srf_norm* anorm, const void* a_scratch,
                          void* stream, SrfBwdCtx* ctx);
 
+bool srf_bwd_level0_proj_ok(int L, const void* const* ptrs, int nptrs);
+int srf_bwd_level0_proj(const float* G0, const float* y1, const srf_norm* pn, const srf_norm* n0, const float* w0, const float* b0,
+                        const void* n0_scratch, void* pn_scratch, void* dw_scratch, float* dw, float* dbias, float* gy1,
+                        int groups, int C, int L, void* stream, SrfBwdCtx* ctx);
+
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct TrainLayout {
@@ -581,6 +586,7 @@ static int backward_impl(const srf_plan* p, const float* const* P, float* const*
     // pass.  The two norm scratch areas alternate (level k's sums are read while level k-1's are written).
     // (one slice per call -- the alternation is now simply "this call's slice, the next call's slice")
     int pre_reduced = 0, pp = 1;
+    bool head_done = false;  // level 0 + proj_1x1's norm ran as the fused head (g_y1 in the g_d buffer)
     const float* g_o = go;   // where level 0's conv leaves the gradient w.r.t. o = PReLU(GlobLN(y1))
     for (int k = D - 1; k >= 0; --k) {
       const float* const* Pk = Pu + 5 + 4 * k;   // conv.weight, conv.bias, norm.gamma, norm.beta
@@ -611,6 +617,26 @@ static int backward_impl(const srf_plan* p, const float* const* P, float* const*
         gin = (k - 1 == 0) ? go : fp(s.gu[k - 1]);   // gradient w.r.t. normalised level k-1
       }
       const float* gadd = k > 0 ? gn[k - 1] : nullptr;
+      char* cur_sl = gln_sl + (size_t)pp * s.gln_slice;
+      char* next_sl = cur_sl + s.gln_slice;
+      // Level 0 with its norm already reduced (by level 1's kernel) and the complete G_0 in one buffer: the fused head
+      // (round 6, srf_backward.hip: two passes over {G_0, y1} -- conv 0's backward, its norm's apply, proj_1x1's norm reduce
+      // and apply; neither d_0 nor g_o travels) leaves g_y1 in the g_d buffer; the two buffers swap roles for the rest of the block.
+      if (k == 0 && pre_reduced && !gout2) {
+        const void* hp[3] = {gout1, y1, gd};
+        if (gout1 != gd && srf_bwd_level0_proj_ok(L, hp, 3)) {
+          rc = srf_gln_bwd_impl(gout1, nullptr, dk, &nk, Bg, nC, Lk, nullptr, 0, Gk[2], Gk[3], nullptr, cur_sl, 3, stream, ctx);
+          if (rc) return rc;      // (norm 0's parameter sums, reduced by level 1's kernel: recorded for the batched flush)
+          rc = srf_bwd_level0_proj(gout1, y1, &in, &nk, Pk[0], Pk[1], cur_sl, next_sl, dw_sl, Gk[0], Gk[1], gd, Bg, nC, L,
+                                   stream, ctx);
+          if (rc) return rc;
+          rc = srf_gln_bwd_impl(gd, nullptr, y1, &in, Bg, nC, L, nullptr, 0, Gu[2], Gu[3], Gu[4], next_sl, 3, stream, ctx);
+          if (rc) return rc;      // (proj_1x1's norm: parameter sums recorded; its apply ran inside the fused head)
+          head_done = true;
+          pp += 1;
+          break;
+        }
+      }
       // apply-on-load reads gout1 (with halos) while the same kernel writes gin: at level 0 both would be `go`, so
       // the input gradient goes to the g_d buffer instead, which the on-load form leaves unused
       if (k == 0 && !gout2 && gout1 == go) gin = gd;
@@ -618,8 +644,6 @@ static int backward_impl(const srf_plan* p, const float* const* P, float* const*
       const bool on_load = !gout2 && gout1 != gin && srf_dwconv5_bwd_rowwise_ok(Lin, stride, ptrs, 5);
       if (!on_load && k == 0) gin = go;
       if (k == 0) g_o = gin;
-      char* cur_sl = gln_sl + (size_t)pp * s.gln_slice;
-      char* next_sl = cur_sl + s.gln_slice;
       rc = srf_gln_bwd_impl(gout1, gout2, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, cur_sl,
                             (pre_reduced ? 1 : 0) | (on_load ? 2 : 0), stream, ctx);
       if (rc) return rc;
@@ -629,12 +653,21 @@ static int backward_impl(const srf_plan* p, const float* const* P, float* const*
       if (rc) return rc;
       pp += 1;
     }
-    // proj_1x1: y1 = W_p xin + b_p, o = PReLU(GlobLN(y1))
-    srf_norm pn{slot(s0), Pu[2], Pu[3], Pu[4]};
-    rc = srf_gln_bwd_impl(g_o, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], gln_sl + (size_t)pp * s.gln_slice,
-                          pre_reduced, stream, ctx);   // go = g_y1
+    if (head_done) {
+      float* t2 = go;       // g_y1 sits in the former g_d buffer
+      go = gd;
+      gd = t2;
+    } else {
+      // proj_1x1: y1 = W_p xin + b_p, o = PReLU(GlobLN(y1))
+      srf_norm pn{slot(s0), Pu[2], Pu[3], Pu[4]};
+      rc = srf_gln_bwd_impl(g_o, nullptr, y1, &pn, Bg, nC, L, go, 0, Gu[2], Gu[3], Gu[4], gln_sl + (size_t)pp * s.gln_slice,
+                            pre_reduced, stream, ctx);   // go = g_y1
+      if (rc) {
+        srf_bwd_ctx_defer(ctx, false);
+        return rc;
+      }
+    }
     srf_bwd_ctx_defer(ctx, false);
-    if (rc) return rc;
     rc = srf_pw_wgrad(go, xin, nullptr, Bg, nB, nC, L, Gu[0], Gu[1], 1, wg, stream);
     if (rc) return rc;
     // Data gradients back to back (round 5; srf_pwconv_x3f.hip, no prologue): g_x(i) = W_p^T g_y1 + g_x(i + 1) -- the block's

@@ -194,7 +194,7 @@ def train_flops_per_example(variant, B, C, U, D, K, N, S, T, G=1):
     return 3.0 * flops_per_example(variant, B, C, U, D, K, N, S, T, G)
 
 
-def _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A):
+def _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A, fused_head=True):
     """GroupComm step (groupcomm_sudormrf_v2.py:232-339; csrc/srf_train.hip with gc = true): per block a TAC (MLP over the G groups
     of n = B / G channels, hidden H = 3 n) and a U-ConvBlock on the (batch x group)-folded tensor [Bt G, B / G -> C / G, L].  Folding
     does not change a family's bytes (Bt G rows of C / G channels = Bt rows of C), so the pyramid / norm / depthwise entries are
@@ -243,9 +243,7 @@ def _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A):
     add("pw_wgrad_small", U * 2 * f * L * (B + C), U * 2 * 2.0 * Bt * B * C * L / G)   # res_conv / proj weight gradients
     add("pw_conv_small", U * (f * L * (B + C) + f * L * (C + 2 * B)), U * 2 * 2.0 * Bt * B * C * L / G)   # their data gradients
     add("gln_bwd_reduce", U * f * C * 2 * (L + lv[-1]), U * 4.0 * Bt * C * (L + lv[-1]))
-    add("gln_bwd_apply", U * f * C * (3 * L + (lev_sum - L)) + U * f * C * 3 * L, U * 16.0 * Bt * C * L)
-    dwb = 4 * L + sum(2 * lv[k] + 3 * lv[k - 1] for k in range(1, D))
-    add("dwconv5_bwd", U * f * C * dwb, U * 2.0 * 15 * Bt * C * lev_sum)
+    _block_head_families(add, U, f, C, L, lv, lev_sum, D, Bt, fused_head)
     # TAC backward: x, g_o in (g_po re-read); g_x, Z, GPZ, GPO out (+ the [Bt, H | n, L] tensors of the group mean path)
     add("tac_bwd_mfma", U * f * L * (5 * B + 2 * GH + 4 * H + n), U * 3.0 * tac_flops)
     add("gln_bwd_reduce", U * f * B * 2 * L, U * 4.0 * Bt * B * L)                     # TAC_norm
@@ -265,7 +263,22 @@ def _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A):
     return fam
 
 
-def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, dgrad_pairs=None):
+def _block_head_families(add, U, f, C, L, lv, lev_sum, D, Bt, fused_head):
+    """The norm-apply and depthwise-backward families of the U blocks.  Per level k >= 1 the conv backward reads g_out, d_k (its
+    own norm's apply on load), the conv input, the merge part and writes g_in.  Level 0 and proj_1x1's norm: round 6's fused head
+    (srf_backward.hip, srf_bwd_l0p_kernel) = a reduce pass and an apply pass over {G_0, y1} (2 + 3 C L; d_0 and g_o are
+    re-computed); without it (D = 1, odd lengths, debug flag 1 << 16) the level-0 conv kernel (4 C L) + the norm's apply pass (3)."""
+    deep = sum(2 * lv[k] + 3 * lv[k - 1] for k in range(1, D))
+    head = fused_head and D > 1
+    add("gln_bwd_apply", U * f * C * (3 * L + (lev_sum - L)) + (0 if head else U * f * C * 3 * L), U * (8.0 if head else 16.0) * Bt * C * L)
+    if deep or not head:
+        add("dwconv5_bwd", U * f * C * (deep + (0 if head else 4 * L)), U * 2.0 * 15 * Bt * C * (lev_sum - (L if head else 0)))
+    if head:
+        add("bwd_l0p_reduce", U * f * C * 2 * L, U * 2.0 * 24 * Bt * C * L)
+        add("bwd_l0p_apply", U * f * C * 3 * L, U * 2.0 * 20 * Bt * C * L)
+
+
+def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, dgrad_pairs=None, fused_head=True):
     """{profiler family: (algorithmic bytes per step, FLOPs per step)} of srf_forward_train + the loss + srf_backward + the
     optimizer for the IMPROVED model (csrc/srf_train.hip is the launch sequence this mirrors; launches per step come from the
     in-library profiler, so per-launch figures = these totals / the launches counted).  Bytes = tensors a kernel family must read
@@ -275,7 +288,7 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, dgrad_pair
     if variant not in ("improved", "groupcomm"):
         return None
     if variant == "groupcomm":
-        return _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A)
+        return _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A, fused_head)
     L = frames(T, K, D)
     # round 5: the B = 256 models' data gradients of proj_1x1(i) and res_conv(i - 1) run as ONE launch (srf_pwconv_x3f.hip without
     # prologue) when a launch has at least one 128-column tile per CU -- U - 1 pairs; the first res_conv gradient and the last
@@ -333,10 +346,7 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, dgrad_pair
     add("pw_wgrad", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)                   # res_conv weight (prologue re-applied on load)
     add("pw_conv_x3w<0>", (U - npair) * f * L * (B + C), (U - npair) * 2.0 * Bt * B * C * L)     # res_conv data gradient (un-paired)
     add("gln_bwd_reduce", U * f * C * 2 * (L + lv[-1]), U * 4.0 * Bt * C * (L + lv[-1]))      # final_norm + the deepest level
-    add("gln_bwd_apply", U * f * C * (3 * L + (lev_sum - L)) + U * f * C * 3 * L, U * 16.0 * Bt * C * L)   # final_norm (+ merge sink) + proj norm
-    # per level: the conv backward reads g_out, d_k (its own norm's apply on load), the conv input, the merge part and writes g_in
-    dwb = 4 * L + sum(2 * lv[k] + 3 * lv[k - 1] for k in range(1, D))        # (level 0 has no merge part to add)
-    add("dwconv5_bwd", U * f * C * dwb, U * 2.0 * 15 * Bt * C * lev_sum)
+    _block_head_families(add, U, f, C, L, lv, lev_sum, D, Bt, fused_head)
     add("pw_wgrad", U * f * L * (B + C), U * 2.0 * Bt * B * C * L)                   # proj_1x1 weight
     add("pw_conv_x3w<0>", (U - npair) * f * L * (C + 2 * B), (U - npair) * 2.0 * Bt * B * C * L)   # proj_1x1 data gradient + skip (un-paired)
     if npair:        # g_y1 and the skip gradient in, g_x(i) out, g_f(i - 1) out: the 256-channel g_x is not re-read
