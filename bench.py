@@ -342,7 +342,7 @@ def pmc_traffic(kernel_family, workload, train=False):
            "pw_conv_mfma": "srf_pw_mfma_kernel",
            "pyramid_moments": "srf_pyramid_reg_kernel<true", "pyramid_merge": "srf_pyramid_reg_kernel<false",
            "dwconv5_bwd": "srf_dwconv5_bwd_row_kernel", "gln_bwd_apply": "srf_gln_bwd_apply", "gln_bwd_reduce": "srf_gln_bwd_reduce",
-           "bwd_l0p_reduce": "srf_bwd_l0p_kernel<false>", "bwd_l0p_apply": "srf_bwd_l0p_kernel<true>",
+           "bwd_l0p_reduce": "srf_bwd_l0p_kernel<false>", "bwd_l0p_apply": "srf_bwd_l0p_kernel<true>", "bwd_l1h": "srf_bwd_l1h_kernel",
            "pw_wgrad": "srf_pw_wgrad_kernel", "pw_wgrad_small": "srf_pw_wgrad_small_kernel", "pw_conv_small": "srf_pw_small_kernel",
            "tac_mfma": "srf_tac_mfma_kernel", "tac_bwd_mfma": "srf_tac_bwd_mfma_kernel"}.get(kernel_family, kernel_family)
     must = ""

@@ -1471,6 +1471,212 @@ int srf_bwd_level0_proj(const float* G0, const float* y1, const srf_norm* pn, co
   return SRF_OK;
 }
 
+// ---- level 1 in the same style: conv 1's backward (stride 2) with its own norm's apply on load, the complete G_0 and norm 0's
+// reduce pass -- srf_dwconv5_bwd_row_kernel<2, true, true> -- but with conv 1's INPUT n_0 = GlobLN_0(conv_0(o)) re-computed from
+// y1 instead of read from the saved d_0: with the fused head above nothing reads d_0 any more, so the training forward does not
+// write it (one C*L less in its pyramid pass).  Same trip layout as srf_bwd_l0p_kernel (62 own float4 of level-0 positions +
+// one halo float4 per side; a lane's two level-1 positions are 2 f, 2 f + 1).
+struct L1hArgs {
+  const float* G1;          // [rows][L/2] gradient w.r.t. n_1 (complete)
+  const float* d1;          // [rows][L/2] conv 1's output (norm 1's input)
+  const float* y1;          // [rows][L]
+  const float* gadd;        // [rows][L] the merge part of G_0 (g_merged)
+  float* G0;                // [rows][L] out
+  SrfNormDev pn, n0, n1;    // proj norm (+ PReLU), level-0 norm, level-1 norm
+  double inv0, inv1;        // 1 / (C L), 1 / (C L / 2)
+  const double* n1_bsums;   // S1 / S2 of norm 1 (reduced)
+  double* n0_bsums;         // norm 0: reduce pass output
+  float* n0_rowpart;        // [rows][4]
+  const float* w0;          // conv 0 [C][5], bias0 [C]
+  const float* b0;
+  const float* w1;          // conv 1 [C][5]
+  float* dw_rowpart;        // conv 1 [rows][8]
+  int C, L;
+};
+
+__global__ __launch_bounds__(256) void srf_bwd_l1h_kernel(L1hArgs a, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;   // wave-uniform
+  const int c = (int)(row % a.C);
+  const long g = row / a.C;
+  const int L4 = a.L >> 2;
+  const float* yr = a.y1 + row * (long)a.L;
+  const float* mr = a.gadd + row * (long)a.L;
+  const float* g1r = a.G1 + row * (long)(a.L >> 1);
+  const float* d1r = a.d1 + row * (long)(a.L >> 1);
+  auto fc = [&](int f0) { return min(max(f0 - 1 + lane, 0), L4 - 1); };
+  float4 xv = srf_ld4<SRF_BWD_NT>(yr + 4 * (size_t)fc(0)), mv = srf_ld4<SRF_BWD_NT>(mr + 4 * (size_t)fc(0));
+  float2 gv = srf_ld2<SRF_BWD_NT>(g1r + 2 * (size_t)fc(0)), dv = srf_ld2<SRF_BWD_NT>(d1r + 2 * (size_t)fc(0));
+  float pmean, prstd, zmean, zrstd, omean, orstd;
+  srf_finalize_stats(a.pn.sums, g, a.inv0, pmean, prstd);
+  srf_finalize_stats(a.n0.sums, g, a.inv0, zmean, zrstd);
+  srf_finalize_stats(a.n1.sums, g, a.inv1, omean, orstd);
+  const double2 bk1 = reinterpret_cast<const double2*>(a.n1_bsums)[g * SRF_STAT_BUCKETS + lane];
+  const float om1 = (float)(srf_wave_sum(bk1.x) * a.inv1), om2 = (float)(srf_wave_sum(bk1.y) * a.inv1);
+  const float psc = a.pn.gamma[c] * prstd, psh = a.pn.beta[c] - pmean * psc;
+  const bool act = a.pn.prelu != nullptr;
+  const float slope = act ? a.pn.prelu[0] : 1.f;
+  const float zgam = a.n0.gamma[c], zbet = a.n0.beta[c];
+  const float zsc = zgam * zrstd, zsh = zbet - zmean * zsc;           // n_0 = d_0 zsc + zsh (the forward's affine)
+  const float ogam = a.n1.gamma[c], obet = a.n1.beta[c];
+  float w0[5], w1[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    w0[t] = a.w0[c * 5 + t];
+    w1[t] = a.w1[c * 5 + t];
+  }
+  const float b0 = a.b0[c];
+  float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  for (int f0 = 0; f0 < L4; f0 += 62) {
+    const int f = f0 - 1 + lane;
+    const bool inrow = f >= 0 && f < L4;
+    const bool own = inrow && lane >= 1 && lane <= 62;
+    const float4 xc = xv, mc = mv;
+    const float2 gc = gv, dc = dv;
+    if (f0 + 62 < L4) {
+      const int fn = fc(f0 + 62);
+      xv = srf_ld4<SRF_BWD_NT>(yr + 4 * (size_t)fn);
+      mv = srf_ld4<SRF_BWD_NT>(mr + 4 * (size_t)fn);
+      gv = srf_ld2<SRF_BWD_NT>(g1r + 2 * (size_t)fn);
+      dv = srf_ld2<SRF_BWD_NT>(d1r + 2 * (size_t)fn);
+    }
+    const float xe[4] = {xc.x, xc.y, xc.z, xc.w};
+    // ---- o on positions 4 f - 2 .. 4 f + 5, then d_0 and n_0 (zero outside the row: conv 1 pads n_0) on the own four
+    const float scm = inrow ? psc : 0.f, shm = inrow ? psh : 0.f;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = fmaf(xe[e], scm, shm);
+      if (act) v = srf_prelu(v, slope);
+      o[e + 2] = v;
+    }
+    o[0] = srf_lane_up(o[4]);
+    o[1] = srf_lane_up(o[5]);
+    o[6] = srf_lane_down(o[2]);
+    o[7] = srf_lane_down(o[3]);
+    float d0[4], u[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d0[e] = fmaf(w0[4], o[e + 4], fmaf(w0[3], o[e + 3], fmaf(w0[2], o[e + 2], fmaf(w0[1], o[e + 1], fmaf(w0[0], o[e], b0)))));
+      u[e + 2] = inrow ? fmaf(d0[e], zsc, zsh) : 0.f;
+    }
+    u[0] = srf_lane_up(u[4]);
+    u[1] = srf_lane_up(u[5]);
+    u[6] = srf_lane_down(u[2]);
+    u[7] = srf_lane_down(u[3]);
+    // ---- norm 1's backward on load: g_d1 at level-1 positions 2 f, 2 f + 1 (+ one on either side from the neighbours)
+    float gq[4];
+    {
+      float xh, gz, unused = 0.f;
+      srf_gln_bwd_elem(gc.x, dc.x, omean, orstd, ogam, obet, false, 1.f, xh, gz, unused);
+      gq[1] = inrow ? orstd * (ogam * gz - om1 - xh * om2) : 0.f;
+      srf_gln_bwd_elem(gc.y, dc.y, omean, orstd, ogam, obet, false, 1.f, xh, gz, unused);
+      gq[2] = inrow ? orstd * (ogam * gz - om1 - xh * om2) : 0.f;
+    }
+    gq[0] = srf_lane_up(gq[2]);
+    gq[3] = srf_lane_down(gq[1]);
+    // ---- conv 1's parameter sums (own lanes) and input gradient; + the merge part = the complete G_0
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float gd = own ? gq[q + 1] : 0.f;
+      p[5] += gd;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) p[t] = fmaf(gd, u[2 * q + t], p[t]);
+    }
+    float gi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        if (((e + 2 - t) & 1) == 0) acc = fmaf(w1[t], gq[(e + 2 - t) / 2 + 1], acc);   // (e + 2 - t) in [-2, 5]
+      }
+      gi[e] = acc;
+    }
+    gi[0] += mc.x;
+    gi[1] += mc.y;
+    gi[2] += mc.z;
+    gi[3] += mc.w;
+    // ---- norm 0's reduce pass over the complete gradient (its input d_0 is in registers)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xh, gz;
+      srf_gln_bwd_elem(own ? gi[e] : 0.f, d0[e], zmean, zrstd, zgam, zbet, false, 1.f, xh, gz, n2);
+      n0 += gz;
+      n1 = fmaf(gz, xh, n1);
+    }
+    if (own) *reinterpret_cast<float4*>(a.G0 + row * (long)a.L + 4 * (size_t)f) = make_float4(gi[0], gi[1], gi[2], gi[3]);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) p[k] = srf_dpp_wave_sum(p[k]);
+  n0 = srf_dpp_wave_sum(n0);
+  n1 = srf_dpp_wave_sum(n1);
+  n2 = srf_dpp_wave_sum(n2);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.dw_rowpart[row * 8 + k] = p[k];
+    float* rp = a.n0_rowpart + row * 4;
+    rp[0] = n0;
+    rp[1] = n1;
+    rp[2] = n2;
+    double* dst = srf_stat_slot(a.n0_bsums, g, c);
+    atomicAdd(dst, (double)zgam * (double)n0);
+    atomicAdd(dst + 1, (double)zgam * (double)n1);
+  }
+}
+
+// G1 / d1: [groups,C,L/2]; n1_scratch: norm 1's REDUCED slice; n0_scratch: norm 0's slice (written: buckets + row partials);
+// dw_scratch: conv 1's row-partial slice; dw1 / db1: conv 1's parameter gradients.  G0 must not alias gadd / y1.
+int srf_bwd_level1_head(const float* G1, const float* d1, const srf_norm* n1, const void* n1_scratch, const float* y1,
+                        const srf_norm* pn, const srf_norm* n0, const float* w0, const float* b0, const float* w1, const float* gadd,
+                        float* G0, void* n0_scratch, void* dw_scratch, float* dw1, float* db1, int groups, int C, int L,
+                        void* stream, SrfBwdCtx* ctx) {
+  SRF_CHECK_ARG(G1 && d1 && n1 && n1_scratch && y1 && pn && n0 && w0 && b0 && w1 && gadd && G0 && n0_scratch && dw_scratch &&
+                    G0 != gadd && G0 != y1, "srf_bwd_level1_head: bad pointers");
+  SRF_CHECK_ARG((L % 4) == 0 && L >= 8, "srf_bwd_level1_head: L must be a multiple of 4");
+  SRF_CHECK_ARG(srf_aligned16(G1) && srf_aligned16(d1) && srf_aligned16(y1) && srf_aligned16(gadd) && srf_aligned16(G0),
+                "srf_bwd_level1_head: unaligned tensor");
+  const long rows = (long)groups * C;
+  SRF_CHECK_ARG(groups > 0 && C > 0 && rows < (1L << 31), "srf_bwd_level1_head: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  L1hArgs a;
+  a.G1 = G1;
+  a.d1 = d1;
+  a.y1 = y1;
+  a.gadd = gadd;
+  a.G0 = G0;
+  a.pn = srf_norm_dev(pn);
+  a.n0 = srf_norm_dev(n0);
+  a.n1 = srf_norm_dev(n1);
+  a.inv0 = 1.0 / ((double)C * (double)L);
+  a.inv1 = 1.0 / ((double)C * (double)(L >> 1));
+  a.n1_bsums = reinterpret_cast<const double*>(n1_scratch);
+  a.n0_bsums = reinterpret_cast<double*>(n0_scratch);
+  a.n0_rowpart = reinterpret_cast<float*>(a.n0_bsums + (size_t)groups * SRF_STAT_BUCKETS * 2);
+  a.w0 = w0;
+  a.b0 = b0;
+  a.w1 = w1;
+  a.dw_rowpart = reinterpret_cast<float*>(dw_scratch);
+  a.C = C;
+  a.L = L;
+  const bool defer = ctx && ctx->defer;
+  if (!defer) SRF_CHECK_HIP(hipMemsetAsync(a.n0_bsums, 0, sizeof(double) * (size_t)groups * SRF_STAT_BUCKETS * 2, st));
+  hipLaunchKernelGGL(srf_bwd_l1h_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, rows);
+  SRF_CHECK_LAUNCH("bwd_l1h", st);
+  if (dw1 || db1) {
+    if (defer) {
+      ctx->dw.push_back(DwParamsDesc{a.dw_rowpart, dw1, db1, groups, C});
+    } else {
+      hipLaunchKernelGGL(srf_dwconv5_bwd_params_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((groups + 63) / 64)), dim3(256),
+                         0, st, a.dw_rowpart, groups, C, dw1, db1);
+      SRF_CHECK_LAUNCH("dwconv5_bwd_params", st);
+    }
+  }
+  return SRF_OK;
+}
+
 // =============================================================================================
 // Mask application and its backward (improved_sudormrf.py:296-298): v[b, s N + n, l] = relu(m[b, s N + n, l]) * e[b, n, l]
 // The inference path fuses this into the mask GEMM's epilogue; training needs the pre-activation m afterwards,

@@ -20,6 +20,8 @@ struct PyrRegArgs {
   int rpw;             // rows per (persistent) wavefront
   int C, L, D, tiles, own;   // own = own chunks per tile
   float* lv_out[SRF_MAX_DEPTH];   // training forward (SAVE): the raw (pre-norm) conv output of every level, or null
+  int save = 0;        // SAVE requested (lv_out[1 .. D-1] set; lv_out[0] may be null: level 0 is not kept -- round 6, the backward
+                       // re-computes d_0 from y1)
 };
 
 bool srf_pyramid_reg_supported(int L, int D);

@@ -879,6 +879,7 @@ int srf_pyramid_impl(const float* y1, float* merged, const srf_norm* in_norm, co
   if (!(srf_debug_flags() & 64) && srf_pyramid_reg_supported(L, D)) {
     PyrRegArgs r;
     for (int k = 0; k < SRF_MAX_DEPTH; ++k) r.lv_out[k] = (lv_out && k < D) ? lv_out[k] : nullptr;
+    r.save = lv_out != nullptr;
     r.y1 = y1;
     r.d0 = a.d0;
     r.merged = merged;

@@ -258,9 +258,9 @@ __global__ __launch_bounds__(256) void srf_pyramid_reg_kernel(PyrRegArgs a) {
       o[i] = v;
     }
     srf_conv_s1<CH>(o, x0, lc[0].w, lc[0].b);
-    if (SAVE) srf_pyr_store_chunks<CH>(pyr_strip + (threadIdx.x >> 6) * (60 * (CH / 4 + 1)), x0, own,
-                                       a.lv_out[0] + (size_t)row * L, tile * a.own, min(a.own, nchunks - tile * a.own),
-                                       lane);
+    if (SAVE && a.lv_out[0])      // (kernel-uniform; null = level 0 is not kept)
+      srf_pyr_store_chunks<CH>(pyr_strip + (threadIdx.x >> 6) * (60 * (CH / 4 + 1)), x0, own, a.lv_out[0] + (size_t)row * L,
+                               tile * a.own, min(a.own, nchunks - tile * a.own), lane);
     const float vmask = valid ? 1.f : 0.f;
     if (MOMENTS) {
 #pragma unroll
@@ -464,10 +464,10 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
     a.rpw = 1;
     grid = dim3((unsigned)a.C, (unsigned)((a.tiles + 3) / 4), (unsigned)(rows / a.C));
   }
-  const bool save = !moments && a.lv_out[0] != nullptr;
+  const bool save = !moments && a.save != 0;
   if (save)
     for (int k = 0; k < a.D; ++k)
-      SRF_CHECK_ARG(a.lv_out[k] && srf_aligned16(a.lv_out[k]), "srf_pyramid: level output %d missing / unaligned", k);
+      SRF_CHECK_ARG((a.lv_out[k] || (k == 0 && a.D > 1)) && srf_aligned16(a.lv_out[k]), "srf_pyramid: level output %d missing / unaligned", k);
   if (CH == 16) {
     if (moments && persist)
       hipLaunchKernelGGL((srf_pyramid_reg_kernel<true, 16, true>), grid, dim3(256), 0, st, a);

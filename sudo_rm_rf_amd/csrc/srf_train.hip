@@ -57,7 +57,20 @@ int srf_bwd_level0_proj(const float* G0, const float* y1, const srf_norm* pn, co
                         const void* n0_scratch, void* pn_scratch, void* dw_scratch, float* dw, float* dbias, float* gy1,
                         int groups, int C, int L, void* stream, SrfBwdCtx* ctx);
 
+int srf_bwd_level1_head(const float* G1, const float* d1, const srf_norm* n1, const void* n1_scratch, const float* y1,
+                        const srf_norm* pn, const srf_norm* n0, const float* w0, const float* b0, const float* w1, const float* gadd,
+                        float* G0, void* n0_scratch, void* dw_scratch, float* dw1, float* db1, int groups, int C, int L,
+                        void* stream, SrfBwdCtx* ctx);
+
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+// Round 6: levels 1 and 0 of a block's pyramid backward and proj_1x1's norm backward run on the fused-head kernels
+// (srf_backward.hip: srf_bwd_l1h_kernel, srf_bwd_l0p_kernel), which re-compute d_0 from y1 -- so srf_forward_train does not WRITE
+// d_0 either.  One predicate for both sides (a pure function of the plan, the kernel mode and the debug flags: they must not
+// change between a srf_forward_train and its srf_backward); every buffer involved is a 256-byte-aligned slice of saved / scratch.
+static bool train_fused_head(const srf_plan* p) {
+  return p->cfg.upsampling_depth > 1 && srf_bwd_level0_proj_ok(p->L, nullptr, 0);
+}
 
 struct TrainLayout {
   size_t stats, enc, x0, x_stride, blk0, blk_stride, y1, lv[SRF_MAX_DEPTH], merged, q, u, m, v, total;
@@ -305,6 +318,7 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
   const bool fused_pyr = !(srf_debug_flags() & (16 | 64 | 128)) && srf_kernel_mode() != 1 &&
                          srf_pyramid_supported(nC, (int)L, D) && srf_pyramid_reg_supported((int)L, D) &&
                          srf_pyramid_scratch_bytes(Bg, nC, (int)L, D) <= (s.gd + F_ * Bt * c.in_channels * L) - s.gf;
+  const bool skip_d0 = fused_pyr && train_fused_head(p);     // (the backward re-computes d_0: nothing reads it)
   for (int i = 0; i < U; ++i) {
     const float* const* Pb = P + p->p_block0 + (size_t)i * p->p_block_stride;
     const float* const* Pu = Pb + p->p_ublock_off;
@@ -354,7 +368,7 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
         bv[k] = Pk[1];
         gv_[k] = Pk[2];
         bev[k] = Pk[3];
-        lv_out[k] = (float*)(blk + t.lv[k]);
+        lv_out[k] = (k == 0 && skip_d0) ? nullptr : (float*)(blk + t.lv[k]);
         lv_sums[k] = slot(s0 + 1 + k);
       }
       const srf_norm in{slot(s0), Pu[2], Pu[3], Pu[4]};
@@ -587,6 +601,7 @@ static int backward_impl(const srf_plan* p, const float* const* P, float* const*
     // (one slice per call -- the alternation is now simply "this call's slice, the next call's slice")
     int pre_reduced = 0, pp = 1;
     bool head_done = false;  // level 0 + proj_1x1's norm ran as the fused head (g_y1 in the g_d buffer)
+    const bool head = train_fused_head(p);   // (re-computes d_0: needed whenever the forward skipped it, harmless otherwise)
     const float* g_o = go;   // where level 0's conv leaves the gradient w.r.t. o = PReLU(GlobLN(y1))
     for (int k = D - 1; k >= 0; --k) {
       const float* const* Pk = Pu + 5 + 4 * k;   // conv.weight, conv.bias, norm.gamma, norm.beta
@@ -622,9 +637,11 @@ static int backward_impl(const srf_plan* p, const float* const* P, float* const*
       // Level 0 with its norm already reduced (by level 1's kernel) and the complete G_0 in one buffer: the fused head
       // (round 6, srf_backward.hip: two passes over {G_0, y1} -- conv 0's backward, its norm's apply, proj_1x1's norm reduce
       // and apply; neither d_0 nor g_o travels) leaves g_y1 in the g_d buffer; the two buffers swap roles for the rest of the block.
-      if (k == 0 && pre_reduced && !gout2) {
+      if (k == 0 && head) {
         const void* hp[3] = {gout1, y1, gd};
-        if (gout1 != gd && srf_bwd_level0_proj_ok(L, hp, 3)) {
+        SRF_CHECK_ARG(pre_reduced && !gout2 && gout1 != gd && srf_bwd_level0_proj_ok(L, hp, 3),
+                      "srf_backward: the fused backward head lost its preconditions at level 0");
+        {
           rc = srf_gln_bwd_impl(gout1, nullptr, dk, &nk, Bg, nC, Lk, nullptr, 0, Gk[2], Gk[3], nullptr, cur_sl, 3, stream, ctx);
           if (rc) return rc;      // (norm 0's parameter sums, reduced by level 1's kernel: recorded for the batched flush)
           rc = srf_bwd_level0_proj(gout1, y1, &in, &nk, Pk[0], Pk[1], cur_sl, next_sl, dw_sl, Gk[0], Gk[1], gd, Bg, nC, L,
@@ -647,6 +664,17 @@ static int backward_impl(const srf_plan* p, const float* const* P, float* const*
       rc = srf_gln_bwd_impl(gout1, gout2, dk, &nk, Bg, nC, Lk, gd, 0, Gk[2], Gk[3], nullptr, cur_sl,
                             (pre_reduced ? 1 : 0) | (on_load ? 2 : 0), stream, ctx);
       if (rc) return rc;
+      if (k == 1 && head) {
+        // level 1 on the fused-head kernel: conv 1's input n_0 re-computed from y1 (the forward did not keep d_0)
+        SRF_CHECK_ARG(on_load, "srf_backward: the fused backward head needs the row kernels' preconditions at level 1");
+        const srf_norm pn1{slot(s0), Pu[2], Pu[3], Pu[4]};
+        rc = srf_bwd_level1_head(gout1, dk, &nk, cur_sl, y1, &pn1, &in, Pu[5], Pu[6], Pk[0], gadd, gin, next_sl,
+                                 dw_sl + (size_t)k * s.dw_slice, Gk[0], Gk[1], Bg, nC, L, stream, ctx);
+        if (rc) return rc;
+        pre_reduced = 1;
+        pp += 1;
+        continue;
+      }
       rc = srf_dwconv5_bwd_impl(on_load ? gout1 : gd, src, &in, Pk[0], Bg, nC, Lin, stride, gin, Gk[0], Gk[1],
                                 dw_sl + (size_t)k * s.dw_slice, gadd, next_sl, &pre_reduced, on_load ? dk : nullptr,
                                 on_load ? &nk : nullptr, on_load ? cur_sl : nullptr, stream, ctx);

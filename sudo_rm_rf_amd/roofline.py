@@ -223,7 +223,7 @@ def _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A, fused_head=T
     dw = 2.0 * 5 * Bt * C * lev_sum
     add("pyramid_moments", U * f * C * L, U * dw)
     add("pyramid_finalize", U * 8.0 * Bt * C * D * 5)
-    add("pyramid_merge_save", U * f * C * (2 * L + lev_sum), U * (dw + 2.0 * D * Bt * C * L))
+    add("pyramid_merge_save", U * f * C * (2 * L + lev_sum - (L if fused_head and D > 1 else 0)), U * (dw + 2.0 * D * Bt * C * L))
     add("pw_conv_small", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L / G)        # res_conv + residual
     add("pw_conv_x3w4<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
     add("mask_apply", f * L * (2 * SN + N), 2.0 * Bt * SN * L)
@@ -268,12 +268,14 @@ def _block_head_families(add, U, f, C, L, lv, lev_sum, D, Bt, fused_head):
     own norm's apply on load), the conv input, the merge part and writes g_in.  Level 0 and proj_1x1's norm: round 6's fused head
     (srf_backward.hip, srf_bwd_l0p_kernel) = a reduce pass and an apply pass over {G_0, y1} (2 + 3 C L; d_0 and g_o are
     re-computed); without it (D = 1, odd lengths, debug flag 1 << 16) the level-0 conv kernel (4 C L) + the norm's apply pass (3)."""
-    deep = sum(2 * lv[k] + 3 * lv[k - 1] for k in range(1, D))
     head = fused_head and D > 1
+    deep = sum(2 * lv[k] + 3 * lv[k - 1] for k in range(2 if head else 1, D))
     add("gln_bwd_apply", U * f * C * (3 * L + (lev_sum - L)) + (0 if head else U * f * C * 3 * L), U * (8.0 if head else 16.0) * Bt * C * L)
     if deep or not head:
-        add("dwconv5_bwd", U * f * C * (deep + (0 if head else 4 * L)), U * 2.0 * 15 * Bt * C * (lev_sum - (L if head else 0)))
+        add("dwconv5_bwd", U * f * C * (deep + (0 if head else 4 * L)),
+            U * 2.0 * 15 * Bt * C * (lev_sum - ((L + lv[1]) if head else 0)))
     if head:
+        add("bwd_l1h", U * f * C * (2 * lv[1] + 3 * L), U * 2.0 * 22 * Bt * C * L)       # level 1, conv input re-computed from y1
         add("bwd_l0p_reduce", U * f * C * 2 * L, U * 2.0 * 24 * Bt * C * L)
         add("bwd_l0p_apply", U * f * C * 3 * L, U * 2.0 * 20 * Bt * C * L)
 
@@ -324,7 +326,8 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, dgrad_pair
     dw = 2.0 * 5 * Bt * C * lev_sum
     add("pyramid_moments", U * f * C * L, U * dw)
     add("pyramid_finalize", U * 8.0 * Bt * C * D * 5)
-    add("pyramid_merge_save", U * f * C * (2 * L + lev_sum), U * (dw + 2.0 * D * Bt * C * L))     # pass 2 + the levels on the side
+    add("pyramid_merge_save", U * f * C * (2 * L + lev_sum - (L if fused_head and D > 1 else 0)),
+        U * (dw + 2.0 * D * Bt * C * L))     # pass 2 + the levels on the side (level 0 not kept with the fused backward head)
     add("pw_conv_x3w4<2>", (U - npair) * f * L * (C + 2 * B), (U - npair) * 2.0 * Bt * B * C * L)
     add("pw_conv_x3w4<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
     add("mask_apply", f * L * (2 * SN + N), 2.0 * Bt * SN * L)

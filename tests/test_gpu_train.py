@@ -270,8 +270,9 @@ def test_training_step_with_and_without_fused_pairs():
 def test_training_step_with_and_without_the_fused_backward_head(shape):
     """Round 6: level 0 of a block's pyramid backward and proj_1x1's norm backward run as TWO passes over {G_0, y1}
     (srf_bwd_l0p_kernel: d_0 and g_o re-computed instead of read / written) instead of the level-0 conv kernel + the norm's apply
-    pass.  Same arithmetic per element (d_0 is the forward's bit for bit), different summation order of the row sums: the whole
-    step with and without it (debug flag 1 << 16) agrees to rounding, and the profiler proves which path ran."""
+    pass, level 1 on srf_bwd_l1h_kernel (conv 1's input re-computed from y1), and the training forward does not write d_0 at all.
+    Same arithmetic per element (d_0 is the forward's bit for bit), different summation order of the row sums: the whole step
+    with and without it (debug flag 1 << 16) agrees to rounding, and the profiler proves which path ran."""
     import sudo_rm_rf.dnn.losses.sisdr as sisdr_lib
     from sudo_rm_rf_amd import ops
     if shape == "improved_d5":
@@ -294,8 +295,9 @@ def test_training_step_with_and_without_the_fused_backward_head(shape):
             ops.set_debug_flags(flags)
             with ops.kernel_trace(DEV) as tr:
                 loss_fn(model(mix), tgt).backward()
-            nhead = sum(1 for k, _ in tr.launches if k == "bwd_l0p_apply")
-            assert nhead == (cfg.num_blocks if flags == 0 else 0), (flags, nhead, sorted(tr.names))
+            for fam in ("bwd_l0p_reduce", "bwd_l0p_apply", "bwd_l1h"):
+                nhead = sum(1 for k, _ in tr.launches if k == fam)
+                assert nhead == (cfg.num_blocks if flags == 0 else 0), (fam, flags, nhead, sorted(tr.names))
             grads[flags] = {k: p.grad.clone() for k, p in model.state_dict(keep_vars=True).items()}
     finally:
         ops.set_debug_flags(0)
