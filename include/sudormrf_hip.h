@@ -123,6 +123,7 @@ int srf_profile_timeline(int i, const char** name, float* t_ms, int* stream_inde
  *            every other caller the paired-block kernel (srf_pwconv_x3p.hip) -- default: the paired form inside the forward only
  *   16384    training forward: three bf16 parts per operand (6 MFMAs, round 3) instead of two fp16 parts (3 MFMAs, round 4)
  *   32768    WITHOUT the fused tail: mask GEMM -> masked tensor -> decoder frame GEMM -> overlap-add as separate launches
+ *   1<<17    pyramid pass 1 on a grid of co-resident wavefronts, several rows each (rounds 2-5) -- default since round 6: one row per wavefront
  *   1<<16    srf_backward WITHOUT the fused head of the blocks' pyramid backward (round 6: level 0 + proj_1x1's norm as two passes
  *            over {G_0, y1}): the level-0 conv kernel + the norm's apply pass of rounds 3-5
  *   1<<21    fused conv pair on persistent blocks (2 per CU, several tiles each) whatever the launch size -- default: one tile per block

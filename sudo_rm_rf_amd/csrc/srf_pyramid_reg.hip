@@ -456,8 +456,12 @@ int srf_pyramid_reg_launch(PyrRegArgs a, bool moments, long rows, hipStream_t st
   }
   dim3 grid;
   if (persist) {
+    // Round 6: ONE row per wavefront (the row's moments still stay in registers over its tiles), i.e. rows / 4 blocks whatever
+    // the number of co-resident wavefronts.  Rounds 2-5 sized the grid to the co-resident wavefronts (3 rows per wave at cfg 2:
+    // 5.3 blocks per CU); pass 1 is bound by the loads it has in flight, not by its VALU count (profiles/r06_pyramid_pass1_*):
+    // 1 / 2 / 3 / 4 rows per wave = 54.5 / 55.5 / 61 / 62.8 us at cfg 2, same box.  Debug flag 1 << 17: the old sizing.
     long nwaves = cw < rows ? cw : rows;
-    a.rpw = (int)((rows + nwaves - 1) / nwaves);   // whole rows per wave
+    a.rpw = (srf_debug_flags() & (1 << 17)) ? (int)((rows + nwaves - 1) / nwaves) : 1;   // whole rows per wave
     nwaves = (rows + a.rpw - 1) / a.rpw;
     grid = dim3((unsigned)((nwaves + 3) / 4));
   } else {
