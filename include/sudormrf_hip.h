@@ -257,6 +257,14 @@ int srf_dwconv5(const float* x, const float* w, const float* bias, float* y,
                 int Bt, int C, int Lin, int stride, const srf_norm* in_norm, double* out_sums,
                 void* stream);
 
+/* General Conv1d (round 6, ABI 15): any kernel size / stride / dilation / zero padding / groups, weights [Cout, Cin/groups, K]
+ * (nn.Conv1d layout), bias nullable; y: [Bt, Cout, Lout], Lout = (Lin + 2 padding - dilation (K - 1) - 1) / stride + 1.
+ * Not on the model's path (that builds kSize 1 and depthwise k = 5 only): it serves the reference's building blocks
+ * ConvNormAct / DilatedConvNorm (improved_sudormrf.py:50-73,:138-159) when a user instantiates them with other shapes.
+ * out_sums (nullable): [Bt][SRF_STAT_BUCKETS][2] += {sum, sumsq} of y. */
+int srf_conv1d(const float* x, const float* w, const float* bias, float* y, int Bt, int Cin, int Cout, int Lin, int K,
+               int stride, int padding, int dilation, int groups, double* out_sums, void* stream);
+
 /* Bottom-up nearest-x2 upsample-and-add of D normalised levels:
  * y[b,c,j] = n_0[j] + (n_1[j>>1] + (... + n_{D-1}[j>>(D-1)])),  n_k = GlobLN_k(levels[k]).
  * levels[k]: [Bt,C,L>>k]; norms[k] describes level k (prelu ignored). */

@@ -105,6 +105,7 @@ _PROTOS = {
     "srf_separate": (_i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "srf_wav_denormalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srf_dwconv5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(srf_norm), _vp, _vp]),
+    "srf_conv1d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "srf_pyramid_supported": (_i, [_i, _i, _i]),
     "srf_pyramid_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "srf_pyramid": (_i, [_vp, _vp, C.POINTER(srf_norm), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),

@@ -377,3 +377,80 @@ extern "C" int srf_merge(const float* const* levels, const srf_norm* norms, int 
   SRF_CHECK_LAUNCH(fast ? "merge_fast" : "merge_generic", st);
   return SRF_OK;
 }
+
+
+// =============================================================================================
+// General Conv1d (round 6): any kernel size / stride / dilation / zero padding / groups, fp32 FMA, one thread per output.
+// NOT on the model's path -- UConvBlock only ever builds kSize = 1 (srf_pw_conv) and depthwise k = 5 (srf_dwconv5) -- but the
+// reference's building blocks ConvNormAct / DilatedConvNorm (improved_sudormrf.py:50-73,:138-159) are ordinary nn.Conv1d
+// wrappers that accept any of these, and a user who instantiates one stand-alone gets the same result here.
+//   y[b, co, l] = bias[co] + sum_{ci < Cin/groups, k < K} w[co, ci, k] x[b, g Cin/groups + ci, l stride - pad + k dil],  g = co / (Cout/groups)
+// out_sums (nullable): [Bt][SRF_STAT_BUCKETS][2] += {sum, sumsq} of y (the GlobLN that follows).
+// =============================================================================================
+struct Conv1dArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  double* out_sums;
+  int Cin, Cout, Lin, Lout, K, stride, pad, dil, groups;
+};
+
+__global__ __launch_bounds__(256) void srf_conv1d_kernel(Conv1dArgs a) {
+  __shared__ double red[8];
+  const long b = blockIdx.z;
+  const int co = blockIdx.y;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  const int cpg = a.Cin / a.groups, g = co / (a.Cout / a.groups);
+  float acc = a.bias ? a.bias[co] : 0.f;
+  const bool ok = l < a.Lout;
+  if (ok) {
+    const float* xb = a.x + (b * a.Cin + (long)g * cpg) * a.Lin;
+    const float* wr = a.w + (long)co * cpg * a.K;
+    const int i0 = l * a.stride - a.pad;
+    for (int ci = 0; ci < cpg; ++ci) {
+      const float* xr = xb + (long)ci * a.Lin;
+      for (int k = 0; k < a.K; ++k) {
+        const int i = i0 + k * a.dil;
+        if (i >= 0 && i < a.Lin) acc = fmaf(wr[ci * a.K + k], xr[i], acc);
+      }
+    }
+    a.y[(b * a.Cout + co) * (long)a.Lout + l] = acc;
+  }
+  if (a.out_sums) {
+    const double v = ok ? (double)acc : 0.0;
+    srf_block_stats_atomic<4>(v, v * v, srf_stat_slot(a.out_sums, b, (long)co * gridDim.x + blockIdx.x), red);
+  }
+}
+
+extern "C" int srf_conv1d(const float* x, const float* w, const float* bias, float* y, int Bt, int Cin, int Cout, int Lin,
+                          int K, int stride, int padding, int dilation, int groups, double* out_sums, void* stream) {
+  SRF_CHECK_ARG(x && w && y, "srf_conv1d: null pointer");
+  SRF_CHECK_ARG(Bt > 0 && Cin > 0 && Cout > 0 && Lin > 0 && K > 0 && stride > 0 && padding >= 0 && dilation > 0 && groups > 0,
+                "srf_conv1d: bad sizes");
+  SRF_CHECK_ARG(Cin % groups == 0 && Cout % groups == 0, "srf_conv1d: channels (%d, %d) must be divisible by groups (%d)", Cin,
+                Cout, groups);
+  const long span = (long)dilation * (K - 1) + 1;
+  SRF_CHECK_ARG((long)Lin + 2L * padding >= span, "srf_conv1d: kernel span %ld exceeds the padded input (%d + 2 x %d)", span, Lin,
+                padding);
+  Conv1dArgs a;
+  a.x = x;
+  a.w = w;
+  a.bias = bias;
+  a.y = y;
+  a.out_sums = out_sums;
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.Lin = Lin;
+  a.Lout = (int)(((long)Lin + 2L * padding - span) / stride + 1);
+  a.K = K;
+  a.stride = stride;
+  a.pad = padding;
+  a.dil = dilation;
+  a.groups = groups;
+  SRF_CHECK_ARG(Cout <= 65535 && Bt <= 65535, "srf_conv1d: too many channels / examples");
+  dim3 grid((unsigned)((a.Lout + 255) / 256), (unsigned)Cout, (unsigned)Bt);
+  hipLaunchKernelGGL(srf_conv1d_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  SRF_CHECK_LAUNCH("conv1d", stream);
+  return SRF_OK;
+}

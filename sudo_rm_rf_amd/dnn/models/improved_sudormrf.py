@@ -43,7 +43,8 @@ class GlobLN(_LayerNorm):
 
 
 class ConvNormAct(nn.Module):
-    """Conv1d + GlobLN + PReLU (reference :50-73); the model only uses kSize=1, groups=1."""
+    """Conv1d + GlobLN + PReLU (reference :50-73).  The model only uses kSize=1, groups=1 (the MFMA 1x1 kernels); any other
+    kernel size / stride / groups runs on the general srf_conv1d kernel (round 6), like the nn.Conv1d it mirrors."""
 
     def __init__(self, nIn, nOut, kSize, stride=1, groups=1):
         super().__init__()
@@ -54,11 +55,12 @@ class ConvNormAct(nn.Module):
 
     def forward(self, input):
         c = self.conv
-        if c.kernel_size != (1,) or c.stride != (1,) or c.groups != 1:
-            raise NotImplementedError("HIP path implements the pointwise ConvNormAct used by UConvBlock")
         x = _hip_only(input)
         sums = ops.new_sums(x.shape[0], x.device)
-        y = ops.pw_conv(x, c.weight.detach(), c.bias.detach(), out_sums=sums)
+        if c.kernel_size != (1,) or c.stride != (1,) or c.groups != 1:
+            y = ops.conv1d(x, c.weight.detach(), c.bias.detach(), c.stride[0], c.padding[0], c.dilation[0], c.groups, out_sums=sums)
+        else:
+            y = ops.pw_conv(x, c.weight.detach(), c.bias.detach(), out_sums=sums)
         return ops.gln_apply(y, sums, self.norm.gamma.detach(), self.norm.beta.detach(),
                              prelu=self.act.weight.detach())
 
@@ -79,7 +81,8 @@ class NormAct(nn.Module):
 
 
 class DilatedConvNorm(nn.Module):
-    """Conv1d + GlobLN (reference :138-159); the model only uses depthwise k=5, d=1, stride 1|2."""
+    """Conv1d + GlobLN (reference :138-159).  The model only uses depthwise k=5, d=1, stride 1|2 (srf_dwconv5); any other kernel
+    size / dilation / groups runs on the general srf_conv1d kernel (round 6)."""
 
     def __init__(self, nIn, nOut, kSize, stride=1, d=1, groups=1):
         super().__init__()
@@ -89,12 +92,12 @@ class DilatedConvNorm(nn.Module):
 
     def forward(self, input):
         c = self.conv
-        if not (c.kernel_size == (5,) and c.dilation == (1,) and c.groups == c.in_channels ==
-                c.out_channels and c.stride in ((1,), (2,))):
-            raise NotImplementedError("HIP path implements the depthwise k=5 DilatedConvNorm of UConvBlock")
         x = _hip_only(input)
         sums = ops.new_sums(x.shape[0], x.device)
-        y = ops.dwconv5(x, c.weight.detach(), c.bias.detach(), c.stride[0], out_sums=sums)
+        if c.kernel_size == (5,) and c.dilation == (1,) and c.groups == c.in_channels == c.out_channels and c.stride in ((1,), (2,)):
+            y = ops.dwconv5(x, c.weight.detach(), c.bias.detach(), c.stride[0], out_sums=sums)
+        else:
+            y = ops.conv1d(x, c.weight.detach(), c.bias.detach(), c.stride[0], c.padding[0], c.dilation[0], c.groups, out_sums=sums)
         return ops.gln_apply(y, sums, self.norm.gamma.detach(), self.norm.beta.detach())
 
 

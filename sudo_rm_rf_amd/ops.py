@@ -199,6 +199,23 @@ def dwconv5(x, weight, bias, stride, in_sums=None, in_gamma=None, in_beta=None, 
     return y
 
 
+def conv1d(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, out_sums=None):
+    """General Conv1d (srf_conv1d): x [Bt,Cin,Lin], weight [Cout,Cin/groups,K] -> [Bt,Cout,Lout]; not on the model's path."""
+    dev = _chk(x, weight, bias, out_sums)
+    Bt, Cin, Lin = x.shape
+    Cout, cpg, K = weight.shape
+    if cpg * groups != Cin:
+        raise RuntimeError("weight %s does not match %d input channels in %d groups" % (tuple(weight.shape), Cin, groups))
+    Lout = (Lin + 2 * padding - dilation * (K - 1) - 1) // stride + 1
+    if Lout <= 0:
+        raise RuntimeError("kernel size %d (dilation %d) exceeds the padded input length %d" % (K, dilation, Lin + 2 * padding))
+    y = torch.empty((Bt, Cout, Lout), dtype=torch.float32, device=dev)
+    rc = _lib.load().srf_conv1d(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), Bt, Cin, Cout, Lin, K, stride,
+                                padding, dilation, groups, _lib.ptr(out_sums), _lib.current_stream(dev))
+    _lib.check(rc, "srf_conv1d")
+    return y
+
+
 def merge(levels, sums, gammas, betas, out_sums=None):
     """levels[k] [Bt,C,L>>k] (pre-norm) -> merged [Bt,C,L] (improved_sudormrf.py:214-216)."""
     dev = _chk(*levels, *sums, *gammas, *betas, out_sums)

@@ -336,6 +336,58 @@ def test_submodule_forwards(manifest):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(nIn=8, nOut=12, kSize=3, stride=2, groups=4), dict(nIn=6, nOut=6, kSize=7, stride=1, groups=1),
+                                dict(nIn=16, nOut=16, kSize=1, stride=1, groups=1)],
+                         ids=["k3-s2-g4", "k7", "pointwise"])
+def test_convnormact_any_kernel_size(kw):
+    """The reference's ConvNormAct (improved_sudormrf.py:50-73) is an ordinary nn.Conv1d + GlobLN + PReLU and accepts any
+    kernel size / stride / groups; round 6: so does the mirror (general srf_conv1d kernel outside the shapes UConvBlock builds).
+    Against the same arithmetic in torch fp64 on the CPU."""
+    import torch.nn.functional as F
+    import sudo_rm_rf.dnn.models.improved_sudormrf as improved_sudormrf
+    torch.manual_seed(3)
+    m = improved_sudormrf.ConvNormAct(**kw)
+    with torch.no_grad():
+        m.norm.gamma.uniform_(0.5, 1.5)
+        m.norm.beta.normal_(0.0, 0.3)
+        m.act.weight.fill_(0.17)
+    x = torch.randn(3, kw["nIn"], 157)
+    c = m.conv
+    y = F.conv1d(x.double(), c.weight.double(), c.bias.double(), c.stride, c.padding, c.dilation, c.groups)
+    mean = y.mean(dim=(1, 2), keepdim=True)
+    var = ((y - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    want = F.prelu(m.norm.gamma.double().view(1, -1, 1) * (y - mean) / torch.sqrt(var + 1e-8) + m.norm.beta.double().view(1, -1, 1),
+                   m.act.weight.double())
+    with torch.no_grad():
+        got = m.to(DEV)(x.to(DEV)).cpu().double()
+    assert got.shape == want.shape and (got - want).abs().max().item() <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(nIn=8, nOut=8, kSize=5, stride=1, d=3, groups=8), dict(nIn=4, nOut=10, kSize=3, stride=2, d=2, groups=2),
+                                dict(nIn=8, nOut=8, kSize=5, stride=2, d=1, groups=8)],
+                         ids=["depthwise-dilated", "grouped-k3-d2", "uconv-shape"])
+def test_dilatedconvnorm_any_dilation(kw):
+    """DilatedConvNorm (improved_sudormrf.py:138-159) with any kernel size / dilation / groups, as the reference's."""
+    import torch.nn.functional as F
+    import sudo_rm_rf.dnn.models.improved_sudormrf as improved_sudormrf
+    torch.manual_seed(4)
+    m = improved_sudormrf.DilatedConvNorm(**kw)
+    with torch.no_grad():
+        m.norm.gamma.uniform_(0.5, 1.5)
+        m.norm.beta.normal_(0.0, 0.3)
+    x = torch.randn(2, kw["nIn"], 240)
+    c = m.conv
+    y = F.conv1d(x.double(), c.weight.double(), c.bias.double(), c.stride, c.padding, c.dilation, c.groups)
+    mean = y.mean(dim=(1, 2), keepdim=True)
+    var = ((y - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    want = m.norm.gamma.double().view(1, -1, 1) * (y - mean) / torch.sqrt(var + 1e-8) + m.norm.beta.double().view(1, -1, 1)
+    with torch.no_grad():
+        got = m.to(DEV)(x.to(DEV)).cpu().double()
+    assert got.shape == want.shape and (got - want).abs().max().item() <= 2e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K", [11, 21], ids=["generic-encoder", "k21-encoder"])
 @pytest.mark.parametrize("variant", ["improved", "groupcomm"])
 def test_separate_pipeline_matches_reference_recipe(variant, K):
