@@ -266,7 +266,7 @@ def test_training_step_with_and_without_fused_pairs():
     assert worst_s[1] <= 1e-2, worst_s
 
 
-@pytest.mark.parametrize("shape", ["improved_d5", "improved_d6_short", "groupcomm"])
+@pytest.mark.parametrize("shape", ["improved_d5", "improved_d6_short", "groupcomm", "improved_d2_ragged", "improved_d1"])
 def test_training_step_with_and_without_the_fused_backward_head(shape):
     """Round 6: level 0 of a block's pyramid backward and proj_1x1's norm backward run as TWO passes over {G_0, y1}
     (srf_bwd_l0p_kernel: d_0 and g_o re-computed instead of read / written) instead of the level-0 conv kernel + the norm's apply
@@ -279,6 +279,10 @@ def test_training_step_with_and_without_the_fused_backward_head(shape):
         cfg, B, T = ModelConfig("improved", 64, 128, 3, 5, 21, 128, 2), 3, 8000
     elif shape == "improved_d6_short":
         cfg, B, T = ModelConfig("improved", 32, 64, 2, 6, 21, 64, 2), 2, 1940       # L = 256 after padding: ragged last trips
+    elif shape == "improved_d2_ragged":
+        cfg, B, T = ModelConfig("improved", 16, 24, 2, 2, 21, 32, 2), 3, 2530       # D = 2: level 1 is the deepest level; L = 254 -> 256
+    elif shape == "improved_d1":
+        cfg, B, T = ModelConfig("improved", 16, 24, 2, 1, 21, 32, 2), 2, 1000       # D = 1: no fused head (nothing to fuse), both runs equal
     else:
         cfg, B, T = ModelConfig("groupcomm", 64, 128, 2, 4, 21, 64, 2, 1, 4), 2, 4000
     sd = weights.make_state_dict(cfg, seed=31)
@@ -297,7 +301,8 @@ def test_training_step_with_and_without_the_fused_backward_head(shape):
                 loss_fn(model(mix), tgt).backward()
             for fam in ("bwd_l0p_reduce", "bwd_l0p_apply", "bwd_l1h"):
                 nhead = sum(1 for k, _ in tr.launches if k == fam)
-                assert nhead == (cfg.num_blocks if flags == 0 else 0), (fam, flags, nhead, sorted(tr.names))
+                want = cfg.num_blocks if (flags == 0 and cfg.upsampling_depth > 1) else 0
+                assert nhead == want, (fam, flags, nhead, sorted(tr.names))
             grads[flags] = {k: p.grad.clone() for k, p in model.state_dict(keep_vars=True).items()}
     finally:
         ops.set_debug_flags(0)
