@@ -330,7 +330,7 @@ def pmc_traffic(kernel_family, workload, train=False):
     short = {"cfg2_improved_u16": "cfg2_bs32", "cfg3_groupcomm_u8": "cfg3_groupcomm_bs32", "cfg4_improved_u36_n2048": "cfg4_u36_n2048_bs32",
              "cfg5_improved_u36_n4096": "cfg5_u36_n4096_8s16k_bs16"}.get(workload)
     rel = None
-    for tag in ("r05", "r04", "r03"):      # the newest committed counter pass of this workload
+    for tag in ("r06", "r05", "r04", "r03"):      # the newest committed counter pass of this workload
         cand = "profiles/%s_%s%s_pmc_hbm_traffic.csv" % (tag, short, "_train_step" if train else "")
         if short is not None and os.path.exists(os.path.join(ROOT, cand)):
             rel = cand
