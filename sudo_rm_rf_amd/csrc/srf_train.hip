@@ -216,7 +216,7 @@ extern "C" size_t srf_train_saved_bytes(const srf_plan* p) { return p ? train_la
 extern "C" size_t srf_train_scratch_bytes(const srf_plan* p) { return p ? scratch_layout(p).total : 0; }
 
 static int forward_train_impl(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
-                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, bool split_tail, void* stream);
 
 // The training forward runs its 1x1 convolutions in the EXACT-fp32 CLASS (kernel mode 2: since round 3 the three-part split
 // GEMM where the 256 x 128 kernel takes the launch, else the exact fp32 MFMA kernel) unless debug flag 1<<28 is set.
@@ -230,13 +230,13 @@ extern "C" int srf_forward_train(const srf_plan* p, const float* const* P, int n
                                  void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
   const bool exact = srf_kernel_mode() == 0 && !(srf_debug_flags() & (1 << 28));
   const int prev = exact ? srf_kernel_mode_override(2) : -1;
-  const int rc = forward_train_impl(p, P, num_params, wav, out, saved, saved_bytes, scratch, scratch_bytes, stream);
+  const int rc = forward_train_impl(p, P, num_params, wav, out, saved, saved_bytes, scratch, scratch_bytes, exact, stream);
   if (exact) srf_kernel_mode_override(prev);
   return rc;
 }
 
 static int forward_train_impl(const srf_plan* p, const float* const* P, int num_params, const float* wav, float* out,
-                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, bool split_tail, void* stream) {
   SRF_CHECK_ARG(p && P && wav && out && saved && scratch, "srf_forward_train: null pointer");
   SRF_CHECK_ARG(num_params == p->n_params, "srf_forward_train: expected %d parameter tensors, got %d", p->n_params,
                 num_params);
@@ -425,7 +425,14 @@ static int forward_train_impl(const srf_plan* p, const float* const* P, int num_
   }
   rc = srf_mask_apply(m, enc, v, Bt, p->SA, N, L, stream);
   if (rc) return rc;
-  return srf_decoder(v, Pt[3], out, Bt, p->SA * N, p->SA, K, L, p->T, (float*)(sc + s.dec), stream);
+  // The decoder's frame GEMM (S N -> S K rows) is the LAST linear map of the forward: nothing downstream amplifies the 2^-17
+  // rounding of the split-bf16 GEMM (the loss is smooth in the estimates), unlike the early layers' (see above) -- so when the
+  // exact class was this function's own choice it runs on the split kernel (round 6: 292 -> 130 us at cfg 2, 4 x that at N = 2048)
+  // instead of the exact-fp32 MFMA kernel the thin output (42 rows) would otherwise fall to.
+  const int tail_prev = split_tail ? srf_kernel_mode_override(0) : -1;
+  rc = srf_decoder(v, Pt[3], out, Bt, p->SA * N, p->SA, K, L, p->T, (float*)(sc + s.dec), stream);
+  if (split_tail) srf_kernel_mode_override(tail_prev);
+  return rc;
 }
 
 static int backward_impl(const srf_plan* p, const float* const* P, float* const* G, int num_params, const float* wav,

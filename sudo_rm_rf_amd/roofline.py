@@ -227,14 +227,14 @@ def _train_family_model_groupcomm(B, C, U, D, K, N, S, T, Bt, G, A, fused_head=T
     add("pw_conv_small", U * f * L * (C + 2 * B), U * 2.0 * Bt * B * C * L / G)        # res_conv + residual
     add("pw_conv_x3w4<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
     add("mask_apply", f * L * (2 * SN + N), 2.0 * Bt * SN * L)
-    add("pw_conv_bf16x3_p8<0>", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)
+    add("pw_conv_bf16x3_w8", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)
     add("overlap_add", f * (SK * L + S * A * T), 3.0 * Bt * S * A * T)
     add("pit_sisdr_stats", f * 2 * S * T, 2.0 * Bt * (4 * S + S * S) * T)
     add("pit_sisdr_grad", f * 3 * S * T, 4.0 * Bt * S * T)
     # ---- backward: tail (as the Improved model)
     add("frames_gather", f * (S * A * T + SK * L) + f * (A * T + A * K * L))
     add("pw_wgrad", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)
-    add("pw_conv_mfma", f * L * (SK + SN), 2.0 * Bt * SN * SK * L)
+    add("pw_conv_bf16x3_p8<0>", f * L * (SK + SN), 2.0 * Bt * SN * SK * L)
     add("mask_bwd", f * L * (3 * SN + 2 * N), 3.0 * Bt * SN * L)
     add("pw_wgrad", f * L * (SN + B), 2.0 * Bt * SN * B * L)
     add("pw_conv_x3w<0>", f * L * (SN + B), 2.0 * Bt * SN * B * L)
@@ -332,7 +332,7 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, dgrad_pair
     add("pw_conv_x3w4<3>", f * L * (B + SN), 2.0 * Bt * B * SN * L)
     add("mask_apply", f * L * (2 * SN + N), 2.0 * Bt * SN * L)
     # decoder (stand-alone form): weight transpose, frame GEMM S N -> S K, overlap-add
-    add("pw_conv_bf16x3_p8<0>", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)            # (K = S N, 42 rows: the 128 x 128 kernel)
+    add("pw_conv_bf16x3_w8", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)            # (K = S N, 42 rows: the 128 x 128 split kernel -- round 6: no longer the exact-fp32 MFMA kernel)
     add("overlap_add", f * (SK * L + S * A * T), 3.0 * Bt * S * A * T)
     # ---- loss: one streaming pass over estimates + targets, the gradient pass
     add("pit_sisdr_stats", f * 2 * S * T, 2.0 * Bt * (4 * S + S * S) * T)
@@ -340,7 +340,7 @@ def train_family_model(variant, B, C, U, D, K, N, S, T, Bt, G=1, A=1, dgrad_pair
     # ---- backward: tail
     add("frames_gather", f * (S * A * T + SK * L) + f * (A * T + A * K * L))
     add("pw_wgrad", f * L * (SN + SK), 2.0 * Bt * SN * SK * L)                       # decoder weight
-    add("pw_conv_mfma", f * L * (SK + SN), 2.0 * Bt * SN * SK * L)                   # decoder data gradient (frames -> g_v; K = 42 padded: generic MFMA kernel)
+    add("pw_conv_bf16x3_p8<0>", f * L * (SK + SN), 2.0 * Bt * SN * SK * L)                   # decoder data gradient (frames -> g_v; K = 42 padded to 64: the 128 x 128 split kernel)
     add("mask_bwd", f * L * (3 * SN + 2 * N), 3.0 * Bt * SN * L)
     add("pw_wgrad", f * L * (SN + B), 2.0 * Bt * SN * B * L)                         # mask_net weight
     add("pw_conv_x3w<0>", f * L * (SN + B), 2.0 * Bt * SN * B * L)                   # mask_net data gradient
