@@ -514,6 +514,26 @@ def test_input_gradient_matches_reference_golden(name):
         assert (p1.grad - p2.grad).abs().max().item() <= 1e-5 * max(p1.grad.abs().max().item(), 1e-30)
 
 
+def test_input_gradient_two_audio_channels_matches_oracle_autograd():
+    """d loss / d mixture for a GroupComm model with in_audio_channels = 2 (encoder weight [N, 2, K]: the transposed convolution
+    of srf_backward_wav with two output channels; no reference fixture has A = 2 in training): against torch autograd over the
+    oracle's fp64 forward for a linear loss."""
+    cfg = ModelConfig("groupcomm", 32, 64, 2, 3, 21, 24, 2, 2, 4)
+    sd = weights.make_state_dict(cfg, seed=9)
+    g = torch.Generator().manual_seed(2)
+    mix = torch.randn(2, 2, 1230, generator=g)
+    probe = torch.randn(2, cfg.num_sources * 2, 1230, generator=g)
+    x64 = mix.double().requires_grad_()
+    sd64 = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    (torch_oracle.forward(cfg, sd64, x64) * probe.double()).sum().backward()
+    model = build(cfg, sd).train()
+    x = mix.to(DEV).requires_grad_()
+    (model(x) * probe.to(DEV)).sum().backward()
+    want = x64.grad
+    assert x.grad.shape == want.shape
+    assert ((x.grad.cpu().double() - want).abs().max() / want.abs().max()).item() <= 2e-4
+
+
 def test_distributed_data_parallel_wrapper_single_rank():
     """torch DistributedDataParallel around the module (world size 1, RCCL): its gradient hooks fire on the gradients
     the HIP backward returns, and the result equals the plain module's."""
