@@ -9,6 +9,8 @@
 // Split-K: the (example, time-chunk) pieces are dealt round-robin to P blocks per output tile, each block
 // keeps its 128x128 accumulator over all its pieces and writes ONE partial tile; a second kernel sums the P
 // partials (deterministic, no atomics).
+#include <type_traits>
+
 #include "srf_pw.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -41,8 +43,11 @@ __device__ __forceinline__ void wg_split8(const float (&v)[8], bf16x8& hi, bf16x
 }
 
 // PRO: 0 identity, 1 GlobLN, 2 GlobLN + PReLU, 3 PReLU
-template <int PRO>
-__global__ __launch_bounds__(512, 2) void srf_pw_wgrad_kernel(WgArgs a) {
+// FULL (round 6): M and N multiples of 128 and every time chunk a whole number of 32-wide k-tiles (L % 32 == 0) -- no row / tail masks.
+// The kernel is VALU-issue-bound, not MFMA- or HBM-bound (r06 counters: 13.1 VALU instructions per MFMA, VALU issue 64 % of the kernel's
+// cycles, MFMA pipe 39 %): the masks were 16 multiplies + 16 address selects of the 136 VALU instructions per k-tile.
+template <int PRO, bool FULL>
+__global__ __launch_bounds__(512, 4) void srf_pw_wgrad_kernel(WgArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * WG_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_kernel(WgArgs a) {
 
   // staging: thread -> row r = tid>>2 of BOTH tiles, 8-k packet pk = tid&3 (2 float4 each)
   const int r = tid >> 2, pk = tid & 3;
-  const bool g_ok = (m0 + r) < M, x_ok = (n0 + r) < N;
+  const bool g_ok = FULL || (m0 + r) < M, x_ok = FULL || (n0 + r) < N;
   const int gm = g_ok ? m0 + r : 0, xn = x_ok ? n0 + r : 0;
   const float g_msk = g_ok ? 1.f : 0.f, x_msk = x_ok ? 1.f : 0.f;
   const int lds_off = r * WG_PITCH + pk * 16;
@@ -97,48 +102,71 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_kernel(WgArgs a) {
       sc = gam * rstd;
       sh = bet - mean * sc;
     }
-    const float* gsrc = a.g + ((size_t)b * M + gm) * L;
-    const float* xsrc = a.x + ((size_t)b * N + xn) * L;
+    const float* gsrc = a.g + ((size_t)b * M + gm) * L + l_beg + pk * 8;
+    const float* xsrc = a.x + ((size_t)b * N + xn) * L + l_beg + pk * 8;
 
     float4 rg[2], rx[2];
     float km[2];   // 1 inside the chunk, 0 beyond its end (L % 4 == 0: a float4 is entirely in or out)
-    auto gload = [&](int kt) {
+    auto gload_g = [&](int kt) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int l = l_beg + kt * WG_BK + pk * 8 + h * 4;
-        const bool in = l < l_end;
-        const int lc = in ? l : l_beg;
-        rg[h] = *reinterpret_cast<const float4*>(gsrc + lc);
-        rx[h] = *reinterpret_cast<const float4*>(xsrc + lc);
-        km[h] = in ? 1.f : 0.f;
+        if constexpr (FULL) {
+          rg[h] = *reinterpret_cast<const float4*>(gsrc + kt * WG_BK + h * 4);
+        } else {
+          const int o = kt * WG_BK + h * 4;
+          const bool in = l_beg + pk * 8 + o < l_end;
+          rg[h] = *reinterpret_cast<const float4*>(gsrc + (in ? o : 0));
+          km[h] = in ? 1.f : 0.f;
+        }
       }
     };
-    auto lds_store = [&](int stage) {
-      char* base = smem + stage * WG_STAGE;
-      float vg[8], vx[8];
+    auto gload_x = [&](int kt) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const float mg = km[h] * g_msk, mx = km[h] * x_msk;
-        const float gg[4] = {rg[h].x, rg[h].y, rg[h].z, rg[h].w};
-        const float xx[4] = {rx[h].x, rx[h].y, rx[h].z, rx[h].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          vg[4 * h + j] = gg[j] * mg;
-          float v = xx[j];
-          if (PRO == 1 || PRO == 2) v = fmaf(v, sc, sh);
-          if (PRO == 2 || PRO == 3) v = srf_prelu(v, slope);
-          vx[4 * h + j] = v * mx;
+        if constexpr (FULL) {
+          rx[h] = *reinterpret_cast<const float4*>(xsrc + kt * WG_BK + h * 4);
+        } else {
+          const int o = kt * WG_BK + h * 4;
+          const bool in = l_beg + pk * 8 + o < l_end;
+          rx[h] = *reinterpret_cast<const float4*>(xsrc + (in ? o : 0));
         }
+      }
+    };
+    // the loaded packets, prologue applied, split into the stage's images -- G and X separately (8 live result registers, not 16)
+    auto put_g = [&](int stage) {
+      float vg[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float gg[4] = {rg[h].x, rg[h].y, rg[h].z, rg[h].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vg[4 * h + j] = FULL ? gg[j] : gg[j] * (km[h] * g_msk);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) bsum += vg[j];
       bf16x8 hi, lo;
       wg_split8(vg, hi, lo);
-      *reinterpret_cast<bf16x8*>(base + 0 * WG_IMG + lds_off) = hi;
-      *reinterpret_cast<bf16x8*>(base + 1 * WG_IMG + lds_off) = lo;
+      char* base = smem + stage * WG_STAGE + lds_off;
+      *reinterpret_cast<bf16x8*>(base + 0 * WG_IMG) = hi;
+      *reinterpret_cast<bf16x8*>(base + 1 * WG_IMG) = lo;
+    };
+    auto put_x = [&](int stage, float kmx0, float kmx1) {
+      float vx[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float xx[4] = {rx[h].x, rx[h].y, rx[h].z, rx[h].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = xx[j];
+          if (PRO == 1 || PRO == 2) v = fmaf(v, sc, sh);
+          if (PRO == 2 || PRO == 3) v = srf_prelu(v, slope);
+          vx[4 * h + j] = FULL ? v : v * ((h ? kmx1 : kmx0) * x_msk);
+        }
+      }
+      bf16x8 hi, lo;
       wg_split8(vx, hi, lo);
-      *reinterpret_cast<bf16x8*>(base + 2 * WG_IMG + lds_off) = hi;
-      *reinterpret_cast<bf16x8*>(base + 3 * WG_IMG + lds_off) = lo;
+      char* base = smem + stage * WG_STAGE + lds_off;
+      *reinterpret_cast<bf16x8*>(base + 2 * WG_IMG) = hi;
+      *reinterpret_cast<bf16x8*>(base + 3 * WG_IMG) = lo;
     };
     auto mma_tile = [&](int stage) {
       const char* base = smem + stage * WG_STAGE;
@@ -160,17 +188,154 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_kernel(WgArgs a) {
       }
     };
 
+    auto mma_half = [&](int stage, int ks) {
+      const char* base = smem + stage * WG_STAGE;
+      const int ko = ks * 32;
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + 0 * WG_IMG + a_row + ko);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + 1 * WG_IMG + a_row + ko);
+      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(base + 2 * WG_IMG + b_row0 + ko);
+      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(base + 2 * WG_IMG + b_row1 + ko);
+      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(base + 3 * WG_IMG + b_row0 + ko);
+      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(base + 3 * WG_IMG + b_row1 + ko);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
+    };
+
     // one register set, LDS double-buffered: tile kt+1 is split into the other stage and tile kt+2's loads
-    // are in flight while tile kt's MFMAs run
-    gload(0);
+    // are in flight while tile kt's MFMAs run.  Round 6: the steady state is ONE basic block (no kt + 1 / kt + 2 conditionals): the first
+    // half k-tile's MFMAs with G's split in their shadow, the second half's with X's, each operand's next loads issued as soon as
+    // its registers are free.
+    gload_g(0);
+    gload_x(0);
     __syncthreads();          // previous chunk's last MFMAs are done with both stages
-    lds_store(0);
-    if (nk > 1) gload(1);
+    {
+      const float k0 = km[0], k1 = km[1];
+      put_g(0);
+      put_x(0, k0, k1);
+    }
+    if (nk > 1) {
+      gload_g(1);
+      gload_x(1);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) lds_store((kt + 1) & 1);
-      if (kt + 2 < nk) gload(kt + 2);
-      mma_tile(kt & 1);
+    int kt = 0;
+    if constexpr (FULL) {
+      // Steady state written out with the order FIXED (sched_barrier(0): nothing moves across): each MFMA (8 passes = 32 cycles of
+      // the matrix pipe) is followed by the split of two of tile kt + 1's sixteen values (about 12 VALU instructions), so the
+      // wavefront's own VALU work sits in its MFMAs' shadow; left to itself the scheduler issues the MFMAs in a burst and the
+      // hundred VALU instructions after it.  G first (its registers are then free for tile kt + 2's loads), then X.
+      for (; kt + 2 < nk; ++kt) {
+        const int st = kt & 1;
+        const char* rb = smem + st * WG_STAGE;
+        char* wb = smem + (st ^ 1) * WG_STAGE + lds_off;
+        bf16x8 ah, al, bh0, bh1, bl0, bl1, hi, lo;
+        auto frags = [&](int ko) {
+          ah = *reinterpret_cast<const bf16x8*>(rb + 0 * WG_IMG + a_row + ko);
+          al = *reinterpret_cast<const bf16x8*>(rb + 1 * WG_IMG + a_row + ko);
+          bh0 = *reinterpret_cast<const bf16x8*>(rb + 2 * WG_IMG + b_row0 + ko);
+          bh1 = *reinterpret_cast<const bf16x8*>(rb + 2 * WG_IMG + b_row1 + ko);
+          bl0 = *reinterpret_cast<const bf16x8*>(rb + 3 * WG_IMG + b_row0 + ko);
+          bl1 = *reinterpret_cast<const bf16x8*>(rb + 3 * WG_IMG + b_row1 + ko);
+        };
+        auto pair_g = [&](int q) {          // values 2 q, 2 q + 1 of G's packet
+          const float v0 = q == 0 ? rg[0].x : q == 1 ? rg[0].z : q == 2 ? rg[1].x : rg[1].z;
+          const float v1 = q == 0 ? rg[0].y : q == 1 ? rg[0].w : q == 2 ? rg[1].y : rg[1].w;
+          bsum += v0;
+          bsum += v1;
+          const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+          hi[2 * q] = h0;
+          hi[2 * q + 1] = h1;
+          lo[2 * q] = (__bf16)(v0 - (float)h0);
+          lo[2 * q + 1] = (__bf16)(v1 - (float)h1);
+        };
+        auto pair_x = [&](int q) {
+          float v0 = q == 0 ? rx[0].x : q == 1 ? rx[0].z : q == 2 ? rx[1].x : rx[1].z;
+          float v1 = q == 0 ? rx[0].y : q == 1 ? rx[0].w : q == 2 ? rx[1].y : rx[1].w;
+          if (PRO == 1 || PRO == 2) {
+            v0 = fmaf(v0, sc, sh);
+            v1 = fmaf(v1, sc, sh);
+          }
+          if (PRO == 2 || PRO == 3) {
+            v0 = srf_prelu(v0, slope);
+            v1 = srf_prelu(v1, slope);
+          }
+          const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+          hi[2 * q] = h0;
+          hi[2 * q + 1] = h1;
+          lo[2 * q] = (__bf16)(v0 - (float)h0);
+          lo[2 * q + 1] = (__bf16)(v1 - (float)h1);
+        };
+#define WG_SB() __builtin_amdgcn_sched_barrier(0)
+#define WG_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
+        frags(0);
+        WG_SB();
+        acc0 = WG_MFMA(al, bh0, acc0);
+        pair_g(0);
+        WG_SB();
+        acc1 = WG_MFMA(al, bh1, acc1);
+        pair_g(1);
+        WG_SB();
+        acc0 = WG_MFMA(ah, bl0, acc0);
+        pair_g(2);
+        WG_SB();
+        acc1 = WG_MFMA(ah, bl1, acc1);
+        pair_g(3);
+        WG_SB();
+        acc0 = WG_MFMA(ah, bh0, acc0);
+        *reinterpret_cast<bf16x8*>(wb + 0 * WG_IMG) = hi;
+        *reinterpret_cast<bf16x8*>(wb + 1 * WG_IMG) = lo;
+        gload_g(kt + 2);
+        WG_SB();
+        acc1 = WG_MFMA(ah, bh1, acc1);
+        frags(32);
+        pair_x(0);
+        WG_SB();
+        acc0 = WG_MFMA(al, bh0, acc0);
+        pair_x(1);
+        WG_SB();
+        acc1 = WG_MFMA(al, bh1, acc1);
+        pair_x(2);
+        WG_SB();
+        acc0 = WG_MFMA(ah, bl0, acc0);
+        pair_x(3);
+        WG_SB();
+        acc1 = WG_MFMA(ah, bl1, acc1);
+        *reinterpret_cast<bf16x8*>(wb + 2 * WG_IMG) = hi;
+        *reinterpret_cast<bf16x8*>(wb + 3 * WG_IMG) = lo;
+        gload_x(kt + 2);
+        WG_SB();
+        acc0 = WG_MFMA(ah, bh0, acc0);
+        acc1 = WG_MFMA(ah, bh1, acc1);
+        WG_SB();
+#undef WG_SB
+#undef WG_MFMA
+        __syncthreads();
+      }
+    } else {
+      for (; kt + 2 < nk; ++kt) {
+        const int st = kt & 1, nx = st ^ 1;
+        const float k0 = km[0], k1 = km[1];       // (tile kt + 1's masks, before gload_g(kt + 2) overwrites them)
+        mma_half(st, 0);
+        put_g(nx);
+        gload_g(kt + 2);
+        mma_half(st, 1);
+        put_x(nx, k0, k1);
+        gload_x(kt + 2);
+        __syncthreads();
+      }
+    }
+    for (; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        const float k0 = km[0], k1 = km[1];
+        put_g((kt + 1) & 1);
+        put_x((kt + 1) & 1, k0, k1);
+      }
+      mma_half(kt & 1, 0);
+      mma_half(kt & 1, 1);
       __syncthreads();
     }
   }
@@ -193,6 +358,245 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_kernel(WgArgs a) {
     bsum += __shfl_xor(bsum, 1, 64);
     bsum += __shfl_xor(bsum, 2, 64);
     if (pk == 0 && g_ok) a.bias_part[(size_t)p * M + m0 + r] = bsum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6: the 256 x 128 (or 128 x 256) tile, ONE block per CU.
+// What binds the 128 x 128 kernel above (ablation builds, profiles/r06_wgrad_ablation_and_wide_tile.txt): not the MFMAs (without
+// them 95.6 of 99.0 us), not the split's VALU work (96.3), not the barriers or the LDS writes -- the GLOBAL LOADS (without them 75.5 us):
+// with 8 tiles of 128 x 128 for a 256 x 512 gradient every G row is fetched four times and every X row twice, 840 MB through L2 for 315 MB
+// of operands, by wavefronts that all issue their loads at the same point of a barrier-locked loop.  A tile that spans the whole of the
+// smaller operand (BM = 256 for Cout = 256, BN = 256 for Cin = 256) fetches that operand's rows once per output COLUMN block and the
+// other operand once: 630 MB; 24 MFMAs per wavefront and k-tile against 12 with 24 instead of 16 values to split (1 value per MFMA
+// instead of 1.33) and 0.67 fragment reads per MFMA instead of 1; eight wavefronts with 64 x 64 accumulators (2 per SIMD, up to 256
+// VGPRs), the split of tile kt + 1 written out between the MFMAs of tile kt as in the FULL form above.
+// Full shapes only (Cout % BM == 0, Cin % BN == 0, L % 32 == 0); same partial-tile output and reduction as the kernel above.
+// ---------------------------------------------------------------------------------------------
+template <int PRO, int BM, int BN>
+__global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wsmem[];
+  constexpr int NG = BM / 128, NX = BN / 128, NP = NG + NX;      // 8-k packets per thread and k-tile: G rows, X rows
+  constexpr int IMG_G = BM * WG_PITCH, IMG_X = BN * WG_PITCH;
+  constexpr int OFF_GH = 0, OFF_GL = IMG_G, OFF_XH = 2 * IMG_G, OFF_XL = 2 * IMG_G + IMG_X;
+  constexpr int STAGE = 2 * (IMG_G + IMG_X);
+  constexpr int WN = BN / 64;                                    // wavefronts along N (8 / WN along M)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntiles = a.nMt * a.nNt;
+  int tile, p;
+  if (a.xcd_map) {        // XCD x owns the partials p = x (mod 8): the tiles of one partial share their operand rows through one L2
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % ntiles;
+    p = (j / ntiles) * 8 + xcd;
+  } else {
+    tile = blockIdx.x % ntiles;
+    p = blockIdx.x / ntiles;
+  }
+  const int m0 = (tile % a.nMt) * BM, n0 = (tile / a.nMt) * BN;
+  const int L = a.L, M = a.M, N = a.N;
+  const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
+
+  // staging: thread -> rows r, r + 128 (, ...) of the G tile and of the X tile, 8-k packet pk
+  const int r = tid >> 2, pk = tid & 3;
+  const int lds_off = r * WG_PITCH + pk * 16;
+  float gam[NX], bet[NX];
+#pragma unroll
+  for (int q = 0; q < NX; ++q) {
+    gam[q] = 1.f;
+    bet[q] = 0.f;
+    if (PRO == 1 || PRO == 2) {
+      gam[q] = a.nrm.gamma[n0 + r + 128 * q];
+      bet[q] = a.nrm.beta[n0 + r + 128 * q];
+    }
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float bsum[NG];
+#pragma unroll
+  for (int q = 0; q < NG; ++q) bsum[q] = 0.f;
+  const int frag = (lane & 31) * WG_PITCH + (lane >> 5) * 16;
+  const int a_row = (wm * 64) * WG_PITCH + frag, b_row = (wn * 64) * WG_PITCH + frag;
+
+  const int nchunks = a.Bt * a.nKc;
+  for (int c = p; c < nchunks; c += a.P) {
+    const int b = c / a.nKc, kc = c - b * a.nKc;
+    const int l_beg = kc * a.kc_len;
+    const int l_end = min(l_beg + a.kc_len, L);
+    const int nk = (l_end - l_beg) / WG_BK;
+    float sc[NX], sh[NX];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      sc[q] = 1.f;
+      sh[q] = 0.f;
+    }
+    if (PRO == 1 || PRO == 2) {
+      float mean, rstd;
+      srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
+#pragma unroll
+      for (int q = 0; q < NX; ++q) {
+        sc[q] = gam[q] * rstd;
+        sh[q] = bet[q] - mean * sc[q];
+      }
+    }
+    // uniform bases (SGPRs) + ONE 32-bit per-thread element offset: every load is `global_load_dwordx4 v, v_off, s[base]`, no 64-bit
+    // address pairs held in VGPRs
+    const float* gsrc = a.g + ((size_t)b * M + m0) * L + l_beg;
+    const float* xsrc = a.x + ((size_t)b * N + n0) * L + l_beg;
+    const unsigned tbyte = ((unsigned)r * (unsigned)L + (unsigned)pk * 8u) * 4u;      // (< 2^31: 128 rows of one example)
+    const size_t row128 = (size_t)128 * L;
+
+    // One register set, as in the 128 x 128 kernel: while tile kt's MFMAs run, tile kt + 1 is split out of it into the other LDS stage and
+    // its packets are re-loaded with tile kt + 2.  (Two sets -- two k-tiles of loads in flight per thread, 96 KB per CU -- were built and
+    // measured: 250-256 VGPRs with 12-29 spilled in the GlobLN forms, 101 us against 93.5 us for one set at the cfg-2 shapes.)
+    float4 rg[1][NG][2], rx[1][NX][2];
+    auto gload = [&](auto SET, int u, int kt) {        // packet u: G packets first, then X packets
+      constexpr int S = decltype(SET)::value;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (u < NG)
+          rg[S][u < NG ? u : 0][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gsrc + u * row128 + kt * WG_BK + h * 4) + tbyte);
+        else
+          rx[S][u < NG ? 0 : u - NG][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xsrc + (u - NG) * row128 + kt * WG_BK + h * 4) + tbyte);
+      }
+    };
+    // values 2 e, 2 e + 1 of packet u: prologue, hi / lo split into (hi, lo)[2 e, 2 e + 1]
+    auto pair = [&](auto SET, int u, int e, bf16x8& hi, bf16x8& lo) {
+      constexpr int S = decltype(SET)::value;
+      float v0, v1;
+      if (u < NG) {
+        const float4 t = rg[S][u < NG ? u : 0][e >> 1];
+        v0 = (e & 1) ? t.z : t.x;
+        v1 = (e & 1) ? t.w : t.y;
+        bsum[u < NG ? u : 0] += v0;
+        bsum[u < NG ? u : 0] += v1;
+      } else {
+        const int q = u < NG ? 0 : u - NG;
+        const float4 t = rx[S][q][e >> 1];
+        v0 = (e & 1) ? t.z : t.x;
+        v1 = (e & 1) ? t.w : t.y;
+        if (PRO == 1 || PRO == 2) {
+          v0 = fmaf(v0, sc[q], sh[q]);
+          v1 = fmaf(v1, sc[q], sh[q]);
+        }
+        if (PRO == 2 || PRO == 3) {
+          v0 = srf_prelu(v0, slope);
+          v1 = srf_prelu(v1, slope);
+        }
+      }
+      const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+      hi[2 * e] = h0;
+      hi[2 * e + 1] = h1;
+      lo[2 * e] = (__bf16)(v0 - (float)h0);
+      lo[2 * e + 1] = (__bf16)(v1 - (float)h1);
+    };
+    auto store = [&](int u, int stage, const bf16x8& hi, const bf16x8& lo) {
+      char* base = wsmem + stage * STAGE + lds_off;
+      if (u < NG) {
+        *reinterpret_cast<bf16x8*>(base + OFF_GH + u * 128 * WG_PITCH) = hi;
+        *reinterpret_cast<bf16x8*>(base + OFF_GL + u * 128 * WG_PITCH) = lo;
+      } else {
+        *reinterpret_cast<bf16x8*>(base + OFF_XH + (u - NG) * 128 * WG_PITCH) = hi;
+        *reinterpret_cast<bf16x8*>(base + OFF_XL + (u - NG) * 128 * WG_PITCH) = lo;
+      }
+    };
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+    auto frags = [&](int stage, int ko) {
+      const char* rb = wsmem + stage * STAGE;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(rb + OFF_GH + a_row + i * 32 * WG_PITCH + ko);
+        al[i] = *reinterpret_cast<const bf16x8*>(rb + OFF_GL + a_row + i * 32 * WG_PITCH + ko);
+        bh[i] = *reinterpret_cast<const bf16x8*>(rb + OFF_XH + b_row + i * 32 * WG_PITCH + ko);
+        bl[i] = *reinterpret_cast<const bf16x8*>(rb + OFF_XL + b_row + i * 32 * WG_PITCH + ko);
+      }
+    };
+    // MFMA e of a half k-tile (0 .. 11): pass e / 4 = lo x hi, hi x lo, hi x hi (small terms first); accumulator (i, j) = ((e % 4) / 2, e % 2)
+    auto mfma = [&](int e) {
+      const int pass = e >> 2, i = (e & 3) >> 1, j = e & 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pass == 0 ? al[i] : ah[i], pass == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+    };
+    // One k-tile with the order FIXED (sched_barrier(0)): the 24 MFMAs of tile kt and, after every second one, the split of two of tile
+    // kt + 1's 8 NP values (SPLIT); a packet's registers take tile kt + 2's loads as soon as its last pair has been split (RELOAD).
+    auto step = [&](int kt, auto SET, auto SPLIT, auto RELOAD) {
+      const int st = kt & 1;
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        frags(st, ks * 32);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+          mfma(2 * s6);
+          mfma(2 * s6 + 1);
+          const int w = ks * 6 + s6;           // work slot 0 .. 11
+          if (decltype(SPLIT)::value && w < 4 * NP) {
+            const int u = w >> 2, e = w & 3;
+            pair(SET, u, e, hi, lo);
+            if (e == 3) {
+              store(u, st ^ 1, hi, lo);
+              if (decltype(RELOAD)::value) gload(SET, u, kt + 2);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using Yes = std::true_type;
+    using No = std::false_type;
+
+#pragma unroll
+    for (int u = 0; u < NP; ++u) gload(S0{}, u, 0);
+    __syncthreads();          // the previous chunk's last MFMAs are done with both stages
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pair(S0{}, u, e, hi, lo);
+      store(u, 0, hi, lo);
+    }
+    if (nk > 1) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u) gload(S0{}, u, 1);
+    }
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) step(kt, S0{}, Yes{}, Yes{});
+    for (; kt < nk; ++kt) {
+      if (kt + 1 < nk) step(kt, S0{}, Yes{}, No{});
+      else step(kt, S0{}, No{}, No{});
+    }
+  }
+
+  // ---- partial tile out (C/D layout of the 32x32 MFMA: col = lane&31, row = (rr&3) + 8*(rr>>2) + 4*(lane>>5))
+  float* out = a.part + (size_t)p * M * N;
+  const int col = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * kh;
+        out[(size_t)(m0 + wm * 64 + i * 32 + row) * N + n0 + wn * 64 + j * 32 + col] = acc[i][j][rr];
+      }
+  if (a.bias_part && (tile / a.nMt) == 0) {
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {         // the 4 threads of a row hold disjoint k packets
+      float t = bsum[q];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      if (pk == 0) a.bias_part[(size_t)p * M + m0 + r + 128 * q] = t;
+    }
   }
 }
 
@@ -490,11 +894,42 @@ static void wg_geometry(int M, int N, int L, int Bt, WgArgs* a) {
   a->xcd_map = (a->P % 8 == 0 && !(srf_debug_flags() & 4096)) ? 1 : 0;
 }
 
+// The wide tile (srf_pw_wgrad_wide_kernel): 1 = 256 x 128, 2 = 128 x 256, 0 = not for this shape.  (Debug flag 1 << 18: never -- A/B.)
+static int wg_wide_form(int M, int N, int L) {
+  if (L % WG_BK || srf_kernel_mode() == 1 || (srf_debug_flags() & (1 << 18))) return 0;
+  if (M % 256 == 0 && N % 128 == 0) return 1;
+  if (M % 128 == 0 && N % 256 == 0) return 2;
+  return 0;
+}
+static void wg_geometry_wide(int form, int M, int N, int L, int Bt, WgArgs* a) {
+  a->nMt = M / (form == 1 ? 256 : 128);
+  a->nNt = N / (form == 1 ? 128 : 256);
+  a->kc_len = 800;
+  if (a->kc_len > L) a->kc_len = L;
+  a->nKc = (L + a->kc_len - 1) / a->kc_len;
+  const int ntiles = a->nMt * a->nNt, nchunks = Bt * a->nKc;
+  int P = (256 + ntiles - 1) / ntiles;          // ONE block per CU
+  if (P > nchunks) P = nchunks;
+  if (P > 128) P = 128;
+  if (P >= 8 && (P & 7)) {
+    const int up = (P + 7) & ~7, down = P & ~7;
+    if (up <= nchunks && up <= 128) P = up;
+    else if (5 * down >= 4 * P) P = down;
+  }
+  a->P = P < 1 ? 1 : P;
+  a->xcd_map = (a->P % 8 == 0) ? 1 : 0;
+}
+
 extern "C" size_t srf_pw_wgrad_scratch_bytes(int Bt, int Cout, int Cin, int L) {
   if (Bt <= 0 || Cout <= 0 || Cin <= 0 || L <= 0) return 0;
   WgArgs a;
   wg_geometry(Cout, Cin, L, Bt, &a);
   size_t P = a.P;
+  if ((L % WG_BK) == 0 && ((Cout % 256 == 0 && Cin % 128 == 0) || (Cout % 128 == 0 && Cin % 256 == 0))) {
+    WgArgs w;
+    wg_geometry_wide(Cout % 256 == 0 && Cin % 128 == 0 ? 1 : 2, Cout, Cin, L, Bt, &w);
+    if ((size_t)w.P > P) P = w.P;
+  }
   if (wg_small_ok(Cout, Cin, L)) {
     const size_t ps = wg_small_blocks(Bt, Cout, Cin, L);
     if (ps > P) P = ps;
@@ -554,14 +989,46 @@ extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* i
       default: hipLaunchKernelGGL(srf_pw_wgrad_small_kernel<3>, gs, bs, lds, st, a, LC, npl); break;
     }
     SRF_CHECK_LAUNCH("pw_wgrad_small", st);
+  } else if (const int wide = wg_wide_form(Cout, Cin, L)) {
+    wg_geometry_wide(wide, Cout, Cin, L, Bt, &a);
+    a.bias_part = dbias ? a.part + (size_t)a.P * Cout * Cin : nullptr;
+    constexpr int lds = 2 * 2 * (256 + 128) * WG_PITCH;
+    const long ok = srf_device_cached(8, [](void*) -> long {
+      bool good = true;
+      const void* fns[] = {(const void*)&srf_pw_wgrad_wide_kernel<0, 256, 128>, (const void*)&srf_pw_wgrad_wide_kernel<1, 256, 128>,
+                           (const void*)&srf_pw_wgrad_wide_kernel<2, 256, 128>, (const void*)&srf_pw_wgrad_wide_kernel<3, 256, 128>,
+                           (const void*)&srf_pw_wgrad_wide_kernel<0, 128, 256>, (const void*)&srf_pw_wgrad_wide_kernel<1, 128, 256>,
+                           (const void*)&srf_pw_wgrad_wide_kernel<2, 128, 256>, (const void*)&srf_pw_wgrad_wide_kernel<3, 128, 256>};
+      for (const void* f : fns) good &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+      return good ? 1 : 0;
+    }, nullptr);
+    SRF_CHECK_ARG(ok == 1, "srf_pw_wgrad: cannot reserve %d bytes of LDS", lds);
+    dim3 grid((unsigned)(a.nMt * a.nNt * a.P)), block(512);
+#define WG_WIDE(P_) \
+  if (wide == 1) hipLaunchKernelGGL((srf_pw_wgrad_wide_kernel<P_, 256, 128>), grid, block, lds, st, a); \
+  else hipLaunchKernelGGL((srf_pw_wgrad_wide_kernel<P_, 128, 256>), grid, block, lds, st, a)
+    switch (pro) {
+      case 0: WG_WIDE(0); break;
+      case 1: WG_WIDE(1); break;
+      case 2: WG_WIDE(2); break;
+      default: WG_WIDE(3); break;
+    }
+#undef WG_WIDE
+    SRF_CHECK_LAUNCH("pw_wgrad", st);
   } else {
   dim3 grid((unsigned)(a.nMt * a.nNt * a.P)), block(512);
+  // (debug flag 1 << 19: the masked form for full shapes too -- A/B)
+  const bool full = Cout % WG_BM == 0 && Cin % WG_BN == 0 && L % WG_BK == 0 && a.kc_len % WG_BK == 0 && !(srf_debug_flags() & (1 << 19));
+#define WG_GO(P_) \
+  if (full) hipLaunchKernelGGL((srf_pw_wgrad_kernel<P_, true>), grid, block, 0, st, a); \
+  else hipLaunchKernelGGL((srf_pw_wgrad_kernel<P_, false>), grid, block, 0, st, a)
   switch (pro) {
-    case 0: hipLaunchKernelGGL(srf_pw_wgrad_kernel<0>, grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL(srf_pw_wgrad_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(srf_pw_wgrad_kernel<2>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(srf_pw_wgrad_kernel<3>, grid, block, 0, st, a); break;
+    case 0: WG_GO(0); break;
+    case 1: WG_GO(1); break;
+    case 2: WG_GO(2); break;
+    default: WG_GO(3); break;
   }
+#undef WG_GO
   SRF_CHECK_LAUNCH("pw_wgrad", st);
   }
   int rc;

@@ -36,7 +36,10 @@ def sums64(x):
 
 @pytest.mark.parametrize("Bt,Cin,Cout,L", [(3, 256, 512, 3200), (2, 512, 256, 832), (2, 64, 42, 200), (5, 48, 160, 132),
                                            (1, 16, 32, 36), (32, 256, 512, 3200), (64, 16, 32, 400), (24, 32, 16, 3200),
-                                           (8, 16, 48, 200), (5, 48, 16, 76), (4, 64, 64, 132), (3, 8, 8, 20)])
+                                           (8, 16, 48, 200), (5, 48, 16, 76), (4, 64, 64, 132), (3, 8, 8, 20),
+                                           # round 6: the wide-tile kernel's second form (128 x 256), its single-tile case, a full
+                                           # 128-multiple shape that stays on the 128 x 128 kernel's unmasked form, one chunk of one k-tile
+                                           (3, 256, 128, 96), (2, 128, 256, 1664), (2, 128, 384, 64), (1, 256, 256, 32)])
 @pytest.mark.parametrize("pro", [0, 1, 2, 3])
 def test_pw_wgrad(Bt, Cin, Cout, L, pro):
     from sudo_rm_rf_amd import ops
