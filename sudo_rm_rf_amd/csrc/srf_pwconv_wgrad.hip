@@ -376,7 +376,12 @@ __global__ __launch_bounds__(512, 4) void srf_pw_wgrad_kernel(WgArgs a) {
 template <int PRO, int BM, int BN>
 __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) char wsmem[];
-  constexpr int NG = BM / 128, NX = BN / 128, NP = NG + NX;      // 8-k packets per thread and k-tile: G rows, X rows
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  // Staging in FULL 128-byte lines: eight lanes load the eight float4 of one row's k-tile, a wavefront instruction covers 8 rows x 128 B
+  // (the first build had four lanes per row, 16 rows x 64 B per instruction -- twice the address / tag work in the texture path for the
+  // same bytes; MI355X guide, "fragment-shaped loads").  Thread -> segment sg = tid & 7 of rows rr + 64 u, u = 0 .. NR - 1, of the
+  // concatenated [G tile rows; X tile rows].
+  constexpr int NGR = BM / 64, NXR = BN / 64, NR = NGR + NXR;     // rows per thread and k-tile: G rows, X rows (6 in all)
   constexpr int IMG_G = BM * WG_PITCH, IMG_X = BN * WG_PITCH;
   constexpr int OFF_GH = 0, OFF_GL = IMG_G, OFF_XH = 2 * IMG_G, OFF_XL = 2 * IMG_G + IMG_X;
   constexpr int STAGE = 2 * (IMG_G + IMG_X);
@@ -398,17 +403,16 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
   const int L = a.L, M = a.M, N = a.N;
   const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
 
-  // staging: thread -> rows r, r + 128 (, ...) of the G tile and of the X tile, 8-k packet pk
-  const int r = tid >> 2, pk = tid & 3;
-  const int lds_off = r * WG_PITCH + pk * 16;
-  float gam[NX], bet[NX];
+  const int rr = tid >> 3, sg = tid & 7;
+  const int lds_off = rr * WG_PITCH + sg * 8;
+  float gam[NXR], bet[NXR];
 #pragma unroll
-  for (int q = 0; q < NX; ++q) {
+  for (int q = 0; q < NXR; ++q) {
     gam[q] = 1.f;
     bet[q] = 0.f;
     if (PRO == 1 || PRO == 2) {
-      gam[q] = a.nrm.gamma[n0 + r + 128 * q];
-      bet[q] = a.nrm.beta[n0 + r + 128 * q];
+      gam[q] = a.nrm.gamma[n0 + rr + 64 * q];
+      bet[q] = a.nrm.beta[n0 + rr + 64 * q];
     }
   }
 
@@ -419,9 +423,9 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  float bsum[NG];
+  float bsum[NGR];
 #pragma unroll
-  for (int q = 0; q < NG; ++q) bsum[q] = 0.f;
+  for (int q = 0; q < NGR; ++q) bsum[q] = 0.f;
   const int frag = (lane & 31) * WG_PITCH + (lane >> 5) * 16;
   const int a_row = (wm * 64) * WG_PITCH + frag, b_row = (wn * 64) * WG_PITCH + frag;
 
@@ -431,9 +435,9 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
     const int l_beg = kc * a.kc_len;
     const int l_end = min(l_beg + a.kc_len, L);
     const int nk = (l_end - l_beg) / WG_BK;
-    float sc[NX], sh[NX];
+    float sc[NXR], sh[NXR];
 #pragma unroll
-    for (int q = 0; q < NX; ++q) {
+    for (int q = 0; q < NXR; ++q) {
       sc[q] = 1.f;
       sh[q] = 0.f;
     }
@@ -441,47 +445,32 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
       float mean, rstd;
       srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
 #pragma unroll
-      for (int q = 0; q < NX; ++q) {
+      for (int q = 0; q < NXR; ++q) {
         sc[q] = gam[q] * rstd;
         sh[q] = bet[q] - mean * sc[q];
       }
     }
-    // uniform bases (SGPRs) + ONE 32-bit per-thread element offset: every load is `global_load_dwordx4 v, v_off, s[base]`, no 64-bit
-    // address pairs held in VGPRs
     const float* gsrc = a.g + ((size_t)b * M + m0) * L + l_beg;
     const float* xsrc = a.x + ((size_t)b * N + n0) * L + l_beg;
-    const unsigned tbyte = ((unsigned)r * (unsigned)L + (unsigned)pk * 8u) * 4u;      // (< 2^31: 128 rows of one example)
-    const size_t row128 = (size_t)128 * L;
+    const unsigned tbyte = ((unsigned)rr * (unsigned)L + (unsigned)sg * 4u) * 4u;      // (< 2^31: 64 rows of one example)
+    const size_t row64 = (size_t)64 * L;
 
     // One register set, as in the 128 x 128 kernel: while tile kt's MFMAs run, tile kt + 1 is split out of it into the other LDS stage and
-    // its packets are re-loaded with tile kt + 2.  (Two sets -- two k-tiles of loads in flight per thread, 96 KB per CU -- were built and
+    // its rows are re-loaded with tile kt + 2.  (Two sets -- two k-tiles of loads in flight per thread, 96 KB per CU -- were built and
     // measured: 250-256 VGPRs with 12-29 spilled in the GlobLN forms, 101 us against 93.5 us for one set at the cfg-2 shapes.)
-    float4 rg[1][NG][2], rx[1][NX][2];
-    auto gload = [&](auto SET, int u, int kt) {        // packet u: G packets first, then X packets
-      constexpr int S = decltype(SET)::value;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (u < NG)
-          rg[S][u < NG ? u : 0][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gsrc + u * row128 + kt * WG_BK + h * 4) + tbyte);
-        else
-          rx[S][u < NG ? 0 : u - NG][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xsrc + (u - NG) * row128 + kt * WG_BK + h * 4) + tbyte);
-      }
+    float4 rv[NR];
+    auto gload = [&](int u, int kt) {        // row u of this thread: G rows first, then X rows
+      const float* base = u < NGR ? gsrc + u * row64 : xsrc + (u - NGR) * row64;
+      rv[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base + kt * WG_BK) + tbyte);
     };
-    // values 2 e, 2 e + 1 of packet u: prologue, hi / lo split into (hi, lo)[2 e, 2 e + 1]
-    auto pair = [&](auto SET, int u, int e, bf16x8& hi, bf16x8& lo) {
-      constexpr int S = decltype(SET)::value;
-      float v0, v1;
-      if (u < NG) {
-        const float4 t = rg[S][u < NG ? u : 0][e >> 1];
-        v0 = (e & 1) ? t.z : t.x;
-        v1 = (e & 1) ? t.w : t.y;
-        bsum[u < NG ? u : 0] += v0;
-        bsum[u < NG ? u : 0] += v1;
+    // values 2 e, 2 e + 1 (e = 0, 1) of row u's float4: prologue, hi / lo split
+    auto pair = [&](int u, int e, bf16x4& hi, bf16x4& lo) {
+      float v0 = e ? rv[u].z : rv[u].x, v1 = e ? rv[u].w : rv[u].y;
+      if (u < NGR) {
+        bsum[u < NGR ? u : 0] += v0;
+        bsum[u < NGR ? u : 0] += v1;
       } else {
-        const int q = u < NG ? 0 : u - NG;
-        const float4 t = rx[S][q][e >> 1];
-        v0 = (e & 1) ? t.z : t.x;
-        v1 = (e & 1) ? t.w : t.y;
+        const int q = u < NGR ? 0 : u - NGR;
         if (PRO == 1 || PRO == 2) {
           v0 = fmaf(v0, sc[q], sh[q]);
           v1 = fmaf(v1, sc[q], sh[q]);
@@ -497,14 +486,14 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
       lo[2 * e] = (__bf16)(v0 - (float)h0);
       lo[2 * e + 1] = (__bf16)(v1 - (float)h1);
     };
-    auto store = [&](int u, int stage, const bf16x8& hi, const bf16x8& lo) {
+    auto store = [&](int u, int stage, const bf16x4& hi, const bf16x4& lo) {
       char* base = wsmem + stage * STAGE + lds_off;
-      if (u < NG) {
-        *reinterpret_cast<bf16x8*>(base + OFF_GH + u * 128 * WG_PITCH) = hi;
-        *reinterpret_cast<bf16x8*>(base + OFF_GL + u * 128 * WG_PITCH) = lo;
+      if (u < NGR) {
+        *reinterpret_cast<bf16x4*>(base + OFF_GH + u * 64 * WG_PITCH) = hi;
+        *reinterpret_cast<bf16x4*>(base + OFF_GL + u * 64 * WG_PITCH) = lo;
       } else {
-        *reinterpret_cast<bf16x8*>(base + OFF_XH + (u - NG) * 128 * WG_PITCH) = hi;
-        *reinterpret_cast<bf16x8*>(base + OFF_XL + (u - NG) * 128 * WG_PITCH) = lo;
+        *reinterpret_cast<bf16x4*>(base + OFF_XH + (u - NGR) * 64 * WG_PITCH) = hi;
+        *reinterpret_cast<bf16x4*>(base + OFF_XL + (u - NGR) * 64 * WG_PITCH) = lo;
       }
     };
     bf16x8 ah[2], al[2], bh[2], bl[2];
@@ -524,10 +513,10 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pass == 0 ? al[i] : ah[i], pass == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
     };
     // One k-tile with the order FIXED (sched_barrier(0)): the 24 MFMAs of tile kt and, after every second one, the split of two of tile
-    // kt + 1's 8 NP values (SPLIT); a packet's registers take tile kt + 2's loads as soon as its last pair has been split (RELOAD).
-    auto step = [&](int kt, auto SET, auto SPLIT, auto RELOAD) {
+    // kt + 1's 4 NR values (SPLIT); a row's register takes tile kt + 2's load as soon as its second pair has been split (RELOAD).
+    auto step = [&](int kt, auto SPLIT, auto RELOAD) {
       const int st = kt & 1;
-      bf16x8 hi, lo;
+      bf16x4 hi, lo;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         frags(st, ks * 32);
@@ -537,12 +526,12 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
           mfma(2 * s6);
           mfma(2 * s6 + 1);
           const int w = ks * 6 + s6;           // work slot 0 .. 11
-          if (decltype(SPLIT)::value && w < 4 * NP) {
-            const int u = w >> 2, e = w & 3;
-            pair(SET, u, e, hi, lo);
-            if (e == 3) {
+          if (decltype(SPLIT)::value && w < 2 * NR) {
+            const int u = w >> 1, e = w & 1;
+            pair(u, e, hi, lo);
+            if (e == 1) {
               store(u, st ^ 1, hi, lo);
-              if (decltype(RELOAD)::value) gload(SET, u, kt + 2);
+              if (decltype(RELOAD)::value) gload(u, kt + 2);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -550,30 +539,29 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
       }
       __syncthreads();
     };
-    using S0 = std::integral_constant<int, 0>;
     using Yes = std::true_type;
     using No = std::false_type;
 
 #pragma unroll
-    for (int u = 0; u < NP; ++u) gload(S0{}, u, 0);
+    for (int u = 0; u < NR; ++u) gload(u, 0);
     __syncthreads();          // the previous chunk's last MFMAs are done with both stages
 #pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      bf16x8 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pair(S0{}, u, e, hi, lo);
+    for (int u = 0; u < NR; ++u) {
+      bf16x4 hi, lo;
+      pair(u, 0, hi, lo);
+      pair(u, 1, hi, lo);
       store(u, 0, hi, lo);
     }
     if (nk > 1) {
 #pragma unroll
-      for (int u = 0; u < NP; ++u) gload(S0{}, u, 1);
+      for (int u = 0; u < NR; ++u) gload(u, 1);
     }
     __syncthreads();
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) step(kt, S0{}, Yes{}, Yes{});
+    for (; kt + 2 < nk; ++kt) step(kt, Yes{}, Yes{});
     for (; kt < nk; ++kt) {
-      if (kt + 1 < nk) step(kt, S0{}, Yes{}, No{});
-      else step(kt, S0{}, No{}, No{});
+      if (kt + 1 < nk) step(kt, Yes{}, No{});
+      else step(kt, No{}, No{});
     }
   }
 
@@ -585,17 +573,18 @@ __global__ __launch_bounds__(512, 2) void srf_pw_wgrad_wide_kernel(WgArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * kh;
-        out[(size_t)(m0 + wm * 64 + i * 32 + row) * N + n0 + wn * 64 + j * 32 + col] = acc[i][j][rr];
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
+        out[(size_t)(m0 + wm * 64 + i * 32 + row) * N + n0 + wn * 64 + j * 32 + col] = acc[i][j][q];
       }
   if (a.bias_part && (tile / a.nMt) == 0) {
 #pragma unroll
-    for (int q = 0; q < NG; ++q) {         // the 4 threads of a row hold disjoint k packets
+    for (int q = 0; q < NGR; ++q) {         // the 8 threads of a row hold disjoint segments
       float t = bsum[q];
       t += __shfl_xor(t, 1, 64);
       t += __shfl_xor(t, 2, 64);
-      if (pk == 0) a.bias_part[(size_t)p * M + m0 + r + 128 * q] = t;
+      t += __shfl_xor(t, 4, 64);
+      if (sg == 0) a.bias_part[(size_t)p * M + m0 + rr + 64 * q] = t;
     }
   }
 }
