@@ -65,6 +65,35 @@ def test_pw_wgrad(Bt, Cin, Cout, L, pro):
     assert rel_err(dw2, 2 * want_w) <= 2e-5 and rel_err(db2, 2 * want_b) <= 2e-5
 
 
+@pytest.mark.parametrize("flags", [1 << 18, (1 << 18) | (1 << 19)])
+@pytest.mark.parametrize("Bt,Cin,Cout,L,pro", [(3, 256, 512, 3200, 2), (2, 512, 256, 832, 0), (2, 128, 256, 1664, 1), (1, 256, 256, 32, 3)])
+def test_pw_wgrad_kernel_forms_agree(Bt, Cin, Cout, L, pro, flags):
+    """Round 6: full shapes run the wide-tile kernel (256 x 128 / 128 x 256); debug flag 1 << 18 keeps them on the 128 x 128 kernel's
+    unmasked form, 1 << 19 on its masked form (what ragged shapes run).  All three against fp64, and against each other."""
+    from sudo_rm_rf_amd import ops
+    x = rnd(Bt, Cin, L, seed=1, scale=1.3, shift=0.2)
+    g = rnd(Bt, Cout, L, seed=2, scale=0.7)
+    gamma, beta = rnd(Cin, seed=3, scale=0.3, shift=1.0), rnd(Cin, seed=4, scale=0.3)
+    slope = torch.tensor([0.17], dtype=torch.float64)
+    fx, kw = x, {}
+    if pro in (1, 2):
+        fx = gln64(x, gamma, beta)
+        kw.update(in_sums=sums64(x), in_gamma=dev32(gamma), in_beta=dev32(beta))
+    if pro in (2, 3):
+        fx = torch.where(fx >= 0, fx, slope * fx)
+        kw.update(in_prelu=dev32(slope))
+    want_w, want_b = torch.einsum("bml,bnl->mn", g, fx), g.sum(dim=(0, 2))
+    dw0, db0 = ops.pw_wgrad(dev32(g), dev32(x), **kw)
+    ops.set_debug_flags(flags)
+    try:
+        dw1, db1 = ops.pw_wgrad(dev32(g), dev32(x), **kw)
+    finally:
+        ops.set_debug_flags(0)
+    for dw, db in ((dw0, db0), (dw1, db1)):
+        assert rel_err(dw, want_w) <= 2e-5 and rel_err(db, want_b) <= 2e-5
+    assert rel_err(dw1, dw0.double().cpu()) <= 1e-5
+
+
 @pytest.mark.parametrize("Bt,C,L", [(3, 64, 3200), (2, 20, 203), (4, 5, 1), (32, 512, 400)])
 @pytest.mark.parametrize("act", [False, True])
 def test_gln_bwd(Bt, C, L, act):

@@ -22,9 +22,9 @@ if [[ $PARTS == *b* ]]; then
     timeout 600 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
   done
   timeout 900 python bench.py --train --steps 10 --warmup 3 > "$OUT/train_cfg2_improved_u16.json" 2> "$OUT/train_cfg2.err"; echo "train rc=$?"; tail -c 300 "$OUT/train_cfg2_improved_u16.json"
-  for w in cfg3_groupcomm_u8 cfg4_improved_u36_n2048; do
-    timeout 600 python bench.py --train --workload $w --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/train_$w.json" 2> "$OUT/train_$w.err"
-  done
+  # (cfg 3 with its cpu_baseline too -- VERDICT r5 next 8; cfg 4's CPU step does not fit the time budget)
+  timeout 900 python bench.py --train --workload cfg3_groupcomm_u8 --steps 5 --warmup 2 > "$OUT/train_cfg3_groupcomm_u8.json" 2> "$OUT/train_cfg3_groupcomm_u8.err"
+  timeout 600 python bench.py --train --workload cfg4_improved_u36_n2048 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/train_cfg4_improved_u36_n2048.json" 2> "$OUT/train_cfg4_improved_u36_n2048.err"
   for w in proj res_conv forward copy; do timeout 120 python tools/power_probe.py $w 3 2>/dev/null | tail -1 >> "$OUT/power.log"; done
 fi
 prof() {   # name, bench args...
