@@ -128,6 +128,7 @@ int srf_profile_timeline(int i, const char** name, float* t_ms, int* stream_inde
  *            over {G_0, y1}): the level-0 conv kernel + the norm's apply pass of rounds 3-5
  *   1<<18    weight-gradient GEMM WITHOUT the wide tile (round 6: 256 x 128 / 128 x 256, one block per CU): the 128 x 128 kernel
  *   1<<19    weight-gradient GEMM, 128 x 128 kernel: the masked form for full shapes too (rounds 3-5)
+ *   1<<20    weight-gradient GEMM, wide tile: 800-column time chunks (several per block) instead of one long chunk per block
  *   1<<21    fused conv pair on persistent blocks (2 per CU, several tiles each) whatever the launch size -- default: one tile per block
  *   1<<23    fused conv pair with every counted wait of its DMA pipeline as a full drain (bisection aid, same results)
  *   1<<22    TAC forward / backward on the VALU kernels instead of the MFMA forms (n = 16, G = 16)

@@ -907,6 +907,13 @@ static void wg_geometry_wide(int form, int M, int N, int L, int Bt, WgArgs* a) {
   }
   a->P = P < 1 ? 1 : P;
   a->xcd_map = (a->P % 8 == 0) ? 1 : 0;
+  // k chunks per block -> one chunk k times as long where the time chunks divide evenly: one pipeline fill per block instead of k
+  // (cfg 2: 2 x 25 k-tiles -> 1 x 50)
+  const int k = nchunks / a->P;
+  if (k >= 2 && nchunks % a->P == 0 && a->nKc % k == 0 && L % (a->kc_len * k) == 0 && !(srf_debug_flags() & (1 << 20))) {
+    a->kc_len *= k;
+    a->nKc /= k;
+  }
 }
 
 extern "C" size_t srf_pw_wgrad_scratch_bytes(int Bt, int Cout, int Cin, int L) {
