@@ -698,10 +698,24 @@ static bool wg_small_ok(int M, int N, int L) {
   return ntile <= 256;
 }
 static int wg_small_lc(int M, int N) { return (M + N) <= 48 ? 256 : ((M + N) <= 96 ? 128 : 64); }
+static size_t wg_small_lds(int M, int N) {
+  const int LC = wg_small_lc(M, N), ntile = (M >> 2) * (N >> 2);
+  const size_t stage = sizeof(float) * (size_t)(M + N) * (LC + 4), red = sizeof(float) * (size_t)(256 / ntile) * ((size_t)M * N + M);
+  return stage > red ? stage : red;
+}
 static int wg_small_blocks(int Bt, int M, int N, int L) {
   const int LC = wg_small_lc(M, N);
   const long pieces = (long)Bt * ((L + LC - 1) / LC);
-  return (int)(pieces < 1024 ? pieces : 1024);
+  // ONE resident round of blocks (round 6): as many as the CUs hold at once by LDS (<= 8 of 4 wavefronts).  The fixed 1024 of rounds
+  // 3-5 were 1.33 rounds at the GroupComm shapes (3 blocks of 50 KB per CU = 768 slots): the last third of the pieces ran on a third
+  // of the chip.  (Debug flag 1 << 18: 1024.)
+  long slots = 1024;
+  if (!(srf_debug_flags() & (1 << 18))) {
+    long per_cu = (long)(160 * 1024 / wg_small_lds(M, N));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    slots = per_cu * srf_device_cus();
+  }
+  return (int)(pieces < slots ? pieces : slots);
 }
 
 // out[m][n] (n < cols_out) = sum_p part[p][m][n]   (part rows have `cols` entries)
@@ -973,10 +987,7 @@ extern "C" int srf_pw_wgrad_ld(const float* g, const float* x, const srf_norm* i
     const int LC = wg_small_lc(Cout, Cin), npl = (L + LC - 1) / LC;
     a.P = wg_small_blocks(Bt, Cout, Cin, L);
     a.bias_part = dbias ? a.part + (size_t)a.P * Cout * Cin : nullptr;
-    size_t lds = sizeof(float) * (size_t)(Cout + Cin) * (LC + 4);
-    const int ntile = (Cout >> 2) * (Cin >> 2);
-    const size_t redb = sizeof(float) * (size_t)(256 / ntile) * ((size_t)Cout * Cin + Cout);
-    if (redb > lds) lds = redb;
+    const size_t lds = wg_small_lds(Cout, Cin);
     dim3 gs((unsigned)a.P), bs(256);
     switch (pro) {
       case 0: hipLaunchKernelGGL(srf_pw_wgrad_small_kernel<0>, gs, bs, lds, st, a, LC, npl); break;
