@@ -611,26 +611,53 @@ __global__ __launch_bounds__(256) void srf_pw_wgrad_small_kernel(WgArgs a, int L
   const float slope = (PRO == 2 || PRO == 3) ? a.nrm.prelu[0] : 1.f;
   float acc[4][4] = {{0.f}};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  // a thread's staging rows do not depend on the piece (see below): their GlobLN affine once, in registers
+  constexpr int NIT = 12;
+  const int nf4 = LC >> 2, sh4 = 31 - __builtin_clz(nf4);      // LC is 64, 128 or 256
+  const int rpi = 256 >> sh4, r0 = threadIdx.x >> sh4, c4 = threadIdx.x & (nf4 - 1);
+  float gam[NIT], bet[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int n = r0 + i * rpi - M;
+    const bool isx = (PRO == 1 || PRO == 2) && n >= 0 && n < N;
+    gam[i] = isx ? a.nrm.gamma[n] : 1.f;
+    bet[i] = isx ? a.nrm.beta[n] : 0.f;
+  }
   const int pieces = a.Bt * npiece_l;
   for (int pc = blockIdx.x; pc < pieces; pc += gridDim.x) {
     const int b = pc / npiece_l, l0 = (pc - b * npiece_l) * LC;
     float mean = 0.f, rstd = 1.f;
     if (PRO == 1 || PRO == 2) srf_finalize_stats(a.nrm.sums, b, a.inv_count, mean, rstd);
     __syncthreads();   // previous piece fully consumed
-    // ---- stage: rows of G then rows of X, float4 along time, zero beyond L
-    const int nf4 = LC >> 2;
-    for (int e = threadIdx.x; e < (M + N) * nf4; e += 256) {
-      const int row = e / nf4, c4 = e - row * nf4;
-      const int l = l0 + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (l < L) {
-        if (row < M) {
-          v = *reinterpret_cast<const float4*>(a.g + ((size_t)b * M + row) * L + l);
-        } else {
-          const int n = row - M;
-          v = *reinterpret_cast<const float4*>(a.x + ((size_t)b * N + n) * L + l);
+    // ---- stage: rows of G then rows of X, float4 along time, zero beyond L.  Round 6: ALL of a thread's loads first (<= 12 float4: up to 48,
+    // 96 or 128 rows of 256, 128 or 64 columns over 256 threads), then the prologue and the LDS stores -- the rolled loop of rounds 3-5 made
+    // twelve dependent round trips to HBM per piece with one float4 in flight per thread (12 KB per CU: 3.3 TB/s by Little's law, which is
+    // what it ran at).
+    // Element e = threadIdx.x + 256 i sits in row (threadIdx.x >> sh4) + i * (256 >> sh4) and -- 256 being a multiple of the 16, 32 or 64
+    // float4 of a row -- always in column c4 = threadIdx.x & (nf4 - 1).
+    const int l = l0 + c4 * 4;
+    const bool l_ok = l < L;
+    const float* gb = a.g + (size_t)b * M * L + l;
+    const float* xb = a.x + (size_t)b * N * L + l;
+    float4 stg[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int row = r0 + i * rpi;
+      stg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M + N && l_ok) {
+        const bool isx = row >= M;
+        const unsigned idx = (unsigned)(isx ? row - M : row) * (unsigned)L;
+        stg[i] = *reinterpret_cast<const float4*>((isx ? xb : gb) + idx);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int row = r0 + i * rpi;
+      if (row < M + N) {
+        float4 v = stg[i];
+        if (row >= M && l_ok) {
           if (PRO == 1 || PRO == 2) {
-            const float sc = a.nrm.gamma[n] * rstd, sh = a.nrm.beta[n] - mean * sc;
+            const float sc = gam[i] * rstd, sh = bet[i] - mean * sc;
             v.x = fmaf(v.x, sc, sh);
             v.y = fmaf(v.y, sc, sh);
             v.z = fmaf(v.z, sc, sh);
@@ -643,8 +670,8 @@ __global__ __launch_bounds__(256) void srf_pw_wgrad_small_kernel(WgArgs a, int L
             v.w = srf_prelu(v.w, slope);
           }
         }
+        *reinterpret_cast<float4*>(wsm + row * pitch + c4 * 4) = v;
       }
-      *reinterpret_cast<float4*>(wsm + row * pitch + c4 * 4) = v;
     }
     __syncthreads();
     if (worker) {
