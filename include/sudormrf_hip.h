@@ -126,7 +126,8 @@ int srf_profile_timeline(int i, const char** name, float* t_ms, int* stream_inde
  *   1<<17    pyramid pass 1 on a grid of co-resident wavefronts, several rows each (rounds 2-5) -- default since round 6: one row per wavefront
  *   1<<16    srf_backward WITHOUT the fused head of the blocks' pyramid backward (round 6: level 0 + proj_1x1's norm as two passes
  *            over {G_0, y1}): the level-0 conv kernel + the norm's apply pass of rounds 3-5
- *   1<<18    weight-gradient GEMM WITHOUT the wide tile (round 6: 256 x 128 / 128 x 256, one block per CU): the 128 x 128 kernel
+ *   1<<18    weight-gradient GEMM WITHOUT the wide tile (round 6: 256 x 128 / 128 x 256, one block per CU): the 128 x 128 kernel;
+ *            small-channel form on a fixed 1024 blocks (rounds 3-5) instead of one resident round
  *   1<<19    weight-gradient GEMM, 128 x 128 kernel: the masked form for full shapes too (rounds 3-5)
  *   1<<20    weight-gradient GEMM, wide tile: 800-column time chunks (several per block) instead of one long chunk per block
  *   1<<21    fused conv pair on persistent blocks (2 per CU, several tiles each) whatever the launch size -- default: one tile per block
